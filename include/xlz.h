@@ -1,0 +1,154 @@
+/*
+ * xlz.h -- C ABI of the MI355X-native batched LZMA / LZMA2 decoder (libxlz.so).
+ *
+ * This is the drop-in boundary for the hot path of kulaginds/lzma:
+ * (*Reader1).decompress (decompress.go:8-1136) and everything it drives
+ * (window.go, state.go, range_decoder.go), plus the LZMA2 chunk framing of
+ * reader2.go:100-298.  The reference is pure Go with no FFI; the entry points
+ * below are what a cgo binding for that path binds (see INTEGRATION.md for the
+ * Go side).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * All compute runs in hand-written HIP kernels on gfx950.  There is NO CPU
+ * decode path in this library: without a usable HIP device every decode entry
+ * point fails with XLZ_ERR_DEVICE.
+ *
+ * file:line citations are into the reference repository.
+ */
+#ifndef XLZ_H
+#define XLZ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XLZ_VERSION_MAJOR 0
+#define XLZ_VERSION_MINOR 1
+
+/* ---- per-stream status -------------------------------------------------- */
+/* >= 0: the reference's reader would have ended with io.EOF (no error).
+ *  < 0: the reference's constructor or Read would have returned an error.   */
+enum {
+    XLZ_OK = 0,                  /* clean end: size reached with Code==0, or end marker
+                                    (decompress.go:14-20,633-641)                               */
+    XLZ_OK_INPUT_EOF = 1,        /* input exhausted; the reference turns ReadByte's io.EOF into a
+                                    normal end of stream (decompress.go:35-38, reader1.go:246)  */
+    XLZ_ERR_RESULT = -1,         /* ErrResultError (errors.go:8)                                 */
+    XLZ_ERR_PROPS = -2,          /* ErrIncorrectProperties (reader1.go:211-213)                  */
+    XLZ_ERR_HEADER_EOF = -3,     /* constructor error: input ended inside the 13-byte header or
+                                    the 5 range-coder init bytes (reader1.go:78-98,153-156)     */
+    XLZ_ERR_RC_INIT = -4,        /* first range-coder byte != 0 (range_decoder.go:32-34)         */
+    XLZ_ERR_UNEXPECTED_EOF = -5, /* io.ErrUnexpectedEOF from LZMA2 framing (reader2.go:104-127)  */
+    XLZ_ERR_OUT_CAP = -6,        /* new: out_cap smaller than the decoded size; out_len==out_cap */
+    XLZ_ERR_BAD_ARG = -7,        /* new: NULL pointer / unknown format                           */
+    XLZ_ERR_DEVICE = -8,         /* new: HIP runtime failure or no gfx950 device                 */
+    XLZ_ERR_UNSUPPORTED = -9,    /* new: stream outside what the GPU path implements (listed in
+                                    DESIGN.md: >= 4 GiB per stream, lc+lp > 6)                  */
+    XLZ_ERR_CLOSED = -10,        /* errAlreadyClosed (readcloser.go:14)                          */
+    XLZ_ERR_NEED_ONE_READER = -11, /* errNeedOneReader (reader1.go:26)                           */
+    XLZ_ERR_INSUFFICIENT_PROPS = -12 /* errInsufficientProperties (reader2.go:43)                */
+};
+
+/* ---- stream formats ------------------------------------------------------ */
+enum {
+    XLZ_FMT_LZMA_ALONE = 0, /* NewReader1: 13-byte header in-band (reader1.go:18-24,77-101)       */
+    XLZ_FMT_LZMA_RAW = 1,   /* NewLZMADecompressorForSevenZip: props byte, dict size and unpack
+                               size out of band (reader1.go:32-61)                               */
+    XLZ_FMT_LZMA2_RAW = 2   /* NewReader2(in, dictSize) (reader2.go:26-41)                        */
+};
+
+typedef struct xlz_stream_desc {
+    const uint8_t *in;    /* compressed bytes (host memory)                                       */
+    size_t in_len;
+    uint8_t *out;         /* host destination; may be NULL for device-resident batches            */
+    size_t out_cap;       /* capacity reserved for this stream's output                           */
+    uint32_t format;      /* XLZ_FMT_*                                                            */
+    uint32_t dict_size;   /* LZMA_RAW: value of DecodeDictSize(props[1:5]); LZMA2_RAW: dictSize
+                             argument of NewReader2 (values < 4096 mean 8 MiB, reader2.go:88-91)  */
+    uint64_t unpack_size; /* LZMA_RAW only; all-ones = unknown (state.go:135-151)                 */
+    uint8_t props;        /* LZMA_RAW only: the lc/lp/pb byte                                     */
+    uint8_t reserved[7];
+} xlz_stream_desc;
+
+typedef struct xlz_result {
+    uint64_t out_len;     /* bytes produced by the decoder (even when status < 0)                 */
+    uint64_t in_consumed; /* input bytes pulled from the source, header included                  */
+    int32_t status;       /* XLZ_OK ... */
+    int32_t reserved;
+} xlz_result;
+
+/* ---- library ------------------------------------------------------------- */
+const char *xlz_version(void);
+const char *xlz_strerror(int status); /* text of the matching reference error (errors.go:5-12)    */
+int xlz_device_count(void);           /* number of HIP devices, 0 if none                         */
+
+/* helpers with the reference's exported names */
+int xlz_decode_prop(uint8_t d, uint8_t *lc, uint8_t *pb, uint8_t *lp); /* DecodeProp reader1.go:210 */
+uint32_t xlz_decode_dict_size(const uint8_t properties[4]);            /* DecodeDictSize   :193    */
+uint32_t xlz_decode_dict_size2(uint8_t encoded);                       /* DecodeDictSize2 reader2.go:296 */
+uint64_t xlz_decode_unpack_size(const uint8_t header[8]);              /* DecodeUnpackSize :178    */
+
+/* ---- context: one per (host thread, GPU) ---------------------------------- */
+typedef struct xlz_ctx xlz_ctx;
+int xlz_ctx_create(int device, xlz_ctx **ctx); /* XLZ_OK or XLZ_ERR_DEVICE                         */
+void xlz_ctx_destroy(xlz_ctx *ctx);
+int xlz_ctx_device(const xlz_ctx *ctx);
+
+/* ---- one-shot batch decode: host buffers in, host buffers out -------------- */
+/* Replaces a loop of `r, _ := NewReader1(src); io.Copy(dst, r)` over n independent
+ * streams (reader1_test.go:76-80).  One bad stream never fails the batch: the return
+ * value is XLZ_OK unless the call itself could not run; per-stream outcomes are in
+ * results[i].  Thread-safe across contexts; calls on one context are serialised.   */
+int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_result *results);
+
+/* ---- device-resident batch: upload once, decode many times ---------------- */
+typedef struct xlz_batch xlz_batch;
+/* Parses headers / LZMA2 framing on the host, uploads the compressed bytes and
+ * allocates the output arena in HBM.  streams[i].out may be NULL.                 */
+int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **batch);
+int xlz_batch_run(xlz_batch *batch);  /* enqueue one full decode pass on the context's stream     */
+int xlz_batch_sync(xlz_batch *batch); /* wait for everything enqueued so far                      */
+int xlz_batch_results(xlz_batch *batch, xlz_result *results); /* sync + fetch per-stream results  */
+int xlz_batch_download(xlz_batch *batch, size_t i, uint8_t *dst, size_t cap); /* copy out stream i */
+int xlz_batch_device_output(xlz_batch *batch, size_t i, void **dptr, size_t *cap);
+/* HIP-event time of the decode kernel(s) of the most recent completed run, in ms */
+int xlz_batch_last_kernel_ms(xlz_batch *batch, float *ms);
+/* algorithmic bytes (compressed in + decoded out) the last run moved, and units  */
+int xlz_batch_stats(xlz_batch *batch, uint64_t *in_bytes, uint64_t *out_bytes, uint64_t *units);
+void xlz_batch_destroy(xlz_batch *batch);
+
+/* ---- pull-style readers mirroring the reference's Go surface --------------- */
+/* The GPU needs the whole compressed stream, so constructors take it as a buffer
+ * (a Go shim slurps its io.Reader first).  Constructor-time errors are the ones
+ * the reference's constructors return; decode errors surface from xlz_reader_read
+ * once all bytes produced before the error have been delivered.                  */
+typedef struct xlz_reader xlz_reader;
+xlz_reader *xlz_new_reader1(xlz_ctx *ctx, const uint8_t *in, size_t in_len, int *err); /* NewReader1 */
+xlz_reader *xlz_new_reader2(xlz_ctx *ctx, const uint8_t *in, size_t in_len, int dict_size,
+                            int *err);                                              /* NewReader2 */
+/* NewLZMADecompressorForSevenZip(props, unpackSize, readers) reader1.go:32-61 */
+xlz_reader *xlz_new_lzma_decompressor_for_sevenzip(xlz_ctx *ctx, const uint8_t *props,
+                                                   size_t props_len, uint64_t unpack_size,
+                                                   const uint8_t *const *readers,
+                                                   const size_t *reader_lens, size_t n_readers,
+                                                   int *err);
+/* NewLZMA2DecompressorForSevenZip(props, _, readers) reader2.go:49-75 */
+xlz_reader *xlz_new_lzma2_decompressor_for_sevenzip(xlz_ctx *ctx, const uint8_t *props,
+                                                    size_t props_len, uint64_t unpack_size,
+                                                    const uint8_t *const *readers,
+                                                    const size_t *reader_lens, size_t n_readers,
+                                                    int *err);
+/* Read(p): returns bytes copied (>= 0).  *err: XLZ_OK while more may follow;
+ * XLZ_EOF at end of stream; a negative status on error.                          */
+#define XLZ_EOF 100
+long xlz_reader_read(xlz_reader *r, uint8_t *p, size_t n, int *err);
+int xlz_reader_close(xlz_reader *r); /* readCloser.Close (readcloser.go:16-28); second call ->
+                                        XLZ_ERR_CLOSED; the handle stays valid until _free       */
+void xlz_reader_free(xlz_reader *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XLZ_H */

@@ -1,0 +1,312 @@
+"""lzma_amd -- MI355X-native batched LZMA / LZMA2 decoder.
+
+Host-side mirror of the reference's Go surface (kulaginds/lzma: NewReader1,
+NewReader2, the bodgit/sevenzip decompressor constructors and the exported
+Decode* helpers) on top of the C ABI in include/xlz.h.  All decoding happens in
+hand-written HIP kernels (lzma_amd/csrc); this package only marshals buffers.
+It fails loudly when libxlz.so or a GPU is missing -- there is no CPU fallback.
+"""
+import ctypes
+
+from . import _native as N
+from ._native import (EOF, ERR_BAD_ARG, ERR_CLOSED, ERR_DEVICE, ERR_HEADER_EOF,  # noqa: F401
+                      ERR_INSUFFICIENT_PROPS, ERR_NEED_ONE_READER, ERR_OUT_CAP, ERR_PROPS,
+                      ERR_RC_INIT, ERR_RESULT, ERR_UNEXPECTED_EOF, ERR_UNSUPPORTED,
+                      FMT_LZMA2_RAW, FMT_LZMA_ALONE, FMT_LZMA_RAW, OK, OK_INPUT_EOF, UNKNOWN_SIZE)
+
+
+class LzmaError(Exception):
+    """A reference error value (errors.go:5-12 and friends) carried as a status code."""
+
+    def __init__(self, status, where=""):
+        self.status = status
+        msg = N.strerror(status)
+        super().__init__("%s%s" % (where + ": " if where else "", msg))
+
+
+# the reference's sentinels, as statuses
+ErrResultError = ERR_RESULT                  # errors.go:8
+ErrIncorrectProperties = ERR_PROPS           # errors.go:7
+ErrUnexpectedEOF = ERR_UNEXPECTED_EOF        # io.ErrUnexpectedEOF (reader2.go:104-127)
+
+
+class Stream:
+    """One compressed stream of a batch (xlz_stream_desc)."""
+
+    def __init__(self, data, fmt=FMT_LZMA_ALONE, out_cap=None, dict_size=0, unpack_size=UNKNOWN_SIZE,
+                 props=0):
+        self.data = bytes(data)
+        self.fmt = fmt
+        self.dict_size = dict_size
+        self.unpack_size = unpack_size
+        self.props = props
+        if out_cap is None:
+            out_cap = self._guess_cap()
+        self.out_cap = out_cap
+
+    def _guess_cap(self):
+        if self.fmt == FMT_LZMA_ALONE and len(self.data) >= 13:
+            u = int.from_bytes(self.data[5:13], "little")
+            if u != UNKNOWN_SIZE:
+                return u
+        if self.fmt == FMT_LZMA_RAW and self.unpack_size != UNKNOWN_SIZE:
+            return self.unpack_size
+        raise ValueError("out_cap is required when the stream does not carry its size")
+
+
+class Context:
+    """One HIP device + stream (xlz_ctx).  One per host thread and GPU."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        st = N.lib().xlz_ctx_create(device, ctypes.byref(self._h))
+        if st != OK:
+            raise LzmaError(st, "xlz_ctx_create(device=%d)" % device)
+
+    def close(self):
+        if self._h:
+            N.lib().xlz_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _make_descs(streams, with_out=True):
+    n = len(streams)
+    descs = (N.StreamDesc * n)()
+    keep_in, outs = [], []
+    for i, s in enumerate(streams):
+        ib = ctypes.create_string_buffer(s.data, len(s.data)) if len(s.data) else ctypes.create_string_buffer(1)
+        keep_in.append(ib)
+        descs[i].inp = ctypes.cast(ib, ctypes.c_void_p)
+        descs[i].in_len = len(s.data)
+        if with_out:
+            ob = ctypes.create_string_buffer(max(int(s.out_cap), 1))
+            outs.append(ob)
+            descs[i].out = ctypes.cast(ob, ctypes.c_void_p)
+        descs[i].out_cap = int(s.out_cap)
+        descs[i].format = s.fmt
+        descs[i].dict_size = s.dict_size & 0xFFFFFFFF
+        descs[i].unpack_size = s.unpack_size
+        descs[i].props = s.props
+    return descs, keep_in, outs
+
+
+def decode_batch(ctx, streams):
+    """Decode independent streams on the GPU.
+
+    Returns a list of (output bytes, status, in_consumed).  A bad stream never
+    fails the batch; the call raises only if it could not run at all.
+    """
+    streams = list(streams)
+    n = len(streams)
+    if n == 0:
+        return []
+    descs, keep, outs = _make_descs(streams)
+    res = (N.Result * n)()
+    st = N.lib().xlz_decode_batch(ctx._h, descs, n, res)
+    if st != OK:
+        raise LzmaError(st, "xlz_decode_batch")
+    del keep
+    return [(outs[i].raw[: res[i].out_len], res[i].status, res[i].in_consumed) for i in range(n)]
+
+
+class Batch:
+    """Device-resident batch: upload once, run many times (xlz_batch)."""
+
+    def __init__(self, ctx, streams):
+        self.ctx = ctx
+        self.streams = list(streams)
+        self.n = len(self.streams)
+        descs, keep, _ = _make_descs(self.streams, with_out=False)
+        self._h = ctypes.c_void_p()
+        st = N.lib().xlz_batch_create(ctx._h, descs, self.n, ctypes.byref(self._h))
+        if st != OK:
+            raise LzmaError(st, "xlz_batch_create")
+
+    def run(self):
+        st = N.lib().xlz_batch_run(self._h)
+        if st != OK:
+            raise LzmaError(st, "xlz_batch_run")
+
+    def sync(self):
+        st = N.lib().xlz_batch_sync(self._h)
+        if st != OK:
+            raise LzmaError(st, "xlz_batch_sync")
+
+    def kernel_ms(self):
+        ms = ctypes.c_float()
+        st = N.lib().xlz_batch_last_kernel_ms(self._h, ctypes.byref(ms))
+        if st != OK:
+            raise LzmaError(st, "xlz_batch_last_kernel_ms")
+        return ms.value
+
+    def results(self):
+        res = (N.Result * max(self.n, 1))()
+        st = N.lib().xlz_batch_results(self._h, res)
+        if st != OK:
+            raise LzmaError(st, "xlz_batch_results")
+        return [(res[i].out_len, res[i].status, res[i].in_consumed) for i in range(self.n)]
+
+    def stats(self):
+        a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        st = N.lib().xlz_batch_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        if st != OK:
+            raise LzmaError(st, "xlz_batch_stats")
+        return a.value, b.value, c.value
+
+    def download(self, i, length):
+        buf = ctypes.create_string_buffer(max(int(length), 1))
+        st = N.lib().xlz_batch_download(self._h, i, ctypes.cast(buf, ctypes.c_void_p), int(length))
+        if st != OK:
+            raise LzmaError(st, "xlz_batch_download")
+        return buf.raw[:length]
+
+    def device_output(self, i):
+        p, cap = ctypes.c_void_p(), ctypes.c_size_t()
+        st = N.lib().xlz_batch_device_output(self._h, i, ctypes.byref(p), ctypes.byref(cap))
+        if st != OK:
+            raise LzmaError(st, "xlz_batch_device_output")
+        return p.value, cap.value
+
+    def close(self):
+        if self._h:
+            N.lib().xlz_batch_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- exported helpers with the reference's names -------------------------------
+def DecodeProp(d):
+    """reader1.go:210-221 -> (lc, pb, lp); raises LzmaError(ErrIncorrectProperties)."""
+    lc, pb, lp = ctypes.c_uint8(), ctypes.c_uint8(), ctypes.c_uint8()
+    st = N.lib().xlz_decode_prop(d, ctypes.byref(lc), ctypes.byref(pb), ctypes.byref(lp))
+    if st != OK:
+        raise LzmaError(st)
+    return lc.value, pb.value, lp.value
+
+
+def DecodeDictSize(properties):
+    """reader1.go:193-208"""
+    return N.lib().xlz_decode_dict_size(bytes(properties[:4]))
+
+
+def DecodeDictSize2(encoded):
+    """reader2.go:296-298"""
+    return N.lib().xlz_decode_dict_size2(encoded)
+
+
+def DecodeUnpackSize(header):
+    """reader1.go:178-191"""
+    return N.lib().xlz_decode_unpack_size(bytes(header[:8]))
+
+
+# ---- pull-style readers ----------------------------------------------------------
+class io_EOF:  # sentinel standing in for Go's io.EOF
+    pass
+
+
+class _Reader:
+    def __init__(self, ctx, handle):
+        self._ctx = ctx
+        self._h = ctypes.c_void_p(handle)
+
+    def Read(self, n):
+        """Go's Read(p []byte): returns (bytes, err) with err None, io_EOF or LzmaError."""
+        buf = ctypes.create_string_buffer(max(n, 1))
+        err = ctypes.c_int()
+        got = N.lib().xlz_reader_read(self._h, ctypes.cast(buf, ctypes.c_void_p), n, ctypes.byref(err))
+        e = None
+        if err.value == EOF:
+            e = io_EOF
+        elif err.value != OK:
+            e = LzmaError(err.value, "lzma: error reading" if self._is_closer else "")
+        return buf.raw[:got], e
+
+    def read_all(self, chunk=32768):
+        """io.Copy(dst, r): returns (bytes, err) where err is None at io.EOF."""
+        out = []
+        while True:
+            b, e = self.Read(chunk)
+            out.append(b)
+            if e is io_EOF:
+                return b"".join(out), None
+            if e is not None:
+                return b"".join(out), e
+
+    def Close(self):
+        """readCloser.Close (readcloser.go:16-28)."""
+        st = N.lib().xlz_reader_close(self._h)
+        if st != OK:
+            return LzmaError(st)
+        return None
+
+    _is_closer = False
+
+    def __del__(self):
+        try:
+            if self._h:
+                N.lib().xlz_reader_free(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+
+class Reader1(_Reader):
+    pass
+
+
+class Reader2(_Reader):
+    pass
+
+
+class ReadCloser(_Reader):
+    _is_closer = True
+
+
+def NewReader1(ctx, data):
+    """NewReader1(inStream) (reader1.go:18-24): returns (reader, err)."""
+    err = ctypes.c_int()
+    h = N.lib().xlz_new_reader1(ctx._h, bytes(data), len(data), ctypes.byref(err))
+    if not h:
+        return None, LzmaError(err.value)
+    return Reader1(ctx, h), None
+
+
+def NewReader2(ctx, data, dict_size):
+    """NewReader2(inStream, dictSize) (reader2.go:26-41): returns (reader, err)."""
+    err = ctypes.c_int()
+    h = N.lib().xlz_new_reader2(ctx._h, bytes(data), len(data), dict_size, ctypes.byref(err))
+    if not h:
+        return None, LzmaError(err.value)
+    return Reader2(ctx, h), None
+
+
+def _sevenzip(fn, ctx, props, unpack_size, readers):
+    n = len(readers)
+    arr = (ctypes.c_char_p * max(n, 1))(*[bytes(r) for r in readers])
+    lens = (ctypes.c_size_t * max(n, 1))(*[len(r) for r in readers])
+    err = ctypes.c_int()
+    h = fn(ctx._h, bytes(props), len(props), unpack_size, arr, lens, n, ctypes.byref(err))
+    if not h:
+        return None, LzmaError(err.value)
+    return ReadCloser(ctx, h), None
+
+
+def NewLZMADecompressorForSevenZip(ctx, props, unpack_size, readers):
+    """reader1.go:32-61: props = props byte + LE32 dict size; exactly one reader."""
+    return _sevenzip(N.lib().xlz_new_lzma_decompressor_for_sevenzip, ctx, props, unpack_size, readers)
+
+
+def NewLZMA2DecompressorForSevenZip(ctx, props, unpack_size, readers):
+    """reader2.go:49-75: props = one dict-size byte; exactly one reader."""
+    return _sevenzip(N.lib().xlz_new_lzma2_decompressor_for_sevenzip, ctx, props, unpack_size, readers)

@@ -1,0 +1,128 @@
+"""ctypes binding of libxlz.so (the C ABI declared in include/xlz.h).
+
+There is no Python or CPU decode path behind this module: if the HIP library is
+missing or no GPU is usable, calls fail loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libxlz.so")
+
+# status codes (include/xlz.h)
+OK = 0
+OK_INPUT_EOF = 1
+ERR_RESULT = -1
+ERR_PROPS = -2
+ERR_HEADER_EOF = -3
+ERR_RC_INIT = -4
+ERR_UNEXPECTED_EOF = -5
+ERR_OUT_CAP = -6
+ERR_BAD_ARG = -7
+ERR_DEVICE = -8
+ERR_UNSUPPORTED = -9
+ERR_CLOSED = -10
+ERR_NEED_ONE_READER = -11
+ERR_INSUFFICIENT_PROPS = -12
+EOF = 100
+
+FMT_LZMA_ALONE = 0
+FMT_LZMA_RAW = 1
+FMT_LZMA2_RAW = 2
+
+UNKNOWN_SIZE = 0xFFFFFFFFFFFFFFFF
+
+# every symbol include/xlz.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "xlz_version", "xlz_strerror", "xlz_device_count", "xlz_decode_prop", "xlz_decode_dict_size",
+    "xlz_decode_dict_size2", "xlz_decode_unpack_size", "xlz_ctx_create", "xlz_ctx_destroy",
+    "xlz_ctx_device", "xlz_decode_batch", "xlz_batch_create", "xlz_batch_run", "xlz_batch_sync",
+    "xlz_batch_results", "xlz_batch_download", "xlz_batch_device_output", "xlz_batch_last_kernel_ms",
+    "xlz_batch_stats", "xlz_batch_destroy", "xlz_new_reader1", "xlz_new_reader2",
+    "xlz_new_lzma_decompressor_for_sevenzip", "xlz_new_lzma2_decompressor_for_sevenzip",
+    "xlz_reader_read", "xlz_reader_close", "xlz_reader_free",
+]
+
+
+class StreamDesc(ctypes.Structure):
+    _fields_ = [
+        ("inp", ctypes.c_void_p),
+        ("in_len", ctypes.c_size_t),
+        ("out", ctypes.c_void_p),
+        ("out_cap", ctypes.c_size_t),
+        ("format", ctypes.c_uint32),
+        ("dict_size", ctypes.c_uint32),
+        ("unpack_size", ctypes.c_uint64),
+        ("props", ctypes.c_uint8),
+        ("reserved", ctypes.c_uint8 * 7),
+    ]
+
+
+class Result(ctypes.Structure):
+    _fields_ = [
+        ("out_len", ctypes.c_uint64),
+        ("in_consumed", ctypes.c_uint64),
+        ("status", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load libxlz.so; raises if it has not been built (lzma_amd.build.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            "lzma_amd: %s is missing -- build the HIP extension first "
+            "(python -m lzma_amd.build); there is no CPU fallback" % SO_PATH)
+    L = ctypes.CDLL(SO_PATH)
+    vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    L.xlz_version.restype = ctypes.c_char_p
+    L.xlz_strerror.restype = ctypes.c_char_p
+    L.xlz_strerror.argtypes = [i32]
+    L.xlz_device_count.restype = i32
+    L.xlz_decode_prop.argtypes = [ctypes.c_uint8] + [ctypes.POINTER(ctypes.c_uint8)] * 3
+    L.xlz_decode_dict_size.restype = ctypes.c_uint32
+    L.xlz_decode_dict_size.argtypes = [ctypes.c_char_p]
+    L.xlz_decode_dict_size2.restype = ctypes.c_uint32
+    L.xlz_decode_dict_size2.argtypes = [ctypes.c_uint8]
+    L.xlz_decode_unpack_size.restype = ctypes.c_uint64
+    L.xlz_decode_unpack_size.argtypes = [ctypes.c_char_p]
+    L.xlz_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
+    L.xlz_ctx_destroy.argtypes = [vp]
+    L.xlz_ctx_destroy.restype = None
+    L.xlz_ctx_device.argtypes = [vp]
+    L.xlz_decode_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), sz, ctypes.POINTER(Result)]
+    L.xlz_batch_create.argtypes = [vp, ctypes.POINTER(StreamDesc), sz, ctypes.POINTER(vp)]
+    L.xlz_batch_run.argtypes = [vp]
+    L.xlz_batch_sync.argtypes = [vp]
+    L.xlz_batch_results.argtypes = [vp, ctypes.POINTER(Result)]
+    L.xlz_batch_download.argtypes = [vp, sz, vp, sz]
+    L.xlz_batch_device_output.argtypes = [vp, sz, ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    L.xlz_batch_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.xlz_batch_stats.argtypes = [vp] + [ctypes.POINTER(ctypes.c_uint64)] * 3
+    L.xlz_batch_destroy.argtypes = [vp]
+    L.xlz_batch_destroy.restype = None
+    L.xlz_new_reader1.restype = vp
+    L.xlz_new_reader1.argtypes = [vp, ctypes.c_char_p, sz, ctypes.POINTER(i32)]
+    L.xlz_new_reader2.restype = vp
+    L.xlz_new_reader2.argtypes = [vp, ctypes.c_char_p, sz, i32, ctypes.POINTER(i32)]
+    for f in (L.xlz_new_lzma_decompressor_for_sevenzip, L.xlz_new_lzma2_decompressor_for_sevenzip):
+        f.restype = vp
+        f.argtypes = [vp, ctypes.c_char_p, sz, ctypes.c_uint64, ctypes.POINTER(ctypes.c_char_p),
+                      ctypes.POINTER(sz), sz, ctypes.POINTER(i32)]
+    L.xlz_reader_read.restype = ctypes.c_long
+    L.xlz_reader_read.argtypes = [vp, vp, sz, ctypes.POINTER(i32)]
+    L.xlz_reader_close.argtypes = [vp]
+    L.xlz_reader_free.argtypes = [vp]
+    L.xlz_reader_free.restype = None
+    _lib = L
+    return L
+
+
+def strerror(status):
+    return lib().xlz_strerror(status).decode()

@@ -1,0 +1,45 @@
+"""Builds lzma_amd/libxlz.so (host C ABI + gfx950 kernels) with hipcc, in-tree.
+
+hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but
+travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libxlz.so")
+SOURCES = ["xlz_kernel.hip", "xlz_host.hip"]
+HEADERS = ["xlz_format.h", os.path.join("..", "..", "include", "xlz.h")]
+ARCH = "gfx950"
+
+
+def _stale():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile every HIP source for gfx950 into lzma_amd/libxlz.so."""
+    if not force and not _stale():
+        return SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+           "-I", os.path.join(HERE, "..", "include")]
+    cmd += list(extra_flags)
+    cmd += [os.path.join(CSRC, f) for f in SOURCES]
+    cmd += ["-o", SO]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(SO)

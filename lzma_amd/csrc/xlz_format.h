@@ -1,0 +1,97 @@
+// xlz_format.h -- structures and constants shared by the host library and the
+// gfx950 kernels.  Names follow the reference's domain (state.go, types.go).
+#pragma once
+#include <stdint.h>
+
+namespace xlz {
+
+// ---- probability-table layout in LDS (units: 16-bit probs) ------------------
+// Same inventory as the reference's `state` struct (state.go:3-27); the order is
+// ours.  Every bit-tree base is a multiple of 4 probs (8 bytes) so that a node's
+// two children / four grandchildren sit in one aligned LDS word / double word.
+constexpr uint32_t kNumStates = 12;      // types.go:17
+constexpr uint32_t kPosBitsMax = 4;      // types.go:15
+constexpr uint32_t P_IS_MATCH = 0;       // [12 << 4]   index (state << 4) + posState
+constexpr uint32_t P_IS_REP = 192;       // [12]
+constexpr uint32_t P_IS_REP_G0 = 204;    // [12]
+constexpr uint32_t P_IS_REP_G1 = 216;    // [12]
+constexpr uint32_t P_IS_REP_G2 = 228;    // [12]
+constexpr uint32_t P_IS_REP0_LONG = 240; // [12 << 4]
+constexpr uint32_t P_POS_SLOT = 432;     // [4][64]
+constexpr uint32_t P_POS_DEC = 688;      // [115] (+1 pad) posDecoders, state.go:7
+constexpr uint32_t P_ALIGN = 804;        // [16]
+// length coder: choice, choice2, 2 pad, low[16][8], mid[16][8], high[256]
+constexpr uint32_t LEN_CHOICE = 0;
+constexpr uint32_t LEN_CHOICE2 = 1;
+constexpr uint32_t LEN_LOW = 4;
+constexpr uint32_t LEN_MID = 4 + 128;
+constexpr uint32_t LEN_HIGH = 4 + 256;
+constexpr uint32_t LEN_CODER_SIZE = 4 + 256 + 256; // 516
+constexpr uint32_t P_LEN = 820;
+constexpr uint32_t P_REP_LEN = P_LEN + LEN_CODER_SIZE; // 1336
+constexpr uint32_t P_LIT = P_REP_LEN + LEN_CODER_SIZE; // 1852; litProbs 0x300 << (lc+lp)
+constexpr uint32_t kLitCoderSize = 0x300;
+
+static inline constexpr uint32_t num_probs(uint32_t lc_plus_lp) { return P_LIT + (kLitCoderSize << lc_plus_lp); }
+
+constexpr uint32_t kMaxLdsBytes = 160u * 1024u; // MI355X LDS per CU
+constexpr uint32_t kWave = 64;
+
+// ---- unit of work: one LZMA1 stream, or one run of LZMA2 chunks ------------
+enum : uint32_t {
+    UNIT_LZMA1 = 0, // payload starts at the first range-coder byte (header already parsed)
+    UNIT_LZMA2 = 2  // payload starts at an LZMA2 control byte; the wave walks the chunks
+};
+
+struct Unit {
+    uint64_t in_off;      // byte offset of the payload in the input arena
+    uint64_t out_off;     // byte offset of this unit's output in the output arena
+    uint64_t unpack_size; // LZMA1: header size, all-ones = undefined (state.go:135-151)
+    uint32_t in_len;      // payload bytes available to this unit
+    uint32_t out_cap;     // bytes this unit may write
+    uint32_t dict_size;   // window size (already clamped the way the reference clamps it)
+    uint32_t stream;      // index of the parent stream
+    uint8_t lc, lp, pb, kind;
+    uint32_t flags;
+    uint32_t expect_out;  // LZMA2: output the host scan predicts for this unit
+    uint32_t pad0;
+    uint64_t pad1;
+};
+static_assert(sizeof(Unit) == 64, "Unit must stay 64 bytes");
+
+struct UnitResult {
+    uint32_t out_len;
+    uint32_t in_consumed;
+    int32_t status;
+    uint32_t aux; // LZMA2: bit0 = unit ended on the end-of-stream control byte
+};
+
+// device-side status values = include/xlz.h
+enum : int32_t {
+    ST_OK = 0,
+    ST_OK_INPUT_EOF = 1,
+    ST_ERR_RESULT = -1,
+    ST_ERR_PROPS = -2,
+    ST_ERR_HEADER_EOF = -3,
+    ST_ERR_RC_INIT = -4,
+    ST_ERR_UNEXPECTED_EOF = -5,
+    ST_ERR_OUT_CAP = -6,
+    ST_ERR_UNSUPPORTED = -9
+};
+
+struct LaunchParams {
+    const uint8_t *in_arena;
+    uint8_t *out_arena;
+    const Unit *units;
+    const uint32_t *order; // work-queue order (heaviest first)
+    UnitResult *results;
+    uint32_t *queue;       // one zeroed word per launch
+    uint32_t n_units;
+    uint32_t max_lc_lp;    // sizes the dynamic LDS
+};
+
+// implemented in xlz_kernel.hip
+int launch_decode(const LaunchParams &p, int num_cus, void *stream /* hipStream_t */);
+uint32_t decode_lds_bytes(uint32_t max_lc_lp);
+
+} // namespace xlz

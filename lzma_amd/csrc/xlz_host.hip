@@ -1,0 +1,726 @@
+// xlz_host.hip -- host side of libxlz.so: the C ABI of include/xlz.h.
+//
+// Host work is limited to what the reference does outside its hot loop:
+// parsing the 13-byte .lzma header (reader1.go:77-147), scanning LZMA2 chunk
+// headers to place units (reader2.go:100-214), moving bytes to and from HBM and
+// launching the gfx950 kernels.  No byte of any stream is DECODED on the host:
+// if no HIP device is usable every decode entry point returns XLZ_ERR_DEVICE.
+//
+// file:line citations are into the reference repository (kulaginds/lzma).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <numeric>
+#include <vector>
+
+#include "../../include/xlz.h"
+#include "xlz_format.h"
+
+using namespace xlz;
+
+namespace {
+
+constexpr uint32_t kLzmaDicMin = 1u << 12;        // types.go:8
+constexpr uint64_t kUnknownSize = ~(uint64_t)0;   // state.go:135-151
+constexpr uint64_t kMaxUnitBytes = 0xFFFF0000ull; // 32-bit offsets inside a unit
+constexpr size_t kArenaAlign = 256;
+constexpr size_t kArenaTailPad = 256; // the input reader runs up to 16 bytes ahead
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            if (getenv("XLZ_DEBUG"))                                                              \
+                fprintf(stderr, "xlz: %s failed: %s\n", #expr, hipGetErrorString(e_));            \
+            return XLZ_ERR_DEVICE;                                                                \
+        }                                                                                         \
+    } while (0)
+
+} // namespace
+
+struct xlz_ctx {
+    int device = 0;
+    int num_cus = 0;
+    hipStream_t stream = nullptr;
+    uint32_t *queue = nullptr; // work-queue head, re-zeroed on the stream before each launch
+    std::mutex mu;
+};
+
+// per-stream bookkeeping of a batch
+struct StreamPlan {
+    int32_t host_status = 1; // 1 = decided on the device; otherwise final status from parsing
+    uint64_t host_in_consumed = 0;
+    uint32_t header_len = 0;
+    uint32_t first_unit = 0, n_units = 0;
+    uint64_t out_off = 0; // into the output arena
+    uint64_t out_cap = 0; // arena bytes reserved
+};
+
+struct xlz_batch {
+    xlz_ctx *ctx = nullptr;
+    size_t n = 0;
+    std::vector<StreamPlan> plans;
+    std::vector<Unit> units;
+    std::vector<uint32_t> order;
+    uint8_t *d_in = nullptr;
+    uint8_t *d_out = nullptr;
+    Unit *d_units = nullptr;
+    uint32_t *d_order = nullptr;
+    UnitResult *d_results = nullptr;
+    size_t in_bytes = 0, out_bytes = 0;
+    uint32_t max_lc_lp = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ran = false;
+    uint64_t algo_in = 0; // compressed payload bytes handed to the device
+};
+
+// ---------------------------------------------------------------- helpers ----
+extern "C" const char *xlz_version(void) { return "xlz 0.1 (gfx950)"; }
+
+extern "C" const char *xlz_strerror(int st)
+{
+    switch (st) {
+    case XLZ_OK: return "ok";
+    case XLZ_OK_INPUT_EOF: return "ok (input ended; reference reports io.EOF)";
+    case XLZ_ERR_RESULT: return "result error";                            // errors.go:8
+    case XLZ_ERR_PROPS: return "incorrect LZMA properties";                // errors.go:7
+    case XLZ_ERR_HEADER_EOF: return "EOF";                                 // io.EOF out of a constructor
+    case XLZ_ERR_RC_INIT: return "rangeDec.Init: result error";            // reader1.go:155
+    case XLZ_ERR_UNEXPECTED_EOF: return "unexpected EOF";                  // io.ErrUnexpectedEOF
+    case XLZ_ERR_OUT_CAP: return "output capacity too small";
+    case XLZ_ERR_BAD_ARG: return "bad argument";
+    case XLZ_ERR_DEVICE: return "HIP device error";
+    case XLZ_ERR_UNSUPPORTED: return "stream not supported by the GPU path";
+    case XLZ_ERR_CLOSED: return "lzma: already closed";                    // readcloser.go:14
+    case XLZ_ERR_NEED_ONE_READER: return "lzma: need exactly one reader";  // reader1.go:26
+    case XLZ_ERR_INSUFFICIENT_PROPS: return "lzma2: not enough properties"; // reader2.go:43
+    case XLZ_EOF: return "EOF";
+    }
+    return "unknown status";
+}
+
+extern "C" int xlz_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// DecodeProp, reader1.go:210-221
+extern "C" int xlz_decode_prop(uint8_t d, uint8_t *lc, uint8_t *pb, uint8_t *lp)
+{
+    if (d >= 9 * 5 * 5) return XLZ_ERR_PROPS;
+    if (lc) *lc = d % 9;
+    d /= 9;
+    if (pb) *pb = d / 5;
+    if (lp) *lp = d % 5;
+    return XLZ_OK;
+}
+
+// DecodeDictSize, reader1.go:193-208
+extern "C" uint32_t xlz_decode_dict_size(const uint8_t p[4])
+{
+    uint32_t d = 0;
+    for (int i = 0; i < 4; i++) d |= (uint32_t)p[i] << (8 * i);
+    return d < kLzmaDicMin ? kLzmaDicMin : d;
+}
+
+// DecodeDictSize2, reader2.go:296-298
+extern "C" uint32_t xlz_decode_dict_size2(uint8_t b)
+{
+    const unsigned sh = (unsigned)(b / 2 + 11);
+    return sh >= 32 ? 0u : (uint32_t)(2u | (b & 1u)) << sh;
+}
+
+// DecodeUnpackSize, reader1.go:178-191
+extern "C" uint64_t xlz_decode_unpack_size(const uint8_t h[8])
+{
+    uint64_t u = 0;
+    for (int i = 0; i < 8; i++) u |= (uint64_t)h[i] << (8 * i);
+    return u;
+}
+
+// ---------------------------------------------------------------- context ----
+extern "C" int xlz_ctx_create(int device, xlz_ctx **out)
+{
+    if (!out) return XLZ_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return XLZ_ERR_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    xlz_ctx *c = new (std::nothrow) xlz_ctx;
+    if (!c) return XLZ_ERR_BAD_ARG;
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&c->queue, 256) != hipSuccess) {
+        delete c;
+        return XLZ_ERR_DEVICE;
+    }
+    *out = c;
+    return XLZ_OK;
+}
+
+extern "C" void xlz_ctx_destroy(xlz_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->queue) (void)hipFree(c->queue);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int xlz_ctx_device(const xlz_ctx *c) { return c ? c->device : -1; }
+
+// ------------------------------------------------------------------ batch ----
+namespace {
+
+// What NewReader1's initializeFull does before the first Read (reader1.go:77-101).
+// Fills `u` for the device, or settles the stream's status on the host.
+void plan_lzma_alone(const xlz_stream_desc &s, StreamPlan &pl, Unit &u, bool &has_unit)
+{
+    has_unit = false;
+    if (s.in_len == 0) { // ReadByte fails at once: constructor returns io.EOF
+        pl.host_status = XLZ_ERR_HEADER_EOF;
+        pl.host_in_consumed = 0;
+        return;
+    }
+    uint8_t lc, pb, lp;
+    if (xlz_decode_prop(s.in[0], &lc, &pb, &lp) != XLZ_OK) { // "decode prop: %w"
+        pl.host_status = XLZ_ERR_PROPS;
+        pl.host_in_consumed = 1;
+        return;
+    }
+    if (s.in_len < 13) { // "decode dict size" / "decode unpack size": EOF
+        pl.host_status = XLZ_ERR_HEADER_EOF;
+        pl.host_in_consumed = s.in_len;
+        return;
+    }
+    u.dict_size = xlz_decode_dict_size(s.in + 1);
+    u.unpack_size = xlz_decode_unpack_size(s.in + 5);
+    u.lc = lc;
+    u.lp = lp;
+    u.pb = pb;
+    u.kind = UNIT_LZMA1;
+    pl.header_len = 13;
+    has_unit = true;
+}
+
+// NewLZMADecompressorForSevenZip's view: header fields out of band (reader1.go:32-61)
+void plan_lzma_raw(const xlz_stream_desc &s, StreamPlan &pl, Unit &u, bool &has_unit)
+{
+    has_unit = false;
+    uint8_t lc, pb, lp;
+    if (xlz_decode_prop(s.props, &lc, &pb, &lp) != XLZ_OK) {
+        pl.host_status = XLZ_ERR_PROPS;
+        pl.host_in_consumed = 0;
+        return;
+    }
+    u.dict_size = s.dict_size < kLzmaDicMin ? kLzmaDicMin : s.dict_size; // reader1.go:199-201
+    u.unpack_size = s.unpack_size;
+    u.lc = lc;
+    u.lp = lp;
+    u.pb = pb;
+    u.kind = UNIT_LZMA1;
+    pl.header_len = 0;
+    has_unit = true;
+}
+
+int batch_free(xlz_batch *b)
+{
+    if (!b) return XLZ_OK;
+    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    if (b->d_in) (void)hipFree(b->d_in);
+    if (b->d_out) (void)hipFree(b->d_out);
+    if (b->d_units) (void)hipFree(b->d_units);
+    if (b->d_order) (void)hipFree(b->d_order);
+    if (b->d_results) (void)hipFree(b->d_results);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    delete b;
+    return XLZ_OK;
+}
+
+} // namespace
+
+extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **out)
+{
+    if (!ctx || !out || (!streams && n)) return XLZ_ERR_BAD_ARG;
+    *out = nullptr;
+    for (size_t i = 0; i < n; i++)
+        if (!streams[i].in && streams[i].in_len) return XLZ_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    xlz_batch *b = new (std::nothrow) xlz_batch;
+    if (!b) return XLZ_ERR_BAD_ARG;
+    b->ctx = ctx;
+    b->n = n;
+    b->plans.resize(n);
+
+    // ---- plan: parse headers, lay out the arenas -------------------------
+    std::vector<size_t> unit_src_off; // where each unit's payload starts in its stream
+    size_t in_cursor = 0, out_cursor = 0;
+    for (size_t i = 0; i < n; i++) {
+        const xlz_stream_desc &s = streams[i];
+        StreamPlan &pl = b->plans[i];
+        Unit u;
+        memset(&u, 0, sizeof u);
+        bool has_unit = false;
+        switch (s.format) {
+        case XLZ_FMT_LZMA_ALONE: plan_lzma_alone(s, pl, u, has_unit); break;
+        case XLZ_FMT_LZMA_RAW: plan_lzma_raw(s, pl, u, has_unit); break;
+        case XLZ_FMT_LZMA2_RAW:
+            u.kind = UNIT_LZMA2;
+            u.dict_size = s.dict_size < kLzmaDicMin ? 8u * 1024 * 1024 : s.dict_size; // reader2.go:88-91
+            u.unpack_size = kUnknownSize;
+            pl.header_len = 0;
+            has_unit = true;
+            break;
+        default: pl.host_status = XLZ_ERR_BAD_ARG; break;
+        }
+        if (!has_unit) continue;
+
+        const size_t payload = s.in_len - pl.header_len;
+        uint64_t cap = s.out_cap;
+        if (u.kind == UNIT_LZMA1 && u.unpack_size != kUnknownSize && u.unpack_size < cap)
+            cap = u.unpack_size; // a defined size bounds the output (decompress.go:657-662)
+        // 32-bit byte counters on the device: a defined size must fit them
+        const bool size_too_big = u.kind == UNIT_LZMA1 && u.unpack_size != kUnknownSize && u.unpack_size > kMaxUnitBytes;
+        if (payload > kMaxUnitBytes || cap > kMaxUnitBytes || size_too_big ||
+            decode_lds_bytes((uint32_t)u.lc + u.lp) > kMaxLdsBytes) {
+            pl.host_status = XLZ_ERR_UNSUPPORTED;
+            continue;
+        }
+        u.in_off = in_cursor;
+        u.in_len = (uint32_t)payload;
+        u.out_off = out_cursor;
+        u.out_cap = (uint32_t)cap;
+        u.stream = (uint32_t)i;
+        pl.first_unit = (uint32_t)b->units.size();
+        pl.n_units = 1;
+        pl.out_off = out_cursor;
+        pl.out_cap = cap;
+        b->units.push_back(u);
+        unit_src_off.push_back(pl.header_len);
+        b->max_lc_lp = std::max(b->max_lc_lp, (uint32_t)u.lc + u.lp);
+        b->algo_in += payload;
+        in_cursor += align_up(payload + 16, kArenaAlign);
+        out_cursor += align_up((size_t)cap + 1, kArenaAlign);
+    }
+    b->in_bytes = in_cursor + kArenaTailPad;
+    b->out_bytes = out_cursor + kArenaTailPad;
+
+    // work-queue order: most compressed bytes first (decode time tracks the number of
+    // binary decisions, which tracks compressed size)
+    b->order.resize(b->units.size());
+    std::iota(b->order.begin(), b->order.end(), 0u);
+    std::stable_sort(b->order.begin(), b->order.end(),
+                     [&](uint32_t a, uint32_t c) { return b->units[a].in_len > b->units[c].in_len; });
+
+    // ---- device memory + upload ----------------------------------------
+    const size_t nu = b->units.size();
+    auto fail = [&](int st) {
+        batch_free(b);
+        return st;
+    };
+    if (hipMalloc(&b->d_in, b->in_bytes) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+    if (hipMalloc(&b->d_out, b->out_bytes) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+    if (nu) {
+        if (hipMalloc(&b->d_units, nu * sizeof(Unit)) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+        if (hipMalloc(&b->d_order, nu * sizeof(uint32_t)) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+        if (hipMalloc(&b->d_results, nu * sizeof(UnitResult)) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+    }
+    if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess)
+        return fail(XLZ_ERR_DEVICE);
+    {
+        // pack the payloads into one staging image, then a single H2D copy
+        uint8_t *stage = nullptr;
+        if (hipHostMalloc(&stage, b->in_bytes, hipHostMallocDefault) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+        memset(stage, 0, b->in_bytes);
+        for (size_t k = 0; k < nu; k++) {
+            const Unit &u = b->units[k];
+            memcpy(stage + u.in_off, streams[u.stream].in + unit_src_off[k], u.in_len);
+        }
+        hipError_t e = hipMemcpy(b->d_in, stage, b->in_bytes, hipMemcpyHostToDevice);
+        (void)hipHostFree(stage);
+        if (e != hipSuccess) return fail(XLZ_ERR_DEVICE);
+    }
+    if (nu) {
+        if (hipMemcpy(b->d_units, b->units.data(), nu * sizeof(Unit), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(b->d_order, b->order.data(), nu * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(XLZ_ERR_DEVICE);
+    }
+    *out = b;
+    return XLZ_OK;
+}
+
+extern "C" int xlz_batch_run(xlz_batch *b)
+{
+    if (!b) return XLZ_ERR_BAD_ARG;
+    xlz_ctx *ctx = b->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
+    HIP_TRY(hipEventRecord(b->ev0, ctx->stream));
+    if (!b->units.empty()) {
+        LaunchParams p;
+        p.in_arena = b->d_in;
+        p.out_arena = b->d_out;
+        p.units = b->d_units;
+        p.order = b->d_order;
+        p.results = b->d_results;
+        p.queue = ctx->queue;
+        p.n_units = (uint32_t)b->units.size();
+        p.max_lc_lp = b->max_lc_lp;
+        if (launch_decode(p, ctx->num_cus, ctx->stream) != 0) return XLZ_ERR_DEVICE;
+    }
+    HIP_TRY(hipEventRecord(b->ev1, ctx->stream));
+    b->ran = true;
+    return XLZ_OK;
+}
+
+extern "C" int xlz_batch_sync(xlz_batch *b)
+{
+    if (!b) return XLZ_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return XLZ_OK;
+}
+
+extern "C" int xlz_batch_last_kernel_ms(xlz_batch *b, float *ms)
+{
+    if (!b || !ms || !b->ran) return XLZ_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    HIP_TRY(hipEventSynchronize(b->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, b->ev0, b->ev1));
+    return XLZ_OK;
+}
+
+extern "C" int xlz_batch_results(xlz_batch *b, xlz_result *results)
+{
+    if (!b || (!results && b->n) || !b->ran) return XLZ_ERR_BAD_ARG;
+    int st = xlz_batch_sync(b);
+    if (st != XLZ_OK) return st;
+    std::vector<UnitResult> ur(b->units.size());
+    if (!ur.empty())
+        HIP_TRY(hipMemcpy(ur.data(), b->d_results, ur.size() * sizeof(UnitResult), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < b->n; i++) {
+        const StreamPlan &pl = b->plans[i];
+        xlz_result &r = results[i];
+        memset(&r, 0, sizeof r);
+        if (pl.host_status != 1) { // settled while parsing
+            r.status = pl.host_status;
+            r.in_consumed = pl.host_in_consumed;
+            continue;
+        }
+        const UnitResult &u = ur[pl.first_unit];
+        r.status = u.status;
+        r.out_len = u.out_len;
+        r.in_consumed = (uint64_t)pl.header_len + u.in_consumed;
+    }
+    return XLZ_OK;
+}
+
+extern "C" int xlz_batch_stats(xlz_batch *b, uint64_t *in_bytes, uint64_t *out_bytes, uint64_t *units)
+{
+    if (!b || !b->ran) return XLZ_ERR_BAD_ARG;
+    int st = xlz_batch_sync(b);
+    if (st != XLZ_OK) return st;
+    std::vector<UnitResult> ur(b->units.size());
+    if (!ur.empty())
+        HIP_TRY(hipMemcpy(ur.data(), b->d_results, ur.size() * sizeof(UnitResult), hipMemcpyDeviceToHost));
+    uint64_t ci = 0, co = 0;
+    for (const UnitResult &u : ur) {
+        ci += u.in_consumed;
+        co += u.out_len;
+    }
+    if (in_bytes) *in_bytes = ci;
+    if (out_bytes) *out_bytes = co;
+    if (units) *units = ur.size();
+    return XLZ_OK;
+}
+
+extern "C" int xlz_batch_device_output(xlz_batch *b, size_t i, void **dptr, size_t *cap)
+{
+    if (!b || i >= b->n || !dptr) return XLZ_ERR_BAD_ARG;
+    const StreamPlan &pl = b->plans[i];
+    *dptr = pl.host_status == 1 ? b->d_out + pl.out_off : nullptr;
+    if (cap) *cap = pl.host_status == 1 ? (size_t)pl.out_cap : 0;
+    return XLZ_OK;
+}
+
+extern "C" int xlz_batch_download(xlz_batch *b, size_t i, uint8_t *dst, size_t len)
+{
+    if (!b || i >= b->n || (!dst && len)) return XLZ_ERR_BAD_ARG;
+    const StreamPlan &pl = b->plans[i];
+    if (pl.host_status != 1 || len == 0) return XLZ_OK;
+    if (len > pl.out_cap) len = (size_t)pl.out_cap;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    HIP_TRY(hipMemcpy(dst, b->d_out + pl.out_off, len, hipMemcpyDeviceToHost));
+    return XLZ_OK;
+}
+
+extern "C" void xlz_batch_destroy(xlz_batch *b) { batch_free(b); }
+
+extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_result *results)
+{
+    if (!ctx || (!streams && n) || (!results && n)) return XLZ_ERR_BAD_ARG;
+    for (size_t i = 0; i < n; i++)
+        if (!streams[i].out && streams[i].out_cap) return XLZ_ERR_BAD_ARG;
+    xlz_batch *b = nullptr;
+    int st = xlz_batch_create(ctx, streams, n, &b);
+    if (st != XLZ_OK) return st;
+    st = xlz_batch_run(b);
+    if (st == XLZ_OK) st = xlz_batch_results(b, results);
+    if (st == XLZ_OK) {
+        for (size_t i = 0; i < n && st == XLZ_OK; i++)
+            if (results[i].out_len) st = xlz_batch_download(b, i, streams[i].out, (size_t)results[i].out_len);
+    }
+    xlz_batch_destroy(b);
+    return st;
+}
+
+// ---------------------------------------------------------------- readers ----
+// Pull-style mirror of Reader1 / Reader2 / readCloser (reader1.go:223-254,
+// reader2.go:216-250, readcloser.go:9-41) on top of the batch engine.
+struct xlz_reader {
+    xlz_ctx *ctx = nullptr;
+    xlz_stream_desc desc;
+    std::vector<uint8_t> in;
+    std::vector<uint8_t> out;
+    size_t rd = 0;
+    bool decoded = false;
+    bool closed = false;
+    bool is_closer = false; // built by a *ForSevenZip constructor: wraps errors like readCloser
+    int32_t status = XLZ_OK;
+};
+
+namespace {
+
+xlz_reader *reader_new(xlz_ctx *ctx, const uint8_t *in, size_t in_len)
+{
+    xlz_reader *r = new (std::nothrow) xlz_reader;
+    if (!r) return nullptr;
+    r->ctx = ctx;
+    r->in.assign(in, in + in_len);
+    memset(&r->desc, 0, sizeof r->desc);
+    return r;
+}
+
+// rangeDec.Init as seen by a constructor (range_decoder.go:27-46, reader1.go:153-156)
+int check_rc_init(const uint8_t *p, size_t n)
+{
+    if (n == 0) return XLZ_ERR_HEADER_EOF;
+    if (p[0] != 0) return XLZ_ERR_RC_INIT;
+    if (n < 5) return XLZ_ERR_HEADER_EOF;
+    return XLZ_OK;
+}
+
+int reader_decode(xlz_reader *r)
+{
+    if (r->decoded) return XLZ_OK;
+    // Output size: the header's, or a guess that is grown until it fits.
+    uint64_t cap;
+    bool known = false;
+    if (r->desc.format == XLZ_FMT_LZMA_ALONE) {
+        uint64_t u = xlz_decode_unpack_size(r->in.data() + 5);
+        if (u != kUnknownSize) {
+            known = true;
+            cap = u;
+        }
+    } else if (r->desc.format == XLZ_FMT_LZMA_RAW && r->desc.unpack_size != kUnknownSize) {
+        known = true;
+        cap = r->desc.unpack_size;
+    }
+    if (!known) cap = std::max<uint64_t>(1u << 16, (uint64_t)r->in.size() * 6);
+    if (cap > kMaxUnitBytes) cap = kMaxUnitBytes;
+    for (;;) {
+        r->out.resize((size_t)cap);
+        r->desc.in = r->in.data();
+        r->desc.in_len = r->in.size();
+        r->desc.out = r->out.data();
+        r->desc.out_cap = r->out.size();
+        xlz_result res;
+        int st = xlz_decode_batch(r->ctx, &r->desc, 1, &res);
+        if (st != XLZ_OK) return st;
+        if (res.status == XLZ_ERR_OUT_CAP && !known && cap < kMaxUnitBytes) {
+            cap = std::min<uint64_t>(cap * 4, kMaxUnitBytes);
+            continue;
+        }
+        r->status = res.status;
+        r->out.resize((size_t)res.out_len);
+        break;
+    }
+    r->decoded = true;
+    return XLZ_OK;
+}
+
+} // namespace
+
+// NewReader1, reader1.go:18-24
+extern "C" xlz_reader *xlz_new_reader1(xlz_ctx *ctx, const uint8_t *in, size_t in_len, int *err)
+{
+    int e = XLZ_OK;
+    xlz_reader *r = nullptr;
+    if (!ctx || (!in && in_len)) {
+        e = XLZ_ERR_BAD_ARG;
+    } else if (in_len == 0) {
+        e = XLZ_ERR_HEADER_EOF;
+    } else if (xlz_decode_prop(in[0], nullptr, nullptr, nullptr) != XLZ_OK) {
+        e = XLZ_ERR_PROPS;
+    } else if (in_len < 13) {
+        e = XLZ_ERR_HEADER_EOF;
+    } else if ((e = check_rc_init(in + 13, in_len - 13)) == XLZ_OK) {
+        r = reader_new(ctx, in, in_len);
+        if (!r)
+            e = XLZ_ERR_BAD_ARG;
+        else
+            r->desc.format = XLZ_FMT_LZMA_ALONE;
+    }
+    if (err) *err = e;
+    return r;
+}
+
+// NewReader2, reader2.go:26-41: the constructor already runs startChunk for the
+// first chunk, so its framing errors are constructor errors.
+extern "C" xlz_reader *xlz_new_reader2(xlz_ctx *ctx, const uint8_t *in, size_t in_len, int dict_size, int *err)
+{
+    int e = XLZ_OK;
+    xlz_reader *r = nullptr;
+    if (!ctx || (!in && in_len)) {
+        e = XLZ_ERR_BAD_ARG;
+    } else if (in_len == 0) {
+        e = XLZ_ERR_UNEXPECTED_EOF; // reader2.go:104-110
+    } else {
+        const uint8_t c = in[0];
+        const bool lzma_chunk = c >= 0x80;
+        const size_t hl = c == 0 || (c >= 3 && c < 0x80) ? 1 : (c < 3 ? 3 : ((c >> 5) >= 6 ? 6 : 5));
+        if (in_len < hl) {
+            e = XLZ_ERR_UNEXPECTED_EOF; // reader2.go:121-128
+        } else if (lzma_chunk) {
+            // first LZMA chunk: props come from header[5], which is still 0 when the
+            // chunk carries none (reader2.go:146-153)
+            const uint8_t props = hl == 6 ? in[5] : 0;
+            if (xlz_decode_prop(props, nullptr, nullptr, nullptr) != XLZ_OK) {
+                e = XLZ_ERR_PROPS;
+            } else {
+                size_t comp = (((size_t)in[3] << 8) | in[4]) + 1;
+                size_t avail = std::min(comp, in_len - hl);
+                e = check_rc_init(in + hl, avail);
+            }
+        }
+        if (e == XLZ_OK) {
+            r = reader_new(ctx, in, in_len);
+            if (!r) {
+                e = XLZ_ERR_BAD_ARG;
+            } else {
+                r->desc.format = XLZ_FMT_LZMA2_RAW;
+                r->desc.dict_size = (uint32_t)dict_size;
+            }
+        }
+    }
+    if (err) *err = e;
+    return r;
+}
+
+// NewLZMADecompressorForSevenZip, reader1.go:32-61
+extern "C" xlz_reader *xlz_new_lzma_decompressor_for_sevenzip(xlz_ctx *ctx, const uint8_t *props, size_t props_len,
+                                                              uint64_t unpack_size, const uint8_t *const *readers,
+                                                              const size_t *reader_lens, size_t n_readers, int *err)
+{
+    int e = XLZ_OK;
+    xlz_reader *r = nullptr;
+    if (n_readers != 1) {
+        e = XLZ_ERR_NEED_ONE_READER; // :33-35
+    } else if (!ctx || !props || props_len < 5 || !readers || !reader_lens || (!readers[0] && reader_lens[0])) {
+        e = XLZ_ERR_BAD_ARG; // the reference would panic indexing props[1:5]
+    } else if (xlz_decode_prop(props[0], nullptr, nullptr, nullptr) != XLZ_OK) {
+        e = XLZ_ERR_PROPS; // :37-40
+    } else {
+        // the reference hands back the readCloser AND initialize()'s error (:57-60)
+        e = check_rc_init(readers[0], reader_lens[0]);
+        if (e == XLZ_OK) {
+            r = reader_new(ctx, readers[0], reader_lens[0]);
+            if (!r) {
+                e = XLZ_ERR_BAD_ARG;
+            } else {
+                r->desc.format = XLZ_FMT_LZMA_RAW;
+                r->desc.props = props[0];
+                r->desc.dict_size = xlz_decode_dict_size(props + 1);
+                r->desc.unpack_size = unpack_size;
+                r->is_closer = true;
+            }
+        }
+    }
+    if (err) *err = e;
+    return r;
+}
+
+// NewLZMA2DecompressorForSevenZip, reader2.go:49-75
+extern "C" xlz_reader *xlz_new_lzma2_decompressor_for_sevenzip(xlz_ctx *ctx, const uint8_t *props, size_t props_len,
+                                                               uint64_t unpack_size, const uint8_t *const *readers,
+                                                               const size_t *reader_lens, size_t n_readers, int *err)
+{
+    (void)unpack_size; // ignored by the reference too (reader2.go:49)
+    int e = XLZ_OK;
+    xlz_reader *r = nullptr;
+    if (n_readers != 1) {
+        e = XLZ_ERR_NEED_ONE_READER; // :50-52
+    } else if (props_len != 1) {
+        e = XLZ_ERR_INSUFFICIENT_PROPS; // :54-56
+    } else if (!ctx || !props || !readers || !reader_lens) {
+        e = XLZ_ERR_BAD_ARG;
+    } else {
+        r = xlz_new_reader2(ctx, readers[0], reader_lens[0], (int)xlz_decode_dict_size2(props[0]), &e);
+        if (r) r->is_closer = true;
+    }
+    if (err) *err = e;
+    return r;
+}
+
+// Reader1.Read / Reader2.Read / readCloser.Read
+extern "C" long xlz_reader_read(xlz_reader *r, uint8_t *p, size_t n, int *err)
+{
+    int e = XLZ_OK;
+    long got = 0;
+    if (!r || (!p && n)) {
+        e = XLZ_ERR_BAD_ARG;
+    } else if (r->closed) {
+        e = XLZ_ERR_CLOSED; // readcloser.go:31-33
+    } else if ((e = reader_decode(r)) == XLZ_OK) {
+        const size_t left = r->out.size() - r->rd;
+        const size_t k = std::min(left, n);
+        if (k) memcpy(p, r->out.data() + r->rd, k);
+        r->rd += k;
+        got = (long)k;
+        if (r->rd == r->out.size() && (k < n || n == 0)) e = r->status >= 0 ? XLZ_EOF : r->status;
+    }
+    if (err) *err = e;
+    return got;
+}
+
+// readCloser.Close, readcloser.go:16-28
+extern "C" int xlz_reader_close(xlz_reader *r)
+{
+    if (!r) return XLZ_ERR_BAD_ARG;
+    if (r->closed) return XLZ_ERR_CLOSED;
+    r->closed = true;
+    r->in.clear();
+    r->in.shrink_to_fit();
+    r->out.clear();
+    r->out.shrink_to_fit();
+    return XLZ_OK;
+}
+
+extern "C" void xlz_reader_free(xlz_reader *r) { delete r; }
