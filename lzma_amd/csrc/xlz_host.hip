@@ -30,6 +30,7 @@ constexpr uint64_t kUnknownSize = ~(uint64_t)0;   // state.go:135-151
 constexpr uint64_t kMaxUnitBytes = 0xFFFF0000ull; // 32-bit offsets inside a unit
 constexpr size_t kArenaAlign = 256;
 constexpr size_t kArenaTailPad = 256; // the input reader runs up to 16 bytes ahead
+constexpr size_t kOutTailPad = 64;    // wave_copy stores whole 64-lane rows: scratch bytes past a unit's end
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -315,7 +316,7 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
         b->max_lc_lp = std::max(b->max_lc_lp, (uint32_t)u.lc + u.lp);
         b->algo_in += payload;
         in_cursor += align_up(payload + 16, kArenaAlign);
-        out_cursor += align_up((size_t)cap + 1, kArenaAlign);
+        out_cursor += align_up((size_t)cap + kOutTailPad, kArenaAlign);
     }
     b->in_bytes = in_cursor + kArenaTailPad;
     b->out_bytes = out_cursor + kArenaTailPad;
