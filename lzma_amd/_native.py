@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libxlz.so")
+SO_PATH = os.environ.get("XLZ_SO") or os.path.join(_HERE, "libxlz.so")  # XLZ_SO: A/B builds
 
 # status codes (include/xlz.h)
 OK = 0

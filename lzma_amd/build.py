@@ -23,9 +23,11 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def build(force=False, verbose=False, extra_flags=(), out=None):
     """Compile every HIP source for gfx950 into lzma_amd/libxlz.so."""
-    if not force and not _stale():
+    if out is None and os.environ.get("XLZ_SO"):
+        return os.environ["XLZ_SO"]  # an A/B build made by hand
+    if out is None and not force and not _stale():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -33,11 +35,11 @@ def build(force=False, verbose=False, extra_flags=()):
            "-I", os.path.join(HERE, "..", "include")]
     cmd += list(extra_flags)
     cmd += [os.path.join(CSRC, f) for f in SOURCES]
-    cmd += ["-o", SO]
+    cmd += ["-o", out or SO]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return SO
+    return out or SO
 
 
 if __name__ == "__main__":

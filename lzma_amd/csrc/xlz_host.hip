@@ -29,7 +29,7 @@ constexpr uint32_t kLzmaDicMin = 1u << 12;        // types.go:8
 constexpr uint64_t kUnknownSize = ~(uint64_t)0;   // state.go:135-151
 constexpr uint64_t kMaxUnitBytes = 0xFFFF0000ull; // 32-bit offsets inside a unit
 constexpr size_t kArenaAlign = 256;
-constexpr size_t kArenaTailPad = 256; // the input reader runs up to 16 bytes ahead
+constexpr size_t kArenaTailPad = 1024; // the 256-byte input window may start near a unit's end
 constexpr size_t kOutTailPad = 64;    // wave_copy stores whole 64-lane rows: scratch bytes past a unit's end
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -7,24 +7,35 @@
 // wave-uniform code (range/code/state live in SGPRs, branches are scalar, no
 // divergence), the unit's whole probability model (state.go:3-27) lives in LDS,
 // and the 64 lanes are used where the work IS parallel: model initialisation,
-// match copies, stored-chunk copies.  One single-wave workgroup owns one LDS
-// model; 160 KiB / 15.6 KiB = 10 units per CU run concurrently and a persistent
-// grid pulls units from an atomic queue (heaviest first).
+// match copies, the compressed-input window (64 lanes x 4 bytes in one VGPR),
+// and the look-ahead of a bit-tree node's children (a per-lane LDS gather).
+// One single-wave workgroup owns one LDS model; 160 KiB / 15.7 KiB = 10 units
+// per CU run concurrently and a persistent grid pulls units from an atomic
+// queue (heaviest first).
+//
+// Two decoders of one packet exist (lzma_packet_checked / lzma_packet_fast).
+// The fast one is hand-scheduled GCN assembly and assumes what lzma_run has
+// verified for it: >= 32 input bytes, >= 288 bytes of output room and bytesLeft.
+// The checked one is plain C++ with every end-of-input / capacity test of the
+// reference and runs only within a few bytes of a stream's or chunk's end.
 //
 // The sliding window (window.go) is the unit's own flat output range in HBM:
 // distances are bounded by dictSize, so `out[pos - dist]` is the circular
 // window's byte, and bytes "before the start" read as 0 exactly like the
 // reference's zero-filled, not-yet-full window.
 //
+// Measured costs on MI355X that shaped this file (tools/ubench): dependent SALU
+// or VALU op 4 cycles; LDS read -> use 60; scalar branch 15 not taken / 20
+// taken; a VCC branch 45; one SIMD issues <= 1 SALU op per 4 cycles.
+//
 // file:line citations are into the reference repository (kulaginds/lzma).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "xlz_format.h"
 
 namespace xlz {
-
-typedef const __attribute__((address_space(4))) uint64_t *const_q_ptr; // scalar (SMEM) loads
 
 #define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 __device__ __forceinline__ uint64_t rfl64(uint64_t v)
@@ -32,37 +43,44 @@ __device__ __forceinline__ uint64_t rfl64(uint64_t v)
     return ((uint64_t)RFL((uint32_t)(v >> 32)) << 32) | RFL((uint32_t)v);
 }
 
-constexpr uint32_t kTop = 1u << 24;          // types.go:27
-constexpr uint32_t kBitModelBits = 11;       // types.go:12
-constexpr uint32_t kMoveBits = 5;            // types.go:13
+constexpr uint32_t kTop = 1u << 24;             // types.go:27
+constexpr uint32_t kBitModelBits = 11;          // types.go:12
+constexpr uint32_t kMoveBits = 5;               // types.go:13
 constexpr uint32_t kProbInitPair = 0x04000400u; // two probs of 1024 (types.go:14)
-constexpr uint32_t kEndPosModelIndex = 14;   // types.go:22
-constexpr uint32_t kNumAlignBits = 4;        // types.go:20
-constexpr uint32_t kMatchMinLen = 2;         // types.go:24
+constexpr uint32_t kEndPosModelIndex = 14;      // types.go:22
+constexpr uint32_t kNumAlignBits = 4;           // types.go:20
+constexpr uint32_t kMatchMinLen = 2;            // types.go:24
 
-enum : int { RUN_END = 0, RUN_INPUT_EOF = 1, RUN_ERR_RESULT = 2, RUN_OUT_CAP = 3 };
+constexpr uint32_t kInWindow = 256;   // bytes of compressed input held in one VGPR (64 lanes x 4)
+constexpr uint32_t kFastInput = 32;   // >= lzmaRequiredInputMax = 20 (types.go:38), with slack
+constexpr uint32_t kFastOutput = 288; // >= maxMatchLen = 273 (types.go:46)
 
-// Everything a unit carries between packets / chunks.  All members are
+enum : int { RUN_END = 0, RUN_INPUT_EOF = 1, RUN_ERR_RESULT = 2, RUN_OUT_CAP = 3, RUN_CONTINUE = 4 };
+
+// Everything a unit carries between packets / chunks.  Except `vin` all members are
 // wave-uniform; after inlining they live in SGPRs.
 struct Dec {
     // range decoder (range_decoder.go:7-13)
     uint32_t range, code;
-    // compressed input: 8-byte scalar loads, one qword ahead
-    const_q_ptr inq;
-    uint32_t qidx;     // index of the next qword to fetch
-    uint64_t cur, nxt; // cur holds `navail` unread bytes (low byte first)
-    uint32_t navail;
-    uint32_t in_remain; // bytes that may still be read (limitedByteReader, bytereader.go:7-28)
+    // compressed input.  Positions are relative to the unit's payload rounded down to 4
+    // bytes.  `vin` holds the 256 bytes at [win0, win0 + 256): lane i = dword i.
+    const uint32_t *inw; // payload base, 4-byte aligned
+    uint32_t vin;        // per lane
+    uint32_t win0;       // window start (multiple of 4)
+    uint32_t arel;       // next byte to read, relative to win0
+    uint32_t cur;        // unread bytes of dword arel >> 2, next byte in bits 7:0
+    uint32_t abase;      // position of the unit's first payload byte (0..3)
+    uint32_t aend;       // first position that may NOT be read (limitedByteReader, bytereader.go:7-28)
     // LZMA state (state.go:28-45)
     uint32_t state, rep0, rep1, rep2, rep3;
     uint32_t lc, lp_mask, pos_mask;
     bool size_defined;
     uint32_t bytes_left;
     // window (window.go:8-16) over the flat output
-    uint32_t pos;       // bytes of output produced by this unit
-    uint32_t wbase;     // output offset of the last dictionary reset (0 for LZMA1)
-    uint32_t wpos;      // the reference's wrapped window.pos
-    uint32_t dict_size; // window.size
+    uint32_t pos;        // bytes of output produced by this unit
+    uint32_t wbase;      // output offset of the last dictionary reset (0 for LZMA1)
+    uint32_t wpos;       // the reference's wrapped window.pos
+    uint32_t dict_size;  // window.size
     uint32_t out_cap;
     uint32_t prev_byte;  // byte at distance 1 (0 while the window is empty)
     uint32_t match_byte; // byte at distance rep0+1, valid right after a match / rep
@@ -134,60 +152,70 @@ __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ out, Dec &d, uin
     }
 }
 
-// ---- input ------------------------------------------------------------------
-__device__ __forceinline__ void in_open(Dec &d, const uint8_t *arena, uint64_t off, uint32_t avail)
+// ---- compressed input ---------------------------------------------------------
+// (re)load the 256-byte window so that it starts at the dword holding position `p`
+__device__ __forceinline__ void in_window(Dec &d, uint32_t p, uint32_t lane)
 {
-    const uint64_t a = (uint64_t)arena + off;
-    const uint32_t sh = (uint32_t)(a & 7);
-    d.inq = (const_q_ptr)(a & ~(uint64_t)7);
-    d.cur = d.inq[0] >> (8 * sh);
-    d.nxt = d.inq[1];
-    d.qidx = 2;
-    d.navail = 8 - sh;
-    d.in_remain = avail;
+    d.win0 = p & ~3u;
+    d.arel = p & 3u;
+    d.vin = d.inw[(d.win0 >> 2) + lane]; // one coalesced 256-byte load
+    d.cur = (uint32_t)__builtin_amdgcn_readlane((int)d.vin, 0) >> (8 * d.arel);
 }
 
-// one byte from the source; false = io.EOF
-#define IN_BYTE(D, B, EOF_STMT)                                                                   \
+__device__ __forceinline__ void in_open(Dec &d, const uint8_t *arena, uint64_t off, uint32_t avail, uint32_t lane)
+{
+    const uint64_t a = (uint64_t)arena + off;
+    d.inw = (const uint32_t *)(a & ~(uint64_t)3);
+    d.abase = (uint32_t)(a & 3);
+    d.aend = d.abase + avail;
+    in_window(d, d.abase, lane);
+}
+
+__device__ __forceinline__ uint32_t in_pos(const Dec &d) { return d.win0 + d.arel; }
+
+// one byte from the window.  The caller has checked in_pos < aend where that matters and
+// lzma_run keeps >= kFastInput bytes of window ahead of every packet.
+#define IN_BYTE(B)                                                                                \
     do {                                                                                          \
-        if ((D).in_remain == 0) { EOF_STMT; }                                                     \
-        (B) = (uint32_t)(D).cur & 0xFFu;                                                          \
-        (D).cur >>= 8;                                                                            \
-        (D).in_remain--;                                                                          \
-        if (--(D).navail == 0) {                                                                  \
-            (D).cur = (D).nxt;                                                                    \
-            (D).navail = 8;                                                                       \
-            (D).nxt = (D).inq[(D).qidx++];                                                        \
-        }                                                                                         \
+        (B) = d.cur & 0xFFu;                                                                      \
+        d.cur >>= 8;                                                                              \
+        d.arel++;                                                                                 \
+        if ((d.arel & 3u) == 0) d.cur = (uint32_t)__builtin_amdgcn_readlane((int)d.vin, d.arel >> 2); \
     } while (0)
 
-// ---- the binary decision (decompress.go:26-43,176-190; range_decoder.go:57-98) ----
+// ================================================================================
+//  CHECKED path: plain C++, every test of the reference.  Runs near stream ends.
+// ================================================================================
+// The binary decision (decompress.go:26-43,176-190; range_decoder.go:57-98).  The
+// probability update  p - ((p - k) >>a 5)  with k = 2017 for bit 0 and k = 0 for bit 1
+// equals the reference's  p + ((2048 - p) >> 5)  /  p - (p >> 5)  for every 11-bit p.
+__device__ __forceinline__ uint32_t rc_core(uint32_t &range, uint32_t &code, uint32_t &p)
+{
+    const uint32_t bound = (range >> kBitModelBits) * p;
+    const bool z = code < bound;
+    range = z ? bound : range - bound;
+    code = z ? code : code - bound;
+    p = p - (uint32_t)((int32_t)(p - (z ? 2017u : 0u)) >> kMoveBits);
+    return z ? 0u : 1u;
+}
+
 #define NORMALIZE()                                                                               \
     do {                                                                                          \
         if (d.range < kTop) {                                                                     \
             uint32_t nb_;                                                                         \
-            IN_BYTE(d, nb_, return RUN_INPUT_EOF);                                                \
+            if (in_pos(d) == d.aend) return RUN_INPUT_EOF; /* decompress.go:35-38 */              \
+            IN_BYTE(nb_);                                                                         \
             d.range <<= 8;                                                                        \
             d.code = (d.code << 8) | nb_;                                                         \
         }                                                                                         \
     } while (0)
 
-#define BIT_NN(IDX, BIT)                                                                          \
+#define BIT_NN(IDX, BITV)                                                                         \
     do {                                                                                          \
         const uint32_t i_ = (IDX);                                                                \
         uint32_t p_ = RFL(probs[i_]);                                                             \
-        const uint32_t bound_ = (d.range >> kBitModelBits) * p_;                                  \
-        if (d.code < bound_) {                                                                    \
-            d.range = bound_;                                                                     \
-            p_ += ((1u << kBitModelBits) - p_) >> kMoveBits;                                      \
-            (BIT) = 0;                                                                            \
-        } else {                                                                                  \
-            d.range -= bound_;                                                                    \
-            d.code -= bound_;                                                                     \
-            p_ -= p_ >> kMoveBits;                                                                \
-            (BIT) = 1;                                                                            \
-        }                                                                                         \
-        probs[i_] = (uint16_t)p_;                                                                 \
+        (BITV) = rc_core(d.range, d.code, p_);                                                    \
+        probs[i_] = (uint16_t)p_; /* all 64 lanes, same address, same value */                    \
     } while (0)
 
 #define BIT(IDX, B)                                                                               \
@@ -245,171 +273,536 @@ __device__ __forceinline__ void in_open(Dec &d, const uint8_t *arena, uint64_t o
 // state.go:153-187
 __device__ __forceinline__ uint32_t upd_literal(uint32_t s) { return s < 4 ? 0 : (s < 10 ? s - 3 : s - 6); }
 
-// (*Reader1).decompress run to the end of the current LZMA chunk
-// (decompress.go:8-1136).  Every mutation happens in the reference's order.
+// distance validity, decompress.go:651-653 + window.CheckDistance (window.go:89-91)
+__device__ __forceinline__ bool bad_distance(const Dec &d)
+{
+    const bool is_full = (d.pos - d.wbase) >= d.dict_size;
+    return d.rep0 >= d.dict_size || !(is_full || d.rep0 <= d.wpos);
+}
+
+// ONE packet of (*Reader1).decompress (one iteration of the loop at decompress.go:13),
+// every mutation in the reference's order, every test of the reference present.
+__device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint8_t *__restrict__ out, uint32_t lane)
+{
+    uint32_t bit, length;
+
+    const uint32_t pos_state = d.wpos & d.pos_mask;              // :22
+    const uint32_t state2 = (d.state << kPosBitsMax) + pos_state; // :23
+
+    BIT(P_IS_MATCH + state2, bit); // :25-43,176-190
+    if (bit == 0) {
+        // ---- literal, decompress.go:44-175 ----
+        if (d.size_defined && d.bytes_left == 0) return RUN_ERR_RESULT; // :45-47
+        const uint32_t lit_state = ((d.wpos & d.lp_mask) << d.lc) + (d.prev_byte >> (8 - d.lc)); // :56
+        const uint32_t lbase = P_LIT + kLitCoderSize * lit_state;                              // :57
+        uint32_t symbol = 1;
+        if (d.state >= 7) { // matched literal :59-114
+            uint32_t mb = d.match_byte;
+            do {
+                const uint32_t match_bit = (mb >> 7) & 1;
+                mb <<= 1;
+                BIT(lbase + ((1 + match_bit) << 8) + symbol, bit);
+                symbol = (symbol << 1) | bit;
+                if (match_bit != bit) break;
+            } while (symbol < 0x100);
+        }
+        while (symbol < 0x100) { // :127-166
+            BIT(lbase + symbol, bit);
+            symbol = (symbol << 1) | bit;
+        }
+        symbol &= 0xFF;
+        if (d.pos >= d.out_cap) return RUN_OUT_CAP;
+        out[d.pos] = (uint8_t)symbol; // window.PutByte :168 (all lanes, same byte, same address)
+        d.pos++;
+        if (++d.wpos >= d.dict_size) d.wpos -= d.dict_size; // window.go:38-41
+        d.prev_byte = symbol;
+        d.state = upd_literal(d.state); // :171
+        d.bytes_left--;                 // :172 (wraps harmlessly when the size is undefined)
+        return RUN_CONTINUE;
+    }
+
+    BIT(P_IS_REP + d.state, bit); // :195-213,669-683
+    if (bit == 0) {
+        // ---- simple match, :215-668 ----
+        d.rep3 = d.rep2;
+        d.rep2 = d.rep1;
+        d.rep1 = d.rep0; // :216
+        LEN_DECODE(P_LEN, length);
+        d.state = d.state < 7 ? 7 : 10; // stateUpdateMatch :431
+        const uint32_t len_state = length > 3 ? 3 : length;
+        uint32_t pos_slot;
+        TREE(P_POS_SLOT + (len_state << 6), 6, pos_slot); // :441-486
+        pos_slot -= 64;
+        if (pos_slot < 4) {
+            d.rep0 = pos_slot; // :488-489
+        } else {
+            const uint32_t nbits = (pos_slot >> 1) - 1;
+            uint32_t dist = (2 | (pos_slot & 1)) << nbits; // :491-492
+            uint32_t sym;
+            if (pos_slot < kEndPosModelIndex) {
+                RTREE(P_POS_DEC + dist - pos_slot, nbits, sym); // :495-546
+                d.rep0 = dist + sym;
+            } else {
+                uint32_t res = 0; // DecodeDirectBits :549-577
+                _Pragma("unroll 1") for (uint32_t n = nbits - kNumAlignBits; n > 0; n--)
+                {
+                    d.range >>= 1;
+                    d.code -= d.range;
+                    const uint32_t t = 0u - (d.code >> 31);
+                    d.code += d.range & t;
+                    res = (res << 1) + (t + 1);
+                    NORMALIZE();
+                }
+                dist += res << kNumAlignBits;
+                RTREE(P_ALIGN, kNumAlignBits, sym); // :579-625
+                d.rep0 = dist + sym;                // :627-628
+            }
+        }
+        if (d.rep0 == 0xFFFFFFFFu) { // end marker :633-645
+            if (d.code == 0) {
+                if (d.size_defined && d.bytes_left > 0) return RUN_ERR_RESULT;
+                return RUN_END;
+            }
+            return RUN_ERR_RESULT;
+        }
+        if (d.size_defined && d.bytes_left == 0) return RUN_ERR_RESULT; // :647-649
+        if (bad_distance(d)) return RUN_ERR_RESULT;                     // :651-653
+        length += kMatchMinLen;                                         // :656
+    } else {
+        // ---- rep match, :685-1123 ----
+        if (d.size_defined && d.bytes_left == 0) return RUN_ERR_RESULT; // :686-688
+        if (d.pos == d.wbase) return RUN_ERR_RESULT;                    // window.IsEmpty :690-692
+        BIT(P_IS_REP_G0 + d.state, bit);                                // :694-772
+        if (bit == 0) {
+            BIT(P_IS_REP0_LONG + state2, bit); // :715-756
+            if (bit == 0) {                    // short rep :735-739
+                d.state = d.state < 7 ? 9 : 11;
+                if (d.pos >= d.out_cap) return RUN_OUT_CAP;
+                uint32_t dist = d.rep0 + 1;
+                if (dist == 0) dist = d.dict_size;
+                wave_copy(out, d, dist, 1, lane);
+                d.pos++;
+                if (++d.wpos >= d.dict_size) d.wpos -= d.dict_size;
+                d.bytes_left--;
+                return RUN_CONTINUE;
+            }
+        } else {
+            uint32_t dist;
+            BIT_NN(P_IS_REP_G1 + d.state, bit); // :777-813
+            if (bit == 0) {
+                dist = d.rep1;
+                d.rep1 = d.rep0;
+                d.rep0 = dist; // rotated before the normalise (:785-798)
+                NORMALIZE();
+            } else {
+                NORMALIZE();
+                BIT_NN(P_IS_REP_G2 + d.state, bit); // :816-861
+                if (bit == 0) {
+                    dist = d.rep2;
+                    d.rep2 = d.rep1;
+                } else {
+                    dist = d.rep3;
+                    d.rep3 = d.rep2;
+                    d.rep2 = d.rep1;
+                }
+                d.rep1 = d.rep0;
+                d.rep0 = dist;
+                NORMALIZE();
+            }
+        }
+        LEN_DECODE(P_REP_LEN, length);
+        d.state = d.state < 7 ? 8 : 11; // stateUpdateRep :933,1027,1103
+        length += kMatchMinLen;
+    }
+
+    // window.CopyMatch + size bookkeeping, :657-668, 936-947, 1030-1041, 1106-1117
+    {
+        bool truncated = false, overflow = false;
+        if (d.size_defined && d.bytes_left < length) {
+            length = d.bytes_left;
+            truncated = true;
+        }
+        if (length > d.out_cap - d.pos) {
+            length = d.out_cap - d.pos;
+            overflow = true;
+        }
+        uint32_t dist = d.rep0 + 1;
+        if (dist == 0) dist = d.dict_size; // CopyMatch(0, n) re-reads the slot being written
+        if (length > 0) wave_copy(out, d, dist, length, lane);
+        d.pos += length;
+        d.wpos += length;
+        if (d.wpos >= d.dict_size) d.wpos -= d.dict_size; // window.go:67-71
+        d.bytes_left -= length;
+        if (overflow) return RUN_OUT_CAP;
+        if (truncated) return RUN_ERR_RESULT;
+    }
+    return RUN_CONTINUE;
+}
+
+#undef NORMALIZE
+#undef BIT_NN
+#undef BIT
+#undef TREE
+#undef RTREE
+#undef LEN_DECODE
+
+// ================================================================================
+//  FAST path: hand-scheduled.  Same arithmetic, same order of model updates; the
+//  end-of-input / capacity / truncation tests are hoisted into lzma_run.
+// ================================================================================
+// Register roles inside the asm blocks
+//   range, code          SGPR   range coder
+//   p                    SGPR   probability of the node being decoded
+//   bit, t0, t1          SGPR   decision and temporaries
+//   cur, arel            SGPR   input window cursor (see IN_BYTE)
+//   vin                  VGPR   the 256-byte input window
+//
+// The decision core: the borrow of `code - bound` IS the decision (SCC), four
+// s_cselect pick range / code / the update constant / the bit.  The new probability
+// p - ((p - k) >>a 5) is formed on the VALU because it is only ever stored to LDS.
+#define XLZ_CORE                                                                                  \
+    "s_lshr_b32 %[t0], %[range], 11\n\t"                                                          \
+    "s_mul_i32 %[t0], %[t0], %[p]\n\t"                                                            \
+    "s_sub_u32 %[t1], %[range], %[t0]\n\t"                                                        \
+    "s_sub_u32 %[bit], %[code], %[t0]\n\t"                                                        \
+    "s_cselect_b32 %[range], %[t0], %[t1]\n\t"                                                    \
+    "s_cselect_b32 %[code], %[code], %[bit]\n\t"                                                  \
+    "s_cselect_b32 %[t1], 0x7e1, 0\n\t"                                                           \
+    "s_cselect_b32 %[bit], 0, 1\n\t"                                                              \
+    "s_sub_u32 %[t1], %[p], %[t1]\n\t"                                                            \
+    "v_ashrrev_i32 v63, 5, %[t1]\n\t"                                                           \
+    "v_sub_u32 v63, %[p], v63\n\t"
+
+// normalisation test: falls through when range >= 2^24 (the common case)
+#define XLZ_NCHK(K)                                                                               \
+    "s_lshr_b32 %[t0], %[range], 24\n\t"                                                          \
+    "s_cbranch_scc0 .Ln" K "_%=\n"                                                                \
+    ".Lb" K "_%=:\n\t"
+
+// out-of-line normalisation (decompress.go:33-42): shift in one byte of the window
+#define XLZ_NSTUB(K)                                                                              \
+    ".Ln" K "_%=:\n\t"                                                                            \
+    "s_lshl_b32 %[range], %[range], 8\n\t"                                                        \
+    "s_lshl_b32 %[code], %[code], 8\n\t"                                                          \
+    "s_and_b32 %[t0], %[cur], 0xff\n\t"                                                           \
+    "s_or_b32 %[code], %[code], %[t0]\n\t"                                                        \
+    "s_lshr_b32 %[cur], %[cur], 8\n\t"                                                            \
+    "s_add_u32 %[arel], %[arel], 1\n\t"                                                           \
+    "s_and_b32 %[t0], %[arel], 3\n\t"                                                             \
+    "s_cbranch_scc1 .Lb" K "_%=\n\t"                                                              \
+    "s_lshr_b32 %[t0], %[arel], 2\n\t"                                                            \
+    "v_readlane_b32 %[cur], %[vin], %[t0]\n\t"                                                    \
+    "s_branch .Lb" K "_%=\n"
+
+// The asm blocks have NO VGPR outputs: hipcc merges the result structs of identical asm
+// blocks through PHIs, and a struct with a VGPR member makes every member (range, code ...)
+// "divergent" for it.  Temporaries are the fixed registers v60..v63, declared as clobbers.
+#define XLZ_VTMP "v60", "v61", "v62", "v63"
+
+#define XLZ_RC_OPERANDS                                                                           \
+    [range] "+s"(d.range), [code] "+s"(d.code), [cur] "+s"(d.cur), [arel] "+s"(d.arel)
+
+// LDS byte address of probs[0] (0 unless the compiler places something in front of it)
+#define XLZ_LDS0 ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)probs)
+
+// One decision on probs[idx] (no look-ahead: the probability is fetched here).
+__device__ __forceinline__ uint32_t fbit(Dec &d, const uint16_t *probs, uint32_t idx)
+{
+    uint32_t bit, t0, t1, p;
+    const uint32_t va = XLZ_LDS0 + (idx << 1);
+    asm volatile("ds_read_u16 v62, %[va]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_readfirstlane_b32 %[p], v62\n\t" XLZ_CORE "ds_write_b16 %[va], v63\n\t" XLZ_NCHK("0")
+                 "s_branch .Le_%=\n" XLZ_NSTUB("0") ".Le_%=:"
+                 : XLZ_RC_OPERANDS, [bit] "=&s"(bit), [t0] "=&s"(t0), [t1] "=&s"(t1), [p] "=&s"(p)
+                 : [va] "v"(va), [vin] "v"(d.vin)
+                 : "scc", "memory", XLZ_VTMP);
+    return bit;
+}
+
+// fbit without the trailing normalisation (the reference rotates reps in between,
+// decompress.go:785-798)
+__device__ __forceinline__ uint32_t fbit_nn(Dec &d, const uint16_t *probs, uint32_t idx)
+{
+    uint32_t bit, t0, t1, p;
+    const uint32_t va = XLZ_LDS0 + (idx << 1);
+    asm volatile("ds_read_u16 v62, %[va]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_readfirstlane_b32 %[p], v62\n\t" XLZ_CORE "ds_write_b16 %[va], v63"
+                 : [range] "+s"(d.range), [code] "+s"(d.code), [bit] "=&s"(bit), [t0] "=&s"(t0), [t1] "=&s"(t1),
+                   [p] "=&s"(p)
+                 : [va] "v"(va)
+                 : "scc", "memory", XLZ_VTMP);
+    return bit;
+}
+
+__device__ __forceinline__ void fnorm(Dec &d)
+{
+    uint32_t t0;
+    asm volatile(XLZ_NCHK("0") "s_branch .Le_%=\n" XLZ_NSTUB("0") ".Le_%=:"
+                 : XLZ_RC_OPERANDS, [t0] "=&s"(t0)
+                 : [vin] "v"(d.vin)
+                 : "scc");
+}
+
+// One level of a bit tree with look-ahead.  On entry p = probs[base + m].  While the
+// decision on node m is computed, lanes 0 and 1 fetch the two children 2m and 2m+1
+// (vbl = byte address of the tree base + 2*lane); once the bit is known v_readlane picks
+// the child's probability -- the LDS round trip is off the critical path.
+#define XLZ_LEVEL(K)                                                                              \
+    "v_lshl_add_u32 v61, %[m], 2, %[vbl]\n\t"                                                     \
+    "ds_read_u16 v62, v61\n\t" XLZ_CORE "v_lshl_add_u32 v60, %[m], 1, %[vbu]\n\t"                 \
+    "ds_write_b16 v60, v63\n\t"                                                                   \
+    "s_lshl1_add_u32 %[m], %[m], %[bit]\n\t" XLZ_NCHK(K) "s_waitcnt lgkmcnt(0)\n\t"               \
+    "v_readlane_b32 %[p], v62, %[bit]\n\t"
+
+#define XLZ_LEVEL_LAST(K)                                                                         \
+    XLZ_CORE "v_lshl_add_u32 v60, %[m], 1, %[vbu]\n\t"                                            \
+    "ds_write_b16 v60, v63\n\t"                                                                   \
+    "s_lshl1_add_u32 %[m], %[m], %[bit]\n\t" XLZ_NCHK(K)
+
+#define XLZ_TREE_OPERANDS                                                                         \
+    XLZ_RC_OPERANDS, [m] "+s"(m), [p] "+s"(p), [bit] "=&s"(bit), [t0] "=&s"(t0), [t1] "=&s"(t1)
+
+#define XLZ_TREE_PROLOGUE                                                                         \
+    uint32_t m = 1, bit, t0, t1;                                                                  \
+    const uint32_t vbu = XLZ_LDS0 + (base << 1); /* byte address of the tree base (uniform) */   \
+    const uint32_t vbl = vbu + (lane << 1); /* ... + 2*lane: lane j addresses child j */          \
+    uint32_t p = RFL(probs[base + 1]);
+
+// forward bit trees (bit_tree_decoder.go:18-40), fully unrolled.  Returns m with its
+// leading 1 (m - (1 << NB) is the symbol).
+__device__ __forceinline__ uint32_t ftree3(Dec &d, const uint16_t *probs, uint32_t base, uint32_t lane)
+{
+    XLZ_TREE_PROLOGUE
+    asm volatile(XLZ_LEVEL("0") XLZ_LEVEL("1") XLZ_LEVEL_LAST("2") "s_branch .Le_%=\n" XLZ_NSTUB("0") XLZ_NSTUB("1")
+                     XLZ_NSTUB("2") ".Le_%=:"
+                 : XLZ_TREE_OPERANDS
+                 : [vbl] "v"(vbl), [vbu] "v"(vbu), [vin] "v"(d.vin)
+                 : "scc", "memory", XLZ_VTMP);
+    return m;
+}
+
+__device__ __forceinline__ uint32_t ftree4(Dec &d, const uint16_t *probs, uint32_t base, uint32_t lane)
+{
+    XLZ_TREE_PROLOGUE
+    asm volatile(XLZ_LEVEL("0") XLZ_LEVEL("1") XLZ_LEVEL("2") XLZ_LEVEL_LAST("3") "s_branch .Le_%=\n" XLZ_NSTUB("0")
+                     XLZ_NSTUB("1") XLZ_NSTUB("2") XLZ_NSTUB("3") ".Le_%=:"
+                 : XLZ_TREE_OPERANDS
+                 : [vbl] "v"(vbl), [vbu] "v"(vbu), [vin] "v"(d.vin)
+                 : "scc", "memory", XLZ_VTMP);
+    return m;
+}
+
+__device__ __forceinline__ uint32_t ftree6(Dec &d, const uint16_t *probs, uint32_t base, uint32_t lane)
+{
+    XLZ_TREE_PROLOGUE
+    asm volatile(XLZ_LEVEL("0") XLZ_LEVEL("1") XLZ_LEVEL("2") XLZ_LEVEL("3") XLZ_LEVEL("4") XLZ_LEVEL_LAST("5")
+                 "s_branch .Le_%=\n" XLZ_NSTUB("0") XLZ_NSTUB("1") XLZ_NSTUB("2") XLZ_NSTUB("3") XLZ_NSTUB("4")
+                     XLZ_NSTUB("5") ".Le_%=:"
+                 : XLZ_TREE_OPERANDS
+                 : [vbl] "v"(vbl), [vbu] "v"(vbu), [vin] "v"(d.vin)
+                 : "scc", "memory", XLZ_VTMP);
+    return m;
+}
+
+__device__ __forceinline__ uint32_t ftree8(Dec &d, const uint16_t *probs, uint32_t base, uint32_t lane)
+{
+    XLZ_TREE_PROLOGUE
+    asm volatile(XLZ_LEVEL("0") XLZ_LEVEL("1") XLZ_LEVEL("2") XLZ_LEVEL("3") XLZ_LEVEL("4") XLZ_LEVEL("5")
+                     XLZ_LEVEL("6") XLZ_LEVEL_LAST("7") "s_branch .Le_%=\n" XLZ_NSTUB("0") XLZ_NSTUB("1") XLZ_NSTUB("2")
+                         XLZ_NSTUB("3") XLZ_NSTUB("4") XLZ_NSTUB("5") XLZ_NSTUB("6") XLZ_NSTUB("7") ".Le_%=:"
+                 : XLZ_TREE_OPERANDS
+                 : [vbl] "v"(vbl), [vbu] "v"(vbu), [vin] "v"(d.vin)
+                 : "scc", "memory", XLZ_VTMP);
+    return m;
+}
+
+// the rest of a literal's plain tree from node m (< 0x100) on, as a loop with look-ahead
+// (used after a matched literal left the match path, decompress.go:127-166)
+__device__ __forceinline__ uint32_t ftree_rest(Dec &d, const uint16_t *probs, uint32_t base, uint32_t m,
+                                               uint32_t lane)
+{
+    uint32_t bit, t0, t1;
+    const uint32_t vbu = XLZ_LDS0 + (base << 1);
+    const uint32_t vbl = vbu + (lane << 1);
+    uint32_t p = RFL(probs[base + m]);
+    asm volatile(".Lt_%=:\n\t" XLZ_LEVEL("0") "s_cmpk_lt_u32 %[m], 0x100\n\t"
+                 "s_cbranch_scc1 .Lt_%=\n\t"
+                 "s_branch .Le_%=\n" XLZ_NSTUB("0") ".Le_%=:"
+                 : XLZ_TREE_OPERANDS
+                 : [vbl] "v"(vbl), [vbu] "v"(vbu), [vin] "v"(d.vin)
+                 : "scc", "memory", XLZ_VTMP);
+    return m;
+}
+
+// lenDecoder.Decode (len_decoder.go:34-60); returns the raw length (0..271)
+__device__ __forceinline__ uint32_t flen(Dec &d, const uint16_t *probs, uint32_t lbase, uint32_t pos_state,
+                                         uint32_t lane)
+{
+    if (fbit(d, probs, lbase + LEN_CHOICE) == 0) return ftree3(d, probs, lbase + LEN_LOW + (pos_state << 3), lane) - 8;
+    if (fbit(d, probs, lbase + LEN_CHOICE2) == 0) return ftree3(d, probs, lbase + LEN_MID + (pos_state << 3), lane);
+    return 16 + ftree8(d, probs, lbase + LEN_HIGH, lane) - 256;
+}
+
+// ONE packet, hot path.  lzma_run guarantees: >= kFastInput readable input bytes inside the
+// window, >= kFastOutput bytes of output room, and (defined size) >= kFastOutput bytesLeft.
+__device__ __forceinline__ int lzma_packet_fast(Dec &d, uint16_t *probs, uint8_t *__restrict__ out, uint32_t lane)
+{
+    uint32_t length;
+    const uint32_t pos_state = d.wpos & d.pos_mask;              // :22
+    const uint32_t state2 = (d.state << kPosBitsMax) + pos_state; // :23
+
+    if (fbit(d, probs, P_IS_MATCH + state2) == 0) {
+        // ---- literal, decompress.go:44-175 ----
+        const uint32_t lit_state = ((d.wpos & d.lp_mask) << d.lc) + (d.prev_byte >> (8 - d.lc)); // :56
+        const uint32_t lbase = P_LIT + kLitCoderSize * lit_state;                              // :57
+        uint32_t symbol;
+        if (d.state >= 7) { // matched literal :59-114
+            uint32_t mb = d.match_byte, bit;
+            symbol = 1;
+            do {
+                const uint32_t match_bit = (mb >> 7) & 1;
+                mb <<= 1;
+                bit = fbit(d, probs, lbase + ((1 + match_bit) << 8) + symbol);
+                symbol = (symbol << 1) | bit;
+                if (match_bit != bit) break;
+            } while (symbol < 0x100);
+            if (symbol < 0x100) symbol = ftree_rest(d, probs, lbase, symbol, lane);
+        } else {
+            symbol = ftree8(d, probs, lbase, lane); // :127-166
+        }
+        symbol &= 0xFF;
+        out[d.pos] = (uint8_t)symbol; // window.PutByte :168 (all lanes, same byte, same address)
+        d.pos++;
+        if (++d.wpos >= d.dict_size) d.wpos -= d.dict_size; // window.go:38-41
+        d.prev_byte = symbol;
+        d.state = upd_literal(d.state); // :171
+        d.bytes_left--;                 // :172
+        return RUN_CONTINUE;
+    }
+
+    if (fbit(d, probs, P_IS_REP + d.state) == 0) {
+        // ---- simple match, :215-668 ----
+        d.rep3 = d.rep2;
+        d.rep2 = d.rep1;
+        d.rep1 = d.rep0; // :216
+        length = flen(d, probs, P_LEN, pos_state, lane);
+        d.state = d.state < 7 ? 7 : 10; // stateUpdateMatch :431
+        const uint32_t len_state = length > 3 ? 3 : length;
+        const uint32_t pos_slot = ftree6(d, probs, P_POS_SLOT + (len_state << 6), lane) - 64; // :441-486
+        if (pos_slot < 4) {
+            d.rep0 = pos_slot; // :488-489
+        } else {
+            const uint32_t nbits = (pos_slot >> 1) - 1;
+            uint32_t dist = (2 | (pos_slot & 1)) << nbits; // :491-492
+            if (pos_slot < kEndPosModelIndex) {
+                // reverse bit tree over posDecoders :495-546
+                const uint32_t base = P_POS_DEC + dist - pos_slot;
+                uint32_t m = 1, sym = 0;
+                _Pragma("unroll 1") for (uint32_t k = 0; k < nbits; k++)
+                {
+                    const uint32_t b = fbit(d, probs, base + m);
+                    m = (m << 1) | b;
+                    sym |= b << k;
+                }
+                d.rep0 = dist + sym;
+            } else {
+                uint32_t res = 0; // DecodeDirectBits :549-577
+                _Pragma("unroll 1") for (uint32_t n = nbits - kNumAlignBits; n > 0; n--)
+                {
+                    d.range >>= 1;
+                    d.code -= d.range;
+                    const uint32_t t = 0u - (d.code >> 31);
+                    d.code += d.range & t;
+                    res = (res << 1) + (t + 1);
+                    fnorm(d);
+                }
+                dist += res << kNumAlignBits;
+                // reverse bit tree over alignDecoderProbs :579-625: m = 1 b0 b1 b2 b3
+                const uint32_t m = ftree4(d, probs, P_ALIGN, lane);
+                d.rep0 = dist + (__builtin_bitreverse32(m) >> 28); // :627-628
+            }
+        }
+        if (d.rep0 == 0xFFFFFFFFu) { // end marker :633-645
+            if (d.code == 0) {
+                if (d.size_defined && d.bytes_left > 0) return RUN_ERR_RESULT;
+                return RUN_END;
+            }
+            return RUN_ERR_RESULT;
+        }
+        if (bad_distance(d)) return RUN_ERR_RESULT; // :651-653
+        length += kMatchMinLen;                     // :656
+    } else {
+        // ---- rep match, :685-1123 ----
+        if (d.pos == d.wbase) return RUN_ERR_RESULT; // window.IsEmpty :690-692
+        if (fbit(d, probs, P_IS_REP_G0 + d.state) == 0) {   // :694-772
+            if (fbit(d, probs, P_IS_REP0_LONG + state2) == 0) { // short rep :715-739
+                d.state = d.state < 7 ? 9 : 11;
+                uint32_t dist = d.rep0 + 1;
+                if (dist == 0) dist = d.dict_size;
+                wave_copy(out, d, dist, 1, lane);
+                d.pos++;
+                if (++d.wpos >= d.dict_size) d.wpos -= d.dict_size;
+                d.bytes_left--;
+                return RUN_CONTINUE;
+            }
+        } else {
+            uint32_t dist;
+            if (fbit_nn(d, probs, P_IS_REP_G1 + d.state) == 0) { // :777-813
+                dist = d.rep1;
+                d.rep1 = d.rep0;
+                d.rep0 = dist; // rotated before the normalise (:785-798)
+                fnorm(d);
+            } else {
+                fnorm(d);
+                if (fbit_nn(d, probs, P_IS_REP_G2 + d.state) == 0) { // :816-861
+                    dist = d.rep2;
+                    d.rep2 = d.rep1;
+                } else {
+                    dist = d.rep3;
+                    d.rep3 = d.rep2;
+                    d.rep2 = d.rep1;
+                }
+                d.rep1 = d.rep0;
+                d.rep0 = dist;
+                fnorm(d);
+            }
+        }
+        length = flen(d, probs, P_REP_LEN, pos_state, lane);
+        d.state = d.state < 7 ? 8 : 11; // stateUpdateRep :933,1027,1103
+        length += kMatchMinLen;
+    }
+
+    // window.CopyMatch, :664-667 etc. (no truncation / overflow possible here)
+    {
+        uint32_t dist = d.rep0 + 1;
+        if (dist == 0) dist = d.dict_size;
+        wave_copy(out, d, dist, length, lane);
+        d.pos += length;
+        d.wpos += length;
+        if (d.wpos >= d.dict_size) d.wpos -= d.dict_size; // window.go:67-71
+        d.bytes_left -= length;
+    }
+    return RUN_CONTINUE;
+}
+
+// (*Reader1).decompress run to the end of the current LZMA chunk (decompress.go:8-1136)
 __device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint8_t *__restrict__ out, uint32_t lane)
 {
     for (;;) {
-        uint32_t bit, length;
-
         // decompress.go:14-20
         if (d.size_defined && d.bytes_left == 0 && d.code == 0) return RUN_END;
-
-        const uint32_t pos_state = d.wpos & d.pos_mask;              // :22
-        const uint32_t state2 = (d.state << kPosBitsMax) + pos_state; // :23
-
-        BIT(P_IS_MATCH + state2, bit); // :25-43,176-190
-        if (bit == 0) {
-            // ---- literal, decompress.go:44-175 ----
-            if (d.size_defined && d.bytes_left == 0) return RUN_ERR_RESULT; // :45-47
-            const uint32_t lit_state = ((d.wpos & d.lp_mask) << d.lc) + (d.prev_byte >> (8 - d.lc)); // :56
-            const uint32_t lbase = P_LIT + kLitCoderSize * lit_state;                              // :57
-            uint32_t symbol = 1;
-            if (d.state >= 7) { // matched literal :59-114
-                uint32_t mb = d.match_byte;
-                do {
-                    const uint32_t match_bit = (mb >> 7) & 1;
-                    mb <<= 1;
-                    BIT(lbase + ((1 + match_bit) << 8) + symbol, bit);
-                    symbol = (symbol << 1) | bit;
-                    if (match_bit != bit) break;
-                } while (symbol < 0x100);
-            }
-            while (symbol < 0x100) { // :127-166
-                BIT(lbase + symbol, bit);
-                symbol = (symbol << 1) | bit;
-            }
-            symbol &= 0xFF;
-            if (d.pos >= d.out_cap) return RUN_OUT_CAP;
-            out[d.pos] = (uint8_t)symbol; // window.PutByte :168 (all lanes, same byte, same address)
-            d.pos++;
-            if (++d.wpos >= d.dict_size) d.wpos -= d.dict_size; // window.go:38-41
-            d.prev_byte = symbol;
-            d.state = upd_literal(d.state); // :171
-            d.bytes_left--;                 // :172 (wraps harmlessly when the size is undefined)
-            continue;
-        }
-
-        BIT(P_IS_REP + d.state, bit); // :195-213,669-683
-        if (bit == 0) {
-            // ---- simple match, :215-668 ----
-            d.rep3 = d.rep2;
-            d.rep2 = d.rep1;
-            d.rep1 = d.rep0; // :216
-            LEN_DECODE(P_LEN, length);
-            d.state = d.state < 7 ? 7 : 10; // stateUpdateMatch :431
-            const uint32_t len_state = length > 3 ? 3 : length;
-            uint32_t pos_slot;
-            TREE(P_POS_SLOT + (len_state << 6), 6, pos_slot); // :441-486
-            pos_slot -= 64;
-            if (pos_slot < 4) {
-                d.rep0 = pos_slot; // :488-489
-            } else {
-                const uint32_t nbits = (pos_slot >> 1) - 1;
-                uint32_t dist = (2 | (pos_slot & 1)) << nbits; // :491-492
-                uint32_t sym;
-                if (pos_slot < kEndPosModelIndex) {
-                    RTREE(P_POS_DEC + dist - pos_slot, nbits, sym); // :495-546
-                    d.rep0 = dist + sym;
-                } else {
-                    uint32_t res = 0; // DecodeDirectBits :549-577
-                    _Pragma("unroll 1") for (uint32_t n = nbits - kNumAlignBits; n > 0; n--)
-                    {
-                        d.range >>= 1;
-                        d.code -= d.range;
-                        const uint32_t t = 0u - (d.code >> 31);
-                        d.code += d.range & t;
-                        res = (res << 1) + (t + 1);
-                        NORMALIZE();
-                    }
-                    dist += res << kNumAlignBits;
-                    RTREE(P_ALIGN, kNumAlignBits, sym); // :579-625
-                    d.rep0 = dist + sym;                // :627-628
-                }
-            }
-            if (d.rep0 == 0xFFFFFFFFu) { // end marker :633-645
-                if (d.code == 0) {
-                    if (d.size_defined && d.bytes_left > 0) return RUN_ERR_RESULT;
-                    return RUN_END;
-                }
-                return RUN_ERR_RESULT;
-            }
-            if (d.size_defined && d.bytes_left == 0) return RUN_ERR_RESULT; // :647-649
-            // :651-653  rep0 >= size || !CheckDistance(rep0)   (window.go:89-91)
-            {
-                const bool is_full = (d.pos - d.wbase) >= d.dict_size;
-                if (d.rep0 >= d.dict_size || !(is_full || d.rep0 <= d.wpos)) return RUN_ERR_RESULT;
-            }
-            length += kMatchMinLen; // :656
-        } else {
-            // ---- rep match, :685-1123 ----
-            if (d.size_defined && d.bytes_left == 0) return RUN_ERR_RESULT; // :686-688
-            if (d.pos == d.wbase) return RUN_ERR_RESULT;                    // window.IsEmpty :690-692
-            BIT(P_IS_REP_G0 + d.state, bit);                                // :694-772
-            if (bit == 0) {
-                BIT(P_IS_REP0_LONG + state2, bit); // :715-756
-                if (bit == 0) {                    // short rep :735-739
-                    d.state = d.state < 7 ? 9 : 11;
-                    if (d.pos >= d.out_cap) return RUN_OUT_CAP;
-                    uint32_t dist = d.rep0 + 1;
-                    if (dist == 0) dist = d.dict_size;
-                    wave_copy(out, d, dist, 1, lane);
-                    d.pos++;
-                    if (++d.wpos >= d.dict_size) d.wpos -= d.dict_size;
-                    d.bytes_left--;
-                    continue;
-                }
-            } else {
-                uint32_t dist;
-                BIT_NN(P_IS_REP_G1 + d.state, bit); // :777-813
-                if (bit == 0) {
-                    dist = d.rep1;
-                    d.rep1 = d.rep0;
-                    d.rep0 = dist; // rotated before the normalise (:785-798)
-                    NORMALIZE();
-                } else {
-                    NORMALIZE();
-                    BIT_NN(P_IS_REP_G2 + d.state, bit); // :816-861
-                    if (bit == 0) {
-                        dist = d.rep2;
-                        d.rep2 = d.rep1;
-                    } else {
-                        dist = d.rep3;
-                        d.rep3 = d.rep2;
-                        d.rep2 = d.rep1;
-                    }
-                    d.rep1 = d.rep0;
-                    d.rep0 = dist;
-                    NORMALIZE();
-                }
-            }
-            LEN_DECODE(P_REP_LEN, length);
-            d.state = d.state < 7 ? 8 : 11; // stateUpdateRep :933,1027,1103
-            length += kMatchMinLen;
-        }
-
-        // window.CopyMatch + size bookkeeping, :657-668, 936-947, 1030-1041, 1106-1117
-        {
-            bool truncated = false;
-            if (d.size_defined && d.bytes_left < length) {
-                length = d.bytes_left;
-                truncated = true;
-            }
-            bool overflow = false;
-            if (length > d.out_cap - d.pos) {
-                length = d.out_cap - d.pos;
-                overflow = true;
-            }
-            uint32_t dist = d.rep0 + 1;
-            if (dist == 0) dist = d.dict_size; // CopyMatch(0, n) re-reads the slot being written
-            if (length > 0) wave_copy(out, d, dist, length, lane);
-            d.pos += length;
-            d.wpos += length;
-            if (d.wpos >= d.dict_size) d.wpos -= d.dict_size; // window.go:67-71
-            d.bytes_left -= length;
-            if (overflow) return RUN_OUT_CAP;
-            if (truncated) return RUN_ERR_RESULT;
-        }
+        // keep kFastInput bytes of window ahead of the packet
+        if (d.arel > kInWindow - kFastInput) in_window(d, in_pos(d), lane);
+        const bool fast = (d.aend - in_pos(d)) >= kFastInput && (d.out_cap - d.pos) >= kFastOutput &&
+                          (!d.size_defined || d.bytes_left >= kFastOutput);
+        int r;
+        if (fast)
+            r = lzma_packet_fast(d, probs, out, lane);
+        else
+            r = lzma_packet_checked(d, probs, out, lane);
+        if (r != RUN_CONTINUE) return r;
     }
 }
 
@@ -419,10 +812,12 @@ __device__ __forceinline__ int rc_init(Dec &d)
     uint32_t b;
     d.range = 0xFFFFFFFFu;
     d.code = 0;
-    IN_BYTE(d, b, return 1);
+    if (in_pos(d) == d.aend) return 1;
+    IN_BYTE(b);
     if (b != 0) return 2;
     for (int i = 0; i < 4; i++) {
-        IN_BYTE(d, b, return 1);
+        if (in_pos(d) == d.aend) return 1;
+        IN_BYTE(b);
         d.code = (d.code << 8) | b;
     }
     return 0;
@@ -482,7 +877,7 @@ __global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
         int32_t status;
         probs_reset(probs, num_probs(lc + lp), lane); // newState -> Reset (state.go:47-61)
         set_unpack_size(d, unpack);
-        in_open(d, p.in_arena, in_off, in_len);
+        in_open(d, p.in_arena, in_off, in_len, lane);
         const int ir = rc_init(d); // Reader1.initialize, reader1.go:149-159
         if (ir == 1) {
             status = ST_ERR_HEADER_EOF;
@@ -497,7 +892,7 @@ __global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
         {
             UnitResult res; // every lane stores the same 16 bytes
             res.out_len = d.pos;
-            res.in_consumed = in_len - d.in_remain;
+            res.in_consumed = in_pos(d) - d.abase;
             res.status = status;
             res.aux = d.stale << 1;
             p.results[ui] = res;
@@ -505,7 +900,7 @@ __global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
     }
 }
 
-uint32_t decode_lds_bytes(uint32_t max_lc_lp) { return num_probs(max_lc_lp) * 2u; }
+uint32_t decode_lds_bytes(uint32_t max_lc_lp) { return num_probs(max_lc_lp) * 2u + 128u; }
 
 int launch_decode(const LaunchParams &p, int num_cus, void *stream)
 {
@@ -513,6 +908,10 @@ int launch_decode(const LaunchParams &p, int num_cus, void *stream)
     if (lds > kMaxLdsBytes) return -1;
     uint32_t per_cu = kMaxLdsBytes / lds;
     if (per_cu > 16) per_cu = 16;
+    if (const char *e = getenv("XLZ_PER_CU")) { // tuning knob: resident units per CU
+        const uint32_t v = (uint32_t)atoi(e);
+        if (v >= 1 && v < per_cu) per_cu = v;
+    }
     uint32_t grid = (uint32_t)num_cus * per_cu;
     if (grid > p.n_units) grid = p.n_units;
     if (grid == 0) return 0;
