@@ -43,6 +43,11 @@ enum : uint32_t {
     UNIT_LZMA2 = 2  // payload starts at an LZMA2 control byte; the wave walks the chunks
 };
 
+enum : uint32_t {
+    UNIT_F_LAST = 1,        // the parent stream's input ends with this unit
+    UNIT_F_HAVE_READER = 2  // not the stream's first unit: Reader2.lzmaReader already exists
+};
+
 struct Unit {
     uint64_t in_off;      // byte offset of the payload in the input arena
     uint64_t out_off;     // byte offset of this unit's output in the output arena
@@ -63,7 +68,8 @@ struct UnitResult {
     uint32_t out_len;
     uint32_t in_consumed;
     int32_t status;
-    uint32_t aux; // LZMA2: bit0 = unit ended on the end-of-stream control byte
+    uint32_t aux; // bit0: LZMA2 unit ended on an end-of-stream control byte; bit1: a copy reached
+                  // in front of the current dictionary epoch (stale window bytes read as 0)
 };
 
 // device-side status values = include/xlz.h

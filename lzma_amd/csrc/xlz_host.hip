@@ -62,6 +62,10 @@ struct StreamPlan {
     uint32_t first_unit = 0, n_units = 0;
     uint64_t out_off = 0; // into the output arena
     uint64_t out_cap = 0; // arena bytes reserved
+    uint64_t in_off = 0;  // LZMA2: arena offset of the stream's first byte
+    uint32_t in_len = 0;  // LZMA2: stream length
+    uint32_t dict_size = 0;
+    bool lzma2 = false;
 };
 
 struct xlz_batch {
@@ -80,6 +84,10 @@ struct xlz_batch {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ran = false;
     uint64_t algo_in = 0; // compressed payload bytes handed to the device
+    // per-stream results of the latest run (filled lazily by collect())
+    std::vector<xlz_result> final_results;
+    bool collected = false;
+    uint64_t sum_in = 0, sum_out = 0;
 };
 
 // ---------------------------------------------------------------- helpers ----
@@ -236,6 +244,69 @@ void plan_lzma_raw(const xlz_stream_desc &s, StreamPlan &pl, Unit &u, bool &has_
     has_unit = true;
 }
 
+// LZMA2: walk the chunk headers the way Reader2.startChunk does (reader2.go:100-214), trusting
+// each header's sizes, and cut the stream into units that are independent of everything
+// before them: a unit starts at a chunk that resets the dictionary AND whose first
+// compressed chunk carries new properties (hence resets the model too).  Every chunk
+// header states its uncompressed size, so the output offset of each unit is known up front.
+// A stream whose real decode does not follow its headers is detected after the launch
+// (a unit's produced / consumed counts differ) and re-decoded as ONE unit.
+struct Lz2Unit {
+    uint32_t in_start, in_len;
+    uint64_t out_start, expect_out;
+};
+
+void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint32_t &max_lc_lp)
+{
+    size_t pos = 0, unit_start = 0;
+    uint64_t out = 0, unit_out = 0;
+    size_t cand_pos = 0; // pending split: a stored chunk reset the dictionary here
+    uint64_t cand_out = 0;
+    bool cand = false;
+    auto cut = [&](size_t at, uint64_t at_out) {
+        units.push_back({(uint32_t)unit_start, (uint32_t)(at - unit_start), unit_out, at_out - unit_out});
+        unit_start = at;
+        unit_out = at_out;
+    };
+    while (pos < len) {
+        const uint8_t c = in[pos];
+        if (c == 0 || (c >= 3 && c < 0x80)) { // end of stream (reader2.go:175-199)
+            pos++;
+            break;
+        }
+        const bool stored = c < 3;
+        const unsigned sub = c >> 5;
+        const size_t hl = stored ? 3 : (sub >= 6 ? 6 : 5);
+        if (pos + hl > len) break; // truncated header: the device walker reports it
+        uint32_t unc = ((uint32_t)in[pos + 1] << 8) | in[pos + 2];
+        if (stored) {
+            unc += 1;
+            if (c == 1 && pos != 0) {
+                cand = true;
+                cand_pos = pos;
+                cand_out = out;
+            }
+            const size_t body = std::min<size_t>(unc, len - pos - hl);
+            pos += hl + body;
+            out += body;
+            continue;
+        }
+        unc = (unc | ((uint32_t)(c & 0x1F) << 16)) + 1;
+        const size_t comp = (((size_t)in[pos + 3] << 8) | in[pos + 4]) + 1;
+        if (sub >= 6) {
+            const uint8_t props = in[pos + 5];
+            if (props >= 225) break; // the walker reports ErrIncorrectProperties here
+            max_lc_lp = std::max<uint32_t>(max_lc_lp, (props % 9) + (props / 9) % 5);
+            if (sub == 7 && pos != 0 && pos != unit_start) cut(pos, out);
+            else if (cand && cand_pos != unit_start) cut(cand_pos, cand_out);
+        }
+        cand = false; // a compressed chunk without new props keeps the model: no cut
+        pos += hl + std::min(comp, len - pos - hl);
+        out += unc;
+    }
+    units.push_back({(uint32_t)unit_start, (uint32_t)(len - unit_start), unit_out, out - unit_out});
+}
+
 int batch_free(xlz_batch *b)
 {
     if (!b) return XLZ_OK;
@@ -291,12 +362,53 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
         }
         if (!has_unit) continue;
 
+        if (u.kind == UNIT_LZMA2) {
+            if (s.in_len > kMaxUnitBytes || s.out_cap > kMaxUnitBytes) {
+                pl.host_status = XLZ_ERR_UNSUPPORTED;
+                continue;
+            }
+            std::vector<Lz2Unit> lu;
+            uint32_t mx = 0;
+            scan_lzma2(s.in, s.in_len, lu, mx);
+            if (decode_lds_bytes(mx) > kMaxLdsBytes) {
+                pl.host_status = XLZ_ERR_UNSUPPORTED;
+                continue;
+            }
+            b->max_lc_lp = std::max(b->max_lc_lp, mx);
+            pl.lzma2 = true;
+            pl.in_off = in_cursor;
+            pl.in_len = (uint32_t)s.in_len;
+            pl.dict_size = u.dict_size;
+            pl.first_unit = (uint32_t)b->units.size();
+            pl.n_units = (uint32_t)lu.size();
+            pl.out_off = out_cursor;
+            pl.out_cap = s.out_cap;
+            for (size_t k = 0; k < lu.size(); k++) {
+                Unit v = u;
+                const bool last = k + 1 == lu.size();
+                v.in_off = in_cursor + lu[k].in_start;
+                v.in_len = lu[k].in_len;
+                v.out_off = out_cursor + std::min<uint64_t>(lu[k].out_start, s.out_cap);
+                const uint64_t room = s.out_cap > lu[k].out_start ? s.out_cap - lu[k].out_start : 0;
+                v.out_cap = (uint32_t)(last ? room : std::min<uint64_t>(room, lu[k].expect_out));
+                v.expect_out = (uint32_t)lu[k].expect_out;
+                v.stream = (uint32_t)i;
+                v.flags = (last ? UNIT_F_LAST : 0u) | (k ? UNIT_F_HAVE_READER : 0u);
+                b->units.push_back(v);
+                unit_src_off.push_back(lu[k].in_start);
+            }
+            b->algo_in += s.in_len;
+            in_cursor += align_up(s.in_len + 16, kArenaAlign);
+            out_cursor += align_up((size_t)s.out_cap + kOutTailPad, kArenaAlign);
+            continue;
+        }
+
         const size_t payload = s.in_len - pl.header_len;
         uint64_t cap = s.out_cap;
-        if (u.kind == UNIT_LZMA1 && u.unpack_size != kUnknownSize && u.unpack_size < cap)
+        if (u.unpack_size != kUnknownSize && u.unpack_size < cap)
             cap = u.unpack_size; // a defined size bounds the output (decompress.go:657-662)
         // 32-bit byte counters on the device: a defined size must fit them
-        const bool size_too_big = u.kind == UNIT_LZMA1 && u.unpack_size != kUnknownSize && u.unpack_size > kMaxUnitBytes;
+        const bool size_too_big = u.unpack_size != kUnknownSize && u.unpack_size > kMaxUnitBytes;
         if (payload > kMaxUnitBytes || cap > kMaxUnitBytes || size_too_big ||
             decode_lds_bytes((uint32_t)u.lc + u.lp) > kMaxLdsBytes) {
             pl.host_status = XLZ_ERR_UNSUPPORTED;
@@ -307,6 +419,7 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
         u.out_off = out_cursor;
         u.out_cap = (uint32_t)cap;
         u.stream = (uint32_t)i;
+        u.flags = UNIT_F_LAST;
         pl.first_unit = (uint32_t)b->units.size();
         pl.n_units = 1;
         pl.out_off = out_cursor;
@@ -387,6 +500,7 @@ extern "C" int xlz_batch_run(xlz_batch *b)
     }
     HIP_TRY(hipEventRecord(b->ev1, ctx->stream));
     b->ran = true;
+    b->collected = false;
     return XLZ_OK;
 }
 
@@ -407,47 +521,159 @@ extern "C" int xlz_batch_last_kernel_ms(xlz_batch *b, float *ms)
     return XLZ_OK;
 }
 
-extern "C" int xlz_batch_results(xlz_batch *b, xlz_result *results)
+namespace {
+
+// Launch `units` (already laid out against the batch's arenas) and fetch their results.
+int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResult> &res)
 {
-    if (!b || (!results && b->n) || !b->ran) return XLZ_ERR_BAD_ARG;
-    int st = xlz_batch_sync(b);
-    if (st != XLZ_OK) return st;
+    xlz_ctx *ctx = b->ctx;
+    const size_t n = units.size();
+    res.resize(n);
+    if (!n) return XLZ_OK;
+    Unit *d_units = nullptr;
+    uint32_t *d_order = nullptr;
+    UnitResult *d_res = nullptr;
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    int st = XLZ_ERR_DEVICE;
+    if (hipMalloc(&d_units, n * sizeof(Unit)) == hipSuccess && hipMalloc(&d_order, n * sizeof(uint32_t)) == hipSuccess &&
+        hipMalloc(&d_res, n * sizeof(UnitResult)) == hipSuccess &&
+        hipMemcpy(d_units, units.data(), n * sizeof(Unit), hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemsetAsync(ctx->queue, 0, 256, ctx->stream) == hipSuccess) {
+        LaunchParams p;
+        p.in_arena = b->d_in;
+        p.out_arena = b->d_out;
+        p.units = d_units;
+        p.order = d_order;
+        p.results = d_res;
+        p.queue = ctx->queue;
+        p.n_units = (uint32_t)n;
+        p.max_lc_lp = b->max_lc_lp;
+        if (launch_decode(p, ctx->num_cus, ctx->stream) == 0 && hipStreamSynchronize(ctx->stream) == hipSuccess &&
+            hipMemcpy(res.data(), d_res, n * sizeof(UnitResult), hipMemcpyDeviceToHost) == hipSuccess)
+            st = XLZ_OK;
+    }
+    if (d_units) (void)hipFree(d_units);
+    if (d_order) (void)hipFree(d_order);
+    if (d_res) (void)hipFree(d_res);
+    return st;
+}
+
+// Sync, fetch unit results, fold them into per-stream results.  An LZMA2 stream whose
+// units did not produce / consume exactly what its chunk headers announced is decoded
+// again as ONE unit: that pass follows the reference's framing byte for byte.
+int collect(xlz_batch *b)
+{
+    if (b->collected) return XLZ_OK;
+    xlz_ctx *ctx = b->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     std::vector<UnitResult> ur(b->units.size());
     if (!ur.empty())
         HIP_TRY(hipMemcpy(ur.data(), b->d_results, ur.size() * sizeof(UnitResult), hipMemcpyDeviceToHost));
+    b->final_results.assign(b->n, xlz_result{});
+    std::vector<size_t> redo;
     for (size_t i = 0; i < b->n; i++) {
         const StreamPlan &pl = b->plans[i];
-        xlz_result &r = results[i];
-        memset(&r, 0, sizeof r);
+        xlz_result &r = b->final_results[i];
         if (pl.host_status != 1) { // settled while parsing
             r.status = pl.host_status;
             r.in_consumed = pl.host_in_consumed;
             continue;
         }
-        const UnitResult &u = ur[pl.first_unit];
-        r.status = u.status;
-        r.out_len = u.out_len;
-        r.in_consumed = (uint64_t)pl.header_len + u.in_consumed;
+        if (!pl.lzma2) {
+            const UnitResult &u = ur[pl.first_unit];
+            r.status = u.status;
+            r.out_len = u.out_len;
+            r.in_consumed = (uint64_t)pl.header_len + u.in_consumed;
+            continue;
+        }
+        uint64_t out = 0, in_base = 0;
+        bool settled = false;
+        for (uint32_t k = 0; k < pl.n_units && !settled; k++) {
+            const Unit &un = b->units[pl.first_unit + k];
+            const UnitResult &u = ur[pl.first_unit + k];
+            const bool last = k + 1 == pl.n_units;
+            if (last) {
+                r.status = u.status;
+                r.out_len = out + u.out_len;
+                r.in_consumed = in_base + u.in_consumed;
+                settled = true;
+            } else if (u.status == ST_OK && !(u.aux & 1u) && u.out_len == un.expect_out && u.in_consumed == un.in_len) {
+                out += u.out_len;
+                in_base += u.in_consumed;
+            } else if (u.status < 0 && u.status != ST_ERR_OUT_CAP) {
+                // everything before this unit matched its headers, so the unit started from the
+                // reference's exact state and fails where the reference fails
+                r.status = u.status;
+                r.out_len = out + u.out_len;
+                r.in_consumed = in_base + u.in_consumed;
+                settled = true;
+            } else {
+                redo.push_back(i);
+                settled = true;
+            }
+        }
     }
+    if (!redo.empty()) {
+        std::vector<Unit> units;
+        for (size_t i : redo) {
+            const StreamPlan &pl = b->plans[i];
+            Unit u;
+            memset(&u, 0, sizeof u);
+            u.kind = UNIT_LZMA2;
+            u.in_off = pl.in_off;
+            u.in_len = pl.in_len;
+            u.out_off = pl.out_off;
+            u.out_cap = (uint32_t)pl.out_cap;
+            u.dict_size = pl.dict_size;
+            u.unpack_size = kUnknownSize;
+            u.stream = (uint32_t)i;
+            u.flags = UNIT_F_LAST;
+            units.push_back(u);
+        }
+        std::vector<UnitResult> res;
+        int st = run_units(b, units, res);
+        if (st != XLZ_OK) return st;
+        for (size_t k = 0; k < redo.size(); k++) {
+            xlz_result &r = b->final_results[redo[k]];
+            r.status = res[k].status;
+            r.out_len = res[k].out_len;
+            r.in_consumed = res[k].in_consumed;
+        }
+    }
+    b->sum_in = b->sum_out = 0;
+    for (size_t i = 0; i < b->n; i++) {
+        const StreamPlan &pl = b->plans[i];
+        if (pl.host_status != 1) continue;
+        b->sum_out += b->final_results[i].out_len;
+        b->sum_in += b->final_results[i].in_consumed - pl.header_len;
+    }
+    b->collected = true;
+    return XLZ_OK;
+}
+
+} // namespace
+
+extern "C" int xlz_batch_results(xlz_batch *b, xlz_result *results)
+{
+    if (!b || (!results && b->n) || !b->ran) return XLZ_ERR_BAD_ARG;
+    int st = collect(b);
+    if (st != XLZ_OK) return st;
+    for (size_t i = 0; i < b->n; i++) results[i] = b->final_results[i];
     return XLZ_OK;
 }
 
 extern "C" int xlz_batch_stats(xlz_batch *b, uint64_t *in_bytes, uint64_t *out_bytes, uint64_t *units)
 {
     if (!b || !b->ran) return XLZ_ERR_BAD_ARG;
-    int st = xlz_batch_sync(b);
+    int st = collect(b);
     if (st != XLZ_OK) return st;
-    std::vector<UnitResult> ur(b->units.size());
-    if (!ur.empty())
-        HIP_TRY(hipMemcpy(ur.data(), b->d_results, ur.size() * sizeof(UnitResult), hipMemcpyDeviceToHost));
-    uint64_t ci = 0, co = 0;
-    for (const UnitResult &u : ur) {
-        ci += u.in_consumed;
-        co += u.out_len;
-    }
-    if (in_bytes) *in_bytes = ci;
-    if (out_bytes) *out_bytes = co;
-    if (units) *units = ur.size();
+    if (in_bytes) *in_bytes = b->sum_in;
+    if (out_bytes) *out_bytes = b->sum_out;
+    if (units) *units = b->units.size();
     return XLZ_OK;
 }
 

@@ -111,6 +111,11 @@ __device__ __forceinline__ uint32_t umod_small(uint32_t i, uint32_t d)
 // 64 lanes store, so bytes [pos+len, pos+64) receive scratch values -- they are
 // not-yet-produced output (or the 64-byte pad behind the unit's region) and are
 // overwritten by later packets before anything can read them.
+//
+// PRECISE = true (checked path, i.e. near the end of a unit's output range, where the next
+// bytes may belong to a neighbouring unit of the same LZMA2 stream): lanes >= len write
+// their own source byte back to where they read it instead of touching bytes past the copy.
+template <bool PRECISE>
 __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ out, Dec &d, uint32_t dist, uint32_t len,
                                           uint32_t lane)
 {
@@ -121,11 +126,16 @@ __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ out, Dec &d, uin
     if (len < kWave) {
         uint32_t j = lane;
         if (wrap) j = umod_small(lane, dist);
+        if (PRECISE) j = lane <= len ? j : 0u; // never look past the copy
         const uint64_t vs = (uint64_t)pos + j;
         const bool ok = vs >= lo;
-        uint32_t b = out[ok ? vs - dist : 0];
-        b = ok ? b : 0u;
-        out[pos + lane] = (uint8_t)b;
+        const uint64_t sa = ok ? vs - dist : 0;
+        const uint32_t raw = out[sa];
+        const uint32_t b = ok ? raw : 0u;
+        if (PRECISE)
+            out[lane < len ? (uint64_t)pos + lane : sa] = (uint8_t)(lane < len ? b : raw);
+        else
+            out[pos + lane] = (uint8_t)b;
         d.prev_byte = (uint32_t)__builtin_amdgcn_readlane((int)b, len - 1);
         d.match_byte = (uint32_t)__builtin_amdgcn_readlane((int)b, len);
     } else {
@@ -133,11 +143,16 @@ __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ out, Dec &d, uin
             const uint32_t i = base + lane;
             uint32_t j = i;
             if (wrap) j = umod_small(i, dist);
+            if (PRECISE) j = i < len ? j : 0u;
             const uint64_t vs = (uint64_t)pos + j;
             const bool ok = vs >= lo;
-            uint32_t b = out[ok ? vs - dist : 0];
-            b = ok ? b : 0u;
-            out[pos + i] = (uint8_t)b;
+            const uint64_t sa = ok ? vs - dist : 0;
+            const uint32_t raw = out[sa];
+            const uint32_t b = ok ? raw : 0u;
+            if (PRECISE)
+                out[i < len ? (uint64_t)pos + i : sa] = (uint8_t)(i < len ? b : raw);
+            else
+                out[pos + i] = (uint8_t)b;
         }
         // bytes len-1 and len of the copy, re-read (long matches are rare)
         const uint32_t i = len - 1 + (lane & 1); // lanes 0 and 1 matter
@@ -380,7 +395,7 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
                 if (d.pos >= d.out_cap) return RUN_OUT_CAP;
                 uint32_t dist = d.rep0 + 1;
                 if (dist == 0) dist = d.dict_size;
-                wave_copy(out, d, dist, 1, lane);
+                wave_copy<true>(out, d, dist, 1, lane);
                 d.pos++;
                 if (++d.wpos >= d.dict_size) d.wpos -= d.dict_size;
                 d.bytes_left--;
@@ -428,7 +443,7 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
         }
         uint32_t dist = d.rep0 + 1;
         if (dist == 0) dist = d.dict_size; // CopyMatch(0, n) re-reads the slot being written
-        if (length > 0) wave_copy(out, d, dist, length, lane);
+        if (length > 0) wave_copy<true>(out, d, dist, length, lane);
         d.pos += length;
         d.wpos += length;
         if (d.wpos >= d.dict_size) d.wpos -= d.dict_size; // window.go:67-71
@@ -499,6 +514,22 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
 // "divergent" for it.  Temporaries are the fixed registers v60..v63, declared as clobbers.
 #define XLZ_VTMP "v60", "v61", "v62", "v63"
 
+// normalisation at the end of a block: one taken branch skips it in the common case
+#define XLZ_NORM_INLINE                                                                           \
+    "s_lshr_b32 %[t0], %[range], 24\n\t"                                                          \
+    "s_cbranch_scc1 .Le_%=\n\t"                                                                   \
+    "s_lshl_b32 %[range], %[range], 8\n\t"                                                        \
+    "s_lshl_b32 %[code], %[code], 8\n\t"                                                          \
+    "s_and_b32 %[t0], %[cur], 0xff\n\t"                                                           \
+    "s_or_b32 %[code], %[code], %[t0]\n\t"                                                        \
+    "s_lshr_b32 %[cur], %[cur], 8\n\t"                                                            \
+    "s_add_u32 %[arel], %[arel], 1\n\t"                                                           \
+    "s_and_b32 %[t0], %[arel], 3\n\t"                                                             \
+    "s_cbranch_scc1 .Le_%=\n\t"                                                                   \
+    "s_lshr_b32 %[t0], %[arel], 2\n\t"                                                            \
+    "v_readlane_b32 %[cur], %[vin], %[t0]\n"                                                       \
+    ".Le_%=:"
+
 #define XLZ_RC_OPERANDS                                                                           \
     [range] "+s"(d.range), [code] "+s"(d.code), [cur] "+s"(d.cur), [arel] "+s"(d.arel)
 
@@ -512,8 +543,7 @@ __device__ __forceinline__ uint32_t fbit(Dec &d, const uint16_t *probs, uint32_t
     const uint32_t va = XLZ_LDS0 + (idx << 1);
     asm volatile("ds_read_u16 v62, %[va]\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
-                 "v_readfirstlane_b32 %[p], v62\n\t" XLZ_CORE "ds_write_b16 %[va], v63\n\t" XLZ_NCHK("0")
-                 "s_branch .Le_%=\n" XLZ_NSTUB("0") ".Le_%=:"
+                 "v_readfirstlane_b32 %[p], v62\n\t" XLZ_CORE "ds_write_b16 %[va], v63\n\t" XLZ_NORM_INLINE
                  : XLZ_RC_OPERANDS, [bit] "=&s"(bit), [t0] "=&s"(t0), [t1] "=&s"(t1), [p] "=&s"(p)
                  : [va] "v"(va), [vin] "v"(d.vin)
                  : "scc", "memory", XLZ_VTMP);
@@ -539,7 +569,7 @@ __device__ __forceinline__ uint32_t fbit_nn(Dec &d, const uint16_t *probs, uint3
 __device__ __forceinline__ void fnorm(Dec &d)
 {
     uint32_t t0;
-    asm volatile(XLZ_NCHK("0") "s_branch .Le_%=\n" XLZ_NSTUB("0") ".Le_%=:"
+    asm volatile(XLZ_NORM_INLINE
                  : XLZ_RC_OPERANDS, [t0] "=&s"(t0)
                  : [vin] "v"(d.vin)
                  : "scc");
@@ -741,7 +771,7 @@ __device__ __forceinline__ int lzma_packet_fast(Dec &d, uint16_t *probs, uint8_t
                 d.state = d.state < 7 ? 9 : 11;
                 uint32_t dist = d.rep0 + 1;
                 if (dist == 0) dist = d.dict_size;
-                wave_copy(out, d, dist, 1, lane);
+                wave_copy<false>(out, d, dist, 1, lane);
                 d.pos++;
                 if (++d.wpos >= d.dict_size) d.wpos -= d.dict_size;
                 d.bytes_left--;
@@ -778,7 +808,7 @@ __device__ __forceinline__ int lzma_packet_fast(Dec &d, uint16_t *probs, uint8_t
     {
         uint32_t dist = d.rep0 + 1;
         if (dist == 0) dist = d.dict_size;
-        wave_copy(out, d, dist, length, lane);
+        wave_copy<false>(out, d, dist, length, lane);
         d.pos += length;
         d.wpos += length;
         if (d.wpos >= d.dict_size) d.wpos -= d.dict_size; // window.go:67-71
@@ -839,6 +869,131 @@ __device__ __forceinline__ void set_unpack_size(Dec &d, uint64_t u)
     d.bytes_left = (uint32_t)u; // host guarantees a defined size is < 4 GiB
 }
 
+// ---- LZMA2 framing (reader2.go:100-298), one wave walking the chunks of a unit ----
+// stored chunk body: window.ReadFrom + ReadPending (reader2.go:252-294, window.go:142-155)
+__device__ __forceinline__ void stored_copy(const uint8_t *__restrict__ src, uint8_t *__restrict__ out, uint32_t pos,
+                                            uint32_t n, uint32_t lane)
+{
+    // 64 bytes per step; lanes past the end re-copy the last byte (no divergent branch)
+    for (uint32_t base = 0; base < n; base += kWave) {
+        const uint32_t i = min(base + lane, n - 1);
+        out[pos + i] = src[i];
+    }
+}
+
+// prevByte / matchByte straight from the window (after a stored chunk they are not in registers)
+__device__ __forceinline__ void reload_context(Dec &d, const uint8_t *__restrict__ out, uint32_t lane)
+{
+    // lane 0: byte at distance 1, lane 1: byte at distance rep0 + 1 (window.GetByte, window.go:44-53)
+    uint32_t dist = (lane & 1) ? d.rep0 + 1 : 1u;
+    if (dist == 0) dist = d.dict_size;
+    const uint64_t lo = (uint64_t)dist + d.wbase;
+    const bool ok = (uint64_t)d.pos >= lo;
+    uint32_t b = out[ok ? d.pos - dist : 0];
+    b = ok ? b : 0u;
+    d.prev_byte = (uint32_t)__builtin_amdgcn_readlane((int)b, 0);
+    d.match_byte = (uint32_t)__builtin_amdgcn_readlane((int)b, 1);
+    if (d.pos == d.wbase) d.prev_byte = 0; // window.IsEmpty (decompress.go:50-53)
+}
+
+__device__ __forceinline__ void state_reset(Dec &d, uint16_t *probs, uint32_t lc_lp, uint32_t lane)
+{
+    probs_reset(probs, num_probs(lc_lp), lane); // state.Reset, state.go:79-121
+    d.state = 0;
+    d.rep0 = d.rep1 = d.rep2 = d.rep3 = 0;
+}
+
+// LZMA2 walker state that outlives a chunk
+struct Walk {
+    uint32_t unit_end; // first position after the unit's input
+    uint32_t lc_lp;
+    uint32_t h5;       // header[5] persists across chunks (reader2.go:37,147)
+    bool last_unit, have_reader, first_chunk;
+};
+
+enum : int32_t { WALK_RUN_CHUNK = 1000 }; // lzma2_next: a compressed chunk is set up, run it
+
+// Reader2.startChunk (reader2.go:100-173) plus the stored-chunk body.  Returns
+// WALK_RUN_CHUNK when an LZMA chunk is ready for lzma_run, otherwise the unit's final status.
+__device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, const uint8_t *__restrict__ in_bytes,
+                                              uint8_t *__restrict__ out, uint32_t max_lc_lp, uint32_t lane,
+                                              uint32_t &aux)
+{
+    for (;;) {
+        d.aend = w.unit_end;
+        if (in_pos(d) == w.unit_end) // ReadByte fails (reader2.go:103-110)
+            return w.last_unit ? ST_ERR_UNEXPECTED_EOF : ST_OK;
+        if (d.arel > kInWindow - kFastInput) in_window(d, in_pos(d), lane);
+        uint32_t c, h1 = 0, h2 = 0, h3 = 0, h4 = 0;
+        IN_BYTE(c);
+        // decodeChunkType (reader2.go:175-199): 0x03..0x7F fall through to end-of-stream
+        if (c == 0 || (c >= 3 && c < 0x80)) {
+            aux |= 1u;
+            return ST_OK;
+        }
+        const bool stored = c < 3;
+        const uint32_t sub = c >> 5;                            // 4 no reset, 5 state, 6 +props, 7 +dict
+        const uint32_t hl = stored ? 3u : (sub >= 6 ? 6u : 5u); // chunkLength (reader2.go:201-214)
+        if (w.unit_end - in_pos(d) < hl - 1) {                  // io.ReadFull comes up short (:121-128)
+            in_window(d, w.unit_end, lane);
+            return ST_ERR_UNEXPECTED_EOF;
+        }
+        IN_BYTE(h1);
+        IN_BYTE(h2);
+        if (!stored) {
+            IN_BYTE(h3);
+            IN_BYTE(h4);
+            if (hl == 6) IN_BYTE(w.h5);
+        }
+        uint32_t unc = (h1 << 8) | h2; // :130
+        if (c == 1 || sub == 7) {      // dictionary reset: window.Reset (:132-134, window.go:135-140)
+            d.wbase = d.pos;
+            d.wpos = 0;
+            d.prev_byte = 0; // window.IsEmpty again (decompress.go:50-53)
+        }
+        if (stored) {
+            unc++; // :137
+            uint32_t n = min(unc, w.unit_end - in_pos(d)); // a short source delivers what is there
+            bool overflow = false;
+            if (n > d.out_cap - d.pos) {
+                n = d.out_cap - d.pos;
+                overflow = true;
+            }
+            if (n) stored_copy(in_bytes + (in_pos(d) - d.abase), out, d.pos, n, lane);
+            d.pos += n;
+            d.wpos += n; // window.ReadFrom (window.go:146-153); the dictionary may be smaller than n
+            while (d.wpos >= d.dict_size) d.wpos -= d.dict_size;
+            in_window(d, in_pos(d) + n, lane);
+            if (overflow) return ST_ERR_OUT_CAP;
+            reload_context(d, out, lane);
+            continue;
+        }
+        unc |= (c & 0x1Fu) << 16; // :141-142
+        unc++;
+        const uint32_t comp = ((h3 << 8) | h4) + 1; // :143-144 (32-bit: SURVEY parity note 7)
+        if (!w.have_reader || sub >= 6) {
+            // NewReader1ForReader2 / Renew: props from header[5] (reader2.go:146-165)
+            if (w.h5 >= 225) return ST_ERR_PROPS; // DecodeProp, reader1.go:211-213
+            const uint32_t lc = w.h5 % 9, r = w.h5 / 9, lp = r % 5, pb = r / 5;
+            if (lc + lp > max_lc_lp) return ST_ERR_UNSUPPORTED; // LDS is sized by the host's header scan
+            d.lc = lc;
+            d.lp_mask = (1u << lp) - 1;
+            d.pos_mask = (1u << pb) - 1;
+            w.lc_lp = lc + lp;
+            state_reset(d, probs, w.lc_lp, lane);
+        } else if (sub == 5) {
+            state_reset(d, probs, w.lc_lp, lane); // :156-157
+        }
+        w.first_chunk = !w.have_reader;
+        w.have_reader = true;
+        // Reopen: SetUnpackSize + limitByteReader + rangeDec.Init (reader1.go:166-176)
+        d.size_defined = true;
+        d.bytes_left = unc;
+        d.aend = min(in_pos(d) + comp, w.unit_end);
+        return WALK_RUN_CHUNK;
+    }
+}
+
 __global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t probs[];
@@ -853,10 +1008,13 @@ __global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
         const uint32_t ui = RFL(p.order[q]);
         const Unit *up = p.units + ui;
         Dec d;
+        Walk w;
         const uint64_t in_off = rfl64(up->in_off);
         const uint64_t out_off = rfl64(up->out_off);
         const uint64_t unpack = rfl64(up->unpack_size);
         const uint32_t in_len = RFL(up->in_len);
+        const bool lzma2 = RFL(up->kind) == UNIT_LZMA2;
+        const uint32_t flags = RFL(up->flags);
         d.out_cap = RFL(up->out_cap);
         d.dict_size = RFL(up->dict_size);
         const uint32_t lc = RFL(up->lc), lp = RFL(up->lp), pb = RFL(up->pb);
@@ -873,28 +1031,51 @@ __global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
         d.prev_byte = 0;
         d.match_byte = 0;
         d.stale = 0;
-
-        int32_t status;
-        probs_reset(probs, num_probs(lc + lp), lane); // newState -> Reset (state.go:47-61)
+        d.range = 0;
+        d.code = 0;
         set_unpack_size(d, unpack);
         in_open(d, p.in_arena, in_off, in_len, lane);
-        const int ir = rc_init(d); // Reader1.initialize, reader1.go:149-159
-        if (ir == 1) {
-            status = ST_ERR_HEADER_EOF;
-        } else if (ir == 2) {
-            status = ST_ERR_RC_INIT;
-        } else {
+        w.unit_end = d.abase + in_len;
+        w.lc_lp = lc + lp;
+        w.h5 = 0;
+        w.last_unit = (flags & UNIT_F_LAST) != 0;
+        w.have_reader = (flags & UNIT_F_HAVE_READER) != 0;
+        w.first_chunk = true;
+        if (!lzma2) probs_reset(probs, num_probs(lc + lp), lane); // newState -> Reset (state.go:47-61)
+
+        int32_t status;
+        uint32_t aux = 0;
+        // LZMA1: exactly one "chunk" (the whole stream).  LZMA2: one per compressed chunk.
+        for (bool once = true;; once = false) {
+            if (lzma2) {
+                status = lzma2_next(d, w, probs, p.in_arena + in_off, out, p.max_lc_lp, lane, aux);
+                if (status != WALK_RUN_CHUNK) break;
+            } else if (!once) {
+                break;
+            }
+            const int ir = rc_init(d); // Reader1.initialize / Reopen (reader1.go:149-176)
+            if (ir == 1) { // io.EOF: a constructor error, or -- raw, from a later LZMA2 chunk -- a clean EOF
+                status = (!lzma2 || w.first_chunk) ? ST_ERR_HEADER_EOF : ST_OK_INPUT_EOF;
+                break;
+            }
+            if (ir == 2) {
+                status = ST_ERR_RC_INIT;
+                break;
+            }
             const int r = lzma_run(d, probs, out, lane);
             status = r == RUN_END ? ST_OK
                                   : r == RUN_INPUT_EOF ? ST_OK_INPUT_EOF
                                                        : r == RUN_OUT_CAP ? ST_ERR_OUT_CAP : ST_ERR_RESULT;
+            // LZMA2: io.EOF from the chunk -> next startChunk (reader2.go:234-241); the unread
+            // rest of a chunk is NOT skipped by the reference
+            if (status < 0) break;
         }
         {
             UnitResult res; // every lane stores the same 16 bytes
             res.out_len = d.pos;
             res.in_consumed = in_pos(d) - d.abase;
             res.status = status;
-            res.aux = d.stale << 1;
+            res.aux = aux | (d.stale << 1);
             p.results[ui] = res;
         }
     }

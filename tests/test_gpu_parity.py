@@ -159,3 +159,92 @@ def test_device_resident_batch_rerun_is_idempotent(ctx):
     assert cout == sum(len(p) for p in ps) and units == 16
     assert cin == sum(len(c) - 13 for c in cs)
     b.close()
+
+
+# ---------------------------------------------------------------- LZMA2 (reader2.go) ----
+from lzma_amd import FMT_LZMA2_RAW  # noqa: E402
+
+
+def _check_lzma2(ctx, blobs, dicts, caps):
+    got = lzma_amd.decode_batch(ctx, [Stream(b, FMT_LZMA2_RAW, out_cap=c, dict_size=ds)
+                                      for b, ds, c in zip(blobs, dicts, caps)])
+    for i, (b, ds, c) in enumerate(zip(blobs, dicts, caps)):
+        want = oracle.lzma2_raw(b, ds, c)
+        assert got[i][1] == want[1], "status of stream %d: gpu %d oracle %d" % (i, got[i][1], want[1])
+        assert got[i][0] == want[0], "bytes of stream %d differ" % i
+        assert got[i][2] == want[2], "in_consumed of stream %d: %d vs %d" % (i, got[i][2], want[2])
+    return got
+
+
+def test_lzma2_reference_asset(ctx, golden):
+    exp, data = golden
+    out, st, ic = lzma_amd.decode_batch(
+        ctx, [Stream(data["randomfile.dat.lzma2"], FMT_LZMA2_RAW, out_cap=2 << 20, dict_size=0)])[0]
+    assert st == 0 and ic == len(data["randomfile.dat.lzma2"])
+    assert hashlib.md5(out).hexdigest() == RANDOM_MD5  # reader2_test.go:12-29
+
+
+def test_lzma2_chunk_parallel_units(ctx):
+    # cfg4 shape: one stream = many independently compressed segments (dict reset + new props
+    # each) -> many units decoded concurrently; plus stored (incompressible) segments
+    segs = []
+    for i in range(40):
+        fam = "TRZM"[i % 4]
+        segs.append(corpus.plain(fam, 500 + i, 20_000 + 3001 * (i % 7)))
+    blob = corpus.lzma2_concat(segs, dict_size=1 << 16)
+    want = b"".join(segs)
+    got = _check_lzma2(ctx, [blob], [1 << 16], [len(want)])
+    assert got[0][0] == want and got[0][1] == 0
+
+
+def test_lzma2_state_carried_across_chunks(ctx):
+    # a single 3 MB segment: liblzma emits several chunks without dictionary reset, some with
+    # and some without state reset -> one unit, model carried from chunk to chunk
+    ps = [corpus.plain("T", 600, 3_000_000), corpus.plain("M", 601, 1_500_000), corpus.plain("Z", 602, 2_500_000)]
+    blobs = [corpus.compress_raw_lzma2(p, dict_size=1 << 20) for p in ps]
+    got = _check_lzma2(ctx, blobs, [1 << 20] * 3, [len(p) for p in ps])
+    for g, p in zip(got, ps):
+        assert g[0] == p and g[1] == 0
+
+
+def test_lzma2_other_props_and_small_dict(ctx):
+    ps = [corpus.plain("T", 610 + i, 300_000) for i in range(3)]
+    blobs = [corpus.compress_raw_lzma2(ps[0], dict_size=4096, lc=0, lp=2, pb=0),
+             corpus.compress_raw_lzma2(ps[1], dict_size=8192, lc=4, lp=0, pb=4),
+             corpus.lzma2_concat([ps[2][:100_000], ps[2][100_000:]], dict_size=65536, lc=2, lp=1, pb=1)]
+    _check_lzma2(ctx, blobs, [4096, 8192, 65536], [len(p) for p in ps])
+
+
+def test_lzma2_framing_edge_cases_match_oracle(ctx):
+    p = corpus.plain("T", 620, 150_000)
+    c = corpus.lzma2_concat([p[:50_000], p[50_000:100_000], p[100_000:]], dict_size=1 << 16)
+    blobs = [
+        b"", b"\x00", b"\x03garbage", b"\x01\x00", b"\x01\x00\x02abc", b"\x01\x00\x02abc\x00", b"\x01\x00\x04ab",
+        b"\x02\x00\x02abc\x00",                       # stored, no dict reset as first chunk
+        b"\x80\x00\x00\x00\x04\x00\x00\x00\x00\x00\x00",  # LZMA chunk without props first
+        b"\xe0\x00\x00\x00\x04\xe1" + b"\0" * 5,      # bad props byte
+        b"\xe0\x00\x00\x00\x04\x5d\x01\0\0\0\0\x00",  # rc first byte != 0
+        b"\xe0\x00\x00\x00\x02\x5d\x00\0\0",          # rc init cut by the chunk limit
+        c[:-1],                                       # missing end byte -> ErrUnexpectedEOF
+        c[: len(c) // 2],                             # cut inside a chunk
+        c[: len(c) // 3] + c[len(c) // 3 + 5:],       # bytes dropped: headers no longer line up
+        c + b"trailing",                              # bytes after the end marker are ignored
+        c,                                            # out_cap too small (below)
+    ]
+    caps = [200_000] * len(blobs)
+    caps[-1] = 70_000
+    _check_lzma2(ctx, blobs, [1 << 16] * len(blobs), caps)
+
+
+def test_lzma2_corrupted_streams_match_oracle(ctx):
+    import random
+    rnd = random.Random(7)
+    blobs = []
+    for i in range(40):
+        segs = [corpus.plain("TMZR"[(i + k) % 4], 700 + 10 * i + k, 15_000) for k in range(4)]
+        c = bytearray(corpus.lzma2_concat(segs, dict_size=1 << 16))
+        for _ in range(rnd.randint(1, 3)):
+            k = rnd.randrange(0, len(c))
+            c[k] ^= 1 << rnd.randrange(8)
+        blobs.append(bytes(c))
+    _check_lzma2(ctx, blobs, [1 << 16] * len(blobs), [80_000] * len(blobs))
