@@ -96,6 +96,11 @@ int xlz_ctx_create(int device, xlz_ctx **ctx); /* XLZ_OK or XLZ_ERR_DEVICE      
 void xlz_ctx_destroy(xlz_ctx *ctx);
 int xlz_ctx_device(const xlz_ctx *ctx);
 
+/* HIP events on the context's stream, for callers that time a region of enqueued work
+ * (bench.py): slot 0..7.  elapsed_ms waits for event `b`.                           */
+int xlz_ctx_event_record(xlz_ctx *ctx, int slot);
+int xlz_ctx_event_elapsed_ms(xlz_ctx *ctx, int slot_a, int slot_b, float *ms);
+
 /* ---- one-shot batch decode: host buffers in, host buffers out -------------- */
 /* Replaces a loop of `r, _ := NewReader1(src); io.Copy(dst, r)` over n independent
  * streams (reader1_test.go:76-80).  One bad stream never fails the batch: the return

@@ -63,6 +63,18 @@ class Context:
         if st != OK:
             raise LzmaError(st, "xlz_ctx_create(device=%d)" % device)
 
+    def event_record(self, slot):
+        st = N.lib().xlz_ctx_event_record(self._h, slot)
+        if st != OK:
+            raise LzmaError(st, "xlz_ctx_event_record")
+
+    def event_elapsed_ms(self, a, b):
+        ms = ctypes.c_float()
+        st = N.lib().xlz_ctx_event_elapsed_ms(self._h, a, b, ctypes.byref(ms))
+        if st != OK:
+            raise LzmaError(st, "xlz_ctx_event_elapsed_ms")
+        return ms.value
+
     def close(self):
         if self._h:
             N.lib().xlz_ctx_destroy(self._h)

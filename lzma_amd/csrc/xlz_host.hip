@@ -51,6 +51,7 @@ struct xlz_ctx {
     int num_cus = 0;
     hipStream_t stream = nullptr;
     uint32_t *queue = nullptr; // work-queue head, re-zeroed on the stream before each launch
+    hipEvent_t ev[8] = {};
     std::mutex mu;
 };
 
@@ -184,11 +185,32 @@ extern "C" void xlz_ctx_destroy(xlz_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->queue) (void)hipFree(c->queue);
+    for (hipEvent_t e : c->ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 extern "C" int xlz_ctx_device(const xlz_ctx *c) { return c ? c->device : -1; }
+
+extern "C" int xlz_ctx_event_record(xlz_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot >= 8) return XLZ_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->ev[slot]) HIP_TRY(hipEventCreate(&c->ev[slot]));
+    HIP_TRY(hipEventRecord(c->ev[slot], c->stream));
+    return XLZ_OK;
+}
+
+extern "C" int xlz_ctx_event_elapsed_ms(xlz_ctx *c, int a, int b, float *ms)
+{
+    if (!c || !ms || a < 0 || a >= 8 || b < 0 || b >= 8 || !c->ev[a] || !c->ev[b]) return XLZ_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev[b]));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev[a], c->ev[b]));
+    return XLZ_OK;
+}
 
 // ------------------------------------------------------------------ batch ----
 namespace {

@@ -103,12 +103,14 @@ def decode_dict_size2(b):
     return lib().xlzo_decode_dict_size2(b)
 
 
-def decode_batch_mt(streams, out_caps, nthreads, fmt=0, dict_size=0):
-    """Decode a list of byte strings with nthreads host threads.
+def decode_batch_mt(streams, out_caps, nthreads, fmt=0, dict_size=0, timing=False):
+    """Decode a list of byte strings with nthreads host threads (one stream per thread).
 
-    Returns (list of output bytes, list of statuses).  Used by bench.py's
-    cpu_baseline leg (timed by the caller).
+    Returns (list of output bytes, list of statuses); with timing=True the outputs stay
+    ctypes buffers (no copies) and a third value is the wall time of the C call alone, which
+    is what bench.py's cpu_baseline leg reports.
     """
+    import time
     n = len(streams)
     jobs = (Job * n)()
     res = (Result * n)()
@@ -125,5 +127,10 @@ def decode_batch_mt(streams, out_caps, nthreads, fmt=0, dict_size=0):
         jobs[i].out_cap = cap
         jobs[i].fmt = fmt
         jobs[i].dict_size = dict_size
+    t0 = time.perf_counter()
     lib().xlzo_decode_batch_mt(jobs, n, nthreads, res)
-    return [outs[i].raw[: res[i].out_len] for i in range(n)], [res[i].status for i in range(n)]
+    dt = time.perf_counter() - t0
+    sts = [res[i].status for i in range(n)]
+    if timing:
+        return [(outs[i], res[i].out_len) for i in range(n)], sts, dt
+    return [outs[i].raw[: res[i].out_len] for i in range(n)], sts

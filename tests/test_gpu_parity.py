@@ -248,3 +248,78 @@ def test_lzma2_corrupted_streams_match_oracle(ctx):
             c[k] ^= 1 << rnd.randrange(8)
         blobs.append(bytes(c))
     _check_lzma2(ctx, blobs, [1 << 16] * len(blobs), [80_000] * len(blobs))
+
+
+# ------------------------------------------- pull-style readers (reader1.go / reader2.go) ----
+def test_reader1_read_semantics(ctx):
+    p = corpus.plain("T", 800, 100_000)
+    r, err = lzma_amd.NewReader1(ctx, corpus.compress_alone(p))
+    assert err is None
+    got = []
+    while True:                                   # io.Copy with a 32 KiB buffer (reader1_test.go:79)
+        b, e = r.Read(32768)
+        got.append(b)
+        if e is lzma_amd.io_EOF:
+            break
+        assert e is None
+    assert b"".join(got) == p
+    b, e = r.Read(10)
+    assert b == b"" and e is lzma_amd.io_EOF      # reader1.go:239-243
+
+
+def test_reader1_reference_assets(ctx, golden):
+    exp, data = golden
+    for name in ["a.lzma", "a_eos.lzma", "a_eos_and_size.lzma", "a_lp1_lc2_pb1.lzma"]:
+        r, err = lzma_amd.NewReader1(ctx, data[name])
+        assert err is None                        # checkErr1: NoError (reader1_test.go:26-49)
+        out, e = r.read_all()
+        assert e is None and len(out) == 327      # checkErr2: NoError
+    for name in ["bad_corrupted.lzma", "bad_eos_incorrect_size.lzma", "bad_incorrect_size.lzma"]:
+        r, err = lzma_amd.NewReader1(ctx, data[name])
+        assert err is None                        # constructor succeeds (reader1_test.go:50-67)
+        out, e = r.read_all()
+        assert isinstance(e, lzma_amd.LzmaError) and e.status == lzma_amd.ErrResultError
+
+
+def test_reader_constructor_errors(ctx):
+    for blob, status in [(b"", lzma_amd.ERR_HEADER_EOF), (bytes([225]) + b"\0" * 20, lzma_amd.ERR_PROPS),
+                         (bytes([0x5D, 0, 0]), lzma_amd.ERR_HEADER_EOF),
+                         (bytes([0x5D]) + struct.pack("<IQ", 65536, 10) + b"\x01\0\0\0\0", lzma_amd.ERR_RC_INIT)]:
+        r, err = lzma_amd.NewReader1(ctx, blob)
+        assert r is None and err.status == status
+    r, err = lzma_amd.NewReader2(ctx, b"", 0)
+    assert r is None and err.status == lzma_amd.ERR_UNEXPECTED_EOF     # reader2.go:104-110
+
+
+def test_reader2_and_sevenzip_constructors(ctx, golden):
+    exp, data = golden
+    r, err = lzma_amd.NewReader2(ctx, data["randomfile.dat.lzma2"], 0)   # reader2_test.go:19
+    assert err is None
+    out, e = r.read_all()
+    assert e is None and hashlib.md5(out).hexdigest() == RANDOM_MD5
+    p = corpus.plain("T", 801, 60_000)
+    props, ds, raw = corpus.compress_raw_lzma1(p, dict_size=1 << 20)
+    rc, err = lzma_amd.NewLZMADecompressorForSevenZip(ctx, bytes([props]) + struct.pack("<I", ds), len(p), [raw])
+    assert err is None
+    out, e = rc.read_all()
+    assert e is None and out == p
+    assert rc.Close() is None
+    assert rc.Close().status == lzma_amd.ERR_CLOSED                    # readcloser.go:17-19
+    assert rc.Read(4)[1].status == lzma_amd.ERR_CLOSED                 # readcloser.go:31-33
+    _, err = lzma_amd.NewLZMADecompressorForSevenZip(ctx, bytes([props]) + struct.pack("<I", ds), len(p), [raw, raw])
+    assert err.status == lzma_amd.ERR_NEED_ONE_READER                  # reader1.go:33-35
+    _, err = lzma_amd.NewLZMA2DecompressorForSevenZip(ctx, b"\x10\x00", 0, [raw])
+    assert err.status == lzma_amd.ERR_INSUFFICIENT_PROPS               # reader2.go:54-56
+    c2 = corpus.compress_raw_lzma2(p, dict_size=1 << 16)
+    rc, err = lzma_amd.NewLZMA2DecompressorForSevenZip(ctx, bytes([10]), 0, [c2])  # dict byte 10 -> 128 KiB
+    assert err is None
+    out, e = rc.read_all()
+    assert e is None and out == p
+
+
+def test_multi_device_driver_on_gpu(ctx):
+    from lzma_amd import multigpu
+    ps = [corpus.plain("TRMZ"[i % 4], 900 + i, 30_000) for i in range(12)]
+    streams = [Stream(corpus.compress_alone(p), out_cap=len(p)) for p in ps]
+    res = multigpu.decode_batch_multi(streams, [0, 0])   # two host threads, two contexts, one GPU
+    assert [r[0] for r in res] == ps and all(r[1] == 0 for r in res)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# rocprofv3 passes over the default bench command (run on the GPU box via gpurun).
+#   tools/profile_bench.sh <tag> [extra bench args]
+# 1) --kernel-trace --stats  2) --pmc FETCH_SIZE  3) --pmc WRITE_SIZE  4) SQ instruction mix
+# Counter passes are separate runs and never combined with tracing (pool rule).
+TAG=${1:-r01}; shift
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --verify sample $@"
+echo "bench args: $ARGS" > $O/command.txt
+rocprofv3 --kernel-trace --stats -d $O/kt --output-format csv -- python3 $R/bench.py $ARGS > $O/kt.json 2> $O/kt.err || exit 1
+rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py $ARGS > $O/fetch.json 2> $O/fetch.err || exit 1
+rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py $ARGS > $O/write.json 2> $O/write.err || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/sq --output-format csv -- python3 $R/bench.py $ARGS > $O/sq.json 2> $O/sq.err || exit 1
+python3 $R/tools/summarize_prof.py $O > $O/summary.md
+cat $O/summary.md
