@@ -462,359 +462,35 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
 #undef LEN_DECODE
 
 // ================================================================================
-//  FAST path: hand-scheduled.  Same arithmetic, same order of model updates; the
-//  end-of-input / capacity / truncation tests are hoisted into lzma_run.
+//  FAST path: the whole packet loop as ONE hand-scheduled asm statement, generated by
+//  tools/gen_fastpath.py into xlz_fastpath.inc (register conventions and exit codes are
+//  documented there).  Same arithmetic and the same order of model updates as the checked
+//  path; the end-of-input / capacity / truncation tests are hoisted into lzma_run, which
+//  passes them in as two limits (arel_lim, pos_lim).
 // ================================================================================
-// Register roles inside the asm blocks
-//   range, code          SGPR   range coder
-//   p                    SGPR   probability of the node being decoded
-//   bit, t0, t1          SGPR   decision and temporaries
-//   cur, arel            SGPR   input window cursor (see IN_BYTE)
-//   vin                  VGPR   the 256-byte input window
-//
-// The decision core: the borrow of `code - bound` IS the decision (SCC), four
-// s_cselect pick range / code / the update constant / the bit.  The new probability
-// p - ((p - k) >>a 5) is formed on the VALU because it is only ever stored to LDS.
-#define XLZ_CORE                                                                                  \
-    "s_lshr_b32 %[t0], %[range], 11\n\t"                                                          \
-    "s_mul_i32 %[t0], %[t0], %[p]\n\t"                                                            \
-    "s_sub_u32 %[t1], %[range], %[t0]\n\t"                                                        \
-    "s_sub_u32 %[bit], %[code], %[t0]\n\t"                                                        \
-    "s_cselect_b32 %[range], %[t0], %[t1]\n\t"                                                    \
-    "s_cselect_b32 %[code], %[code], %[bit]\n\t"                                                  \
-    "s_cselect_b32 %[t1], 0x7e1, 0\n\t"                                                           \
-    "s_cselect_b32 %[bit], 0, 1\n\t"                                                              \
-    "s_sub_u32 %[t1], %[p], %[t1]\n\t"                                                            \
-    "v_ashrrev_i32 v63, 5, %[t1]\n\t"                                                           \
-    "v_sub_u32 v63, %[p], v63\n\t"
+static_assert(P_IS_MATCH == 0 && P_IS_REP == 192 && P_IS_REP_G0 == 204 && P_IS_REP_G1 == 216 && P_IS_REP_G2 == 228 &&
+                  P_IS_REP0_LONG == 240 && P_POS_SLOT == 432 && P_POS_DEC == 688 && P_ALIGN == 804 && P_LEN == 820 &&
+                  P_REP_LEN == 1336 && P_LIT == 1852 && LEN_LOW == 4 && LEN_MID == 132 && LEN_HIGH == 260,
+              "tools/gen_fastpath.py hard-codes the probability layout");
 
-// normalisation test: falls through when range >= 2^24 (the common case)
-#define XLZ_NCHK(K)                                                                               \
-    "s_lshr_b32 %[t0], %[range], 24\n\t"                                                          \
-    "s_cbranch_scc0 .Ln" K "_%=\n"                                                                \
-    ".Lb" K "_%=:\n\t"
+enum : uint32_t { FX_LIMIT = 0, FX_ERR = 1, FX_MARKER = 2, FX_COPY = 3 };
 
-// out-of-line normalisation (decompress.go:33-42): shift in one byte of the window
-#define XLZ_NSTUB(K)                                                                              \
-    ".Ln" K "_%=:\n\t"                                                                            \
-    "s_lshl_b32 %[range], %[range], 8\n\t"                                                        \
-    "s_lshl_b32 %[code], %[code], 8\n\t"                                                          \
-    "s_and_b32 %[t0], %[cur], 0xff\n\t"                                                           \
-    "s_or_b32 %[code], %[code], %[t0]\n\t"                                                        \
-    "s_lshr_b32 %[cur], %[cur], 8\n\t"                                                            \
-    "s_add_u32 %[arel], %[arel], 1\n\t"                                                           \
-    "s_and_b32 %[t0], %[arel], 3\n\t"                                                             \
-    "s_cbranch_scc1 .Lb" K "_%=\n\t"                                                              \
-    "s_lshr_b32 %[t0], %[arel], 2\n\t"                                                            \
-    "v_readlane_b32 %[cur], %[vin], %[t0]\n\t"                                                    \
-    "s_branch .Lb" K "_%=\n"
-
-// The asm blocks have NO VGPR outputs: hipcc merges the result structs of identical asm
-// blocks through PHIs, and a struct with a VGPR member makes every member (range, code ...)
-// "divergent" for it.  Temporaries are the fixed registers v60..v63, declared as clobbers.
-#define XLZ_VTMP "v60", "v61", "v62", "v63"
-
-// normalisation at the end of a block: one taken branch skips it in the common case
-#define XLZ_NORM_INLINE                                                                           \
-    "s_lshr_b32 %[t0], %[range], 24\n\t"                                                          \
-    "s_cbranch_scc1 .Le_%=\n\t"                                                                   \
-    "s_lshl_b32 %[range], %[range], 8\n\t"                                                        \
-    "s_lshl_b32 %[code], %[code], 8\n\t"                                                          \
-    "s_and_b32 %[t0], %[cur], 0xff\n\t"                                                           \
-    "s_or_b32 %[code], %[code], %[t0]\n\t"                                                        \
-    "s_lshr_b32 %[cur], %[cur], 8\n\t"                                                            \
-    "s_add_u32 %[arel], %[arel], 1\n\t"                                                           \
-    "s_and_b32 %[t0], %[arel], 3\n\t"                                                             \
-    "s_cbranch_scc1 .Le_%=\n\t"                                                                   \
-    "s_lshr_b32 %[t0], %[arel], 2\n\t"                                                            \
-    "v_readlane_b32 %[cur], %[vin], %[t0]\n"                                                       \
-    ".Le_%=:"
-
-#define XLZ_RC_OPERANDS                                                                           \
-    [range] "+s"(d.range), [code] "+s"(d.code), [cur] "+s"(d.cur), [arel] "+s"(d.arel)
-
-// LDS byte address of probs[0] (0 unless the compiler places something in front of it)
-#define XLZ_LDS0 ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)probs)
-
-// One decision on probs[idx] (no look-ahead: the probability is fetched here).
-__device__ __forceinline__ uint32_t fbit(Dec &d, const uint16_t *probs, uint32_t idx)
+__device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint32_t lane, uint32_t arel_lim,
+                                                   uint32_t pos_lim, uint32_t &lenout)
 {
-    uint32_t bit, t0, t1, p;
-    const uint32_t va = XLZ_LDS0 + (idx << 1);
-    asm volatile("ds_read_u16 v62, %[va]\n\t"
-                 "s_waitcnt lgkmcnt(0)\n\t"
-                 "v_readfirstlane_b32 %[p], v62\n\t" XLZ_CORE "ds_write_b16 %[va], v63\n\t" XLZ_NORM_INLINE
-                 : XLZ_RC_OPERANDS, [bit] "=&s"(bit), [t0] "=&s"(t0), [t1] "=&s"(t1), [p] "=&s"(p)
-                 : [va] "v"(va), [vin] "v"(d.vin)
-                 : "scc", "memory", XLZ_VTMP);
-    return bit;
-}
-
-// fbit without the trailing normalisation (the reference rotates reps in between,
-// decompress.go:785-798)
-__device__ __forceinline__ uint32_t fbit_nn(Dec &d, const uint16_t *probs, uint32_t idx)
-{
-    uint32_t bit, t0, t1, p;
-    const uint32_t va = XLZ_LDS0 + (idx << 1);
-    asm volatile("ds_read_u16 v62, %[va]\n\t"
-                 "s_waitcnt lgkmcnt(0)\n\t"
-                 "v_readfirstlane_b32 %[p], v62\n\t" XLZ_CORE "ds_write_b16 %[va], v63"
-                 : [range] "+s"(d.range), [code] "+s"(d.code), [bit] "=&s"(bit), [t0] "=&s"(t0), [t1] "=&s"(t1),
-                   [p] "=&s"(p)
-                 : [va] "v"(va)
-                 : "scc", "memory", XLZ_VTMP);
-    return bit;
-}
-
-__device__ __forceinline__ void fnorm(Dec &d)
-{
-    uint32_t t0;
-    asm volatile(XLZ_NORM_INLINE
-                 : XLZ_RC_OPERANDS, [t0] "=&s"(t0)
-                 : [vin] "v"(d.vin)
-                 : "scc");
-}
-
-// One level of a bit tree with look-ahead.  On entry p = probs[base + m].  While the
-// decision on node m is computed, lanes 0 and 1 fetch the two children 2m and 2m+1
-// (vbl = byte address of the tree base + 2*lane); once the bit is known v_readlane picks
-// the child's probability -- the LDS round trip is off the critical path.
-#define XLZ_LEVEL(K)                                                                              \
-    "v_lshl_add_u32 v61, %[m], 2, %[vbl]\n\t"                                                     \
-    "ds_read_u16 v62, v61\n\t" XLZ_CORE "v_lshl_add_u32 v60, %[m], 1, %[vbu]\n\t"                 \
-    "ds_write_b16 v60, v63\n\t"                                                                   \
-    "s_lshl1_add_u32 %[m], %[m], %[bit]\n\t" XLZ_NCHK(K) "s_waitcnt lgkmcnt(0)\n\t"               \
-    "v_readlane_b32 %[p], v62, %[bit]\n\t"
-
-#define XLZ_LEVEL_LAST(K)                                                                         \
-    XLZ_CORE "v_lshl_add_u32 v60, %[m], 1, %[vbu]\n\t"                                            \
-    "ds_write_b16 v60, v63\n\t"                                                                   \
-    "s_lshl1_add_u32 %[m], %[m], %[bit]\n\t" XLZ_NCHK(K)
-
-#define XLZ_TREE_OPERANDS                                                                         \
-    XLZ_RC_OPERANDS, [m] "+s"(m), [p] "+s"(p), [bit] "=&s"(bit), [t0] "=&s"(t0), [t1] "=&s"(t1)
-
-#define XLZ_TREE_PROLOGUE                                                                         \
-    uint32_t m = 1, bit, t0, t1;                                                                  \
-    const uint32_t vbu = XLZ_LDS0 + (base << 1); /* byte address of the tree base (uniform) */   \
-    const uint32_t vbl = vbu + (lane << 1); /* ... + 2*lane: lane j addresses child j */          \
-    uint32_t p = RFL(probs[base + 1]);
-
-// forward bit trees (bit_tree_decoder.go:18-40), fully unrolled.  Returns m with its
-// leading 1 (m - (1 << NB) is the symbol).
-__device__ __forceinline__ uint32_t ftree3(Dec &d, const uint16_t *probs, uint32_t base, uint32_t lane)
-{
-    XLZ_TREE_PROLOGUE
-    asm volatile(XLZ_LEVEL("0") XLZ_LEVEL("1") XLZ_LEVEL_LAST("2") "s_branch .Le_%=\n" XLZ_NSTUB("0") XLZ_NSTUB("1")
-                     XLZ_NSTUB("2") ".Le_%=:"
-                 : XLZ_TREE_OPERANDS
-                 : [vbl] "v"(vbl), [vbu] "v"(vbu), [vin] "v"(d.vin)
-                 : "scc", "memory", XLZ_VTMP);
-    return m;
-}
-
-__device__ __forceinline__ uint32_t ftree4(Dec &d, const uint16_t *probs, uint32_t base, uint32_t lane)
-{
-    XLZ_TREE_PROLOGUE
-    asm volatile(XLZ_LEVEL("0") XLZ_LEVEL("1") XLZ_LEVEL("2") XLZ_LEVEL_LAST("3") "s_branch .Le_%=\n" XLZ_NSTUB("0")
-                     XLZ_NSTUB("1") XLZ_NSTUB("2") XLZ_NSTUB("3") ".Le_%=:"
-                 : XLZ_TREE_OPERANDS
-                 : [vbl] "v"(vbl), [vbu] "v"(vbu), [vin] "v"(d.vin)
-                 : "scc", "memory", XLZ_VTMP);
-    return m;
-}
-
-__device__ __forceinline__ uint32_t ftree6(Dec &d, const uint16_t *probs, uint32_t base, uint32_t lane)
-{
-    XLZ_TREE_PROLOGUE
-    asm volatile(XLZ_LEVEL("0") XLZ_LEVEL("1") XLZ_LEVEL("2") XLZ_LEVEL("3") XLZ_LEVEL("4") XLZ_LEVEL_LAST("5")
-                 "s_branch .Le_%=\n" XLZ_NSTUB("0") XLZ_NSTUB("1") XLZ_NSTUB("2") XLZ_NSTUB("3") XLZ_NSTUB("4")
-                     XLZ_NSTUB("5") ".Le_%=:"
-                 : XLZ_TREE_OPERANDS
-                 : [vbl] "v"(vbl), [vbu] "v"(vbu), [vin] "v"(d.vin)
-                 : "scc", "memory", XLZ_VTMP);
-    return m;
-}
-
-__device__ __forceinline__ uint32_t ftree8(Dec &d, const uint16_t *probs, uint32_t base, uint32_t lane)
-{
-    XLZ_TREE_PROLOGUE
-    asm volatile(XLZ_LEVEL("0") XLZ_LEVEL("1") XLZ_LEVEL("2") XLZ_LEVEL("3") XLZ_LEVEL("4") XLZ_LEVEL("5")
-                     XLZ_LEVEL("6") XLZ_LEVEL_LAST("7") "s_branch .Le_%=\n" XLZ_NSTUB("0") XLZ_NSTUB("1") XLZ_NSTUB("2")
-                         XLZ_NSTUB("3") XLZ_NSTUB("4") XLZ_NSTUB("5") XLZ_NSTUB("6") XLZ_NSTUB("7") ".Le_%=:"
-                 : XLZ_TREE_OPERANDS
-                 : [vbl] "v"(vbl), [vbu] "v"(vbu), [vin] "v"(d.vin)
-                 : "scc", "memory", XLZ_VTMP);
-    return m;
-}
-
-// the rest of a literal's plain tree from node m (< 0x100) on, as a loop with look-ahead
-// (used after a matched literal left the match path, decompress.go:127-166)
-__device__ __forceinline__ uint32_t ftree_rest(Dec &d, const uint16_t *probs, uint32_t base, uint32_t m,
-                                               uint32_t lane)
-{
-    uint32_t bit, t0, t1;
-    const uint32_t vbu = XLZ_LDS0 + (base << 1);
-    const uint32_t vbl = vbu + (lane << 1);
-    uint32_t p = RFL(probs[base + m]);
-    asm volatile(".Lt_%=:\n\t" XLZ_LEVEL("0") "s_cmpk_lt_u32 %[m], 0x100\n\t"
-                 "s_cbranch_scc1 .Lt_%=\n\t"
-                 "s_branch .Le_%=\n" XLZ_NSTUB("0") ".Le_%=:"
-                 : XLZ_TREE_OPERANDS
-                 : [vbl] "v"(vbl), [vbu] "v"(vbu), [vin] "v"(d.vin)
-                 : "scc", "memory", XLZ_VTMP);
-    return m;
-}
-
-// lenDecoder.Decode (len_decoder.go:34-60); returns the raw length (0..271)
-__device__ __forceinline__ uint32_t flen(Dec &d, const uint16_t *probs, uint32_t lbase, uint32_t pos_state,
-                                         uint32_t lane)
-{
-    if (fbit(d, probs, lbase + LEN_CHOICE) == 0) return ftree3(d, probs, lbase + LEN_LOW + (pos_state << 3), lane) - 8;
-    if (fbit(d, probs, lbase + LEN_CHOICE2) == 0) return ftree3(d, probs, lbase + LEN_MID + (pos_state << 3), lane);
-    return 16 + ftree8(d, probs, lbase + LEN_HIGH, lane) - 256;
-}
-
-// ONE packet, hot path.  lzma_run guarantees: >= kFastInput readable input bytes inside the
-// window, >= kFastOutput bytes of output room, and (defined size) >= kFastOutput bytesLeft.
-__device__ __forceinline__ int lzma_packet_fast(Dec &d, uint16_t *probs, uint8_t *__restrict__ out, uint32_t lane)
-{
-    uint32_t length;
-    const uint32_t pos_state = d.wpos & d.pos_mask;              // :22
-    const uint32_t state2 = (d.state << kPosBitsMax) + pos_state; // :23
-
-    if (fbit(d, probs, P_IS_MATCH + state2) == 0) {
-        // ---- literal, decompress.go:44-175 ----
-        const uint32_t lit_state = ((d.wpos & d.lp_mask) << d.lc) + (d.prev_byte >> (8 - d.lc)); // :56
-        const uint32_t lbase = P_LIT + kLitCoderSize * lit_state;                              // :57
-        uint32_t symbol;
-        if (d.state >= 7) { // matched literal :59-114
-            uint32_t mb = d.match_byte, bit;
-            symbol = 1;
-            do {
-                const uint32_t match_bit = (mb >> 7) & 1;
-                mb <<= 1;
-                bit = fbit(d, probs, lbase + ((1 + match_bit) << 8) + symbol);
-                symbol = (symbol << 1) | bit;
-                if (match_bit != bit) break;
-            } while (symbol < 0x100);
-            if (symbol < 0x100) symbol = ftree_rest(d, probs, lbase, symbol, lane);
-        } else {
-            symbol = ftree8(d, probs, lbase, lane); // :127-166
-        }
-        symbol &= 0xFF;
-        out[d.pos] = (uint8_t)symbol; // window.PutByte :168 (all lanes, same byte, same address)
-        d.pos++;
-        if (++d.wpos >= d.dict_size) d.wpos -= d.dict_size; // window.go:38-41
-        d.prev_byte = symbol;
-        d.state = upd_literal(d.state); // :171
-        d.bytes_left--;                 // :172
-        return RUN_CONTINUE;
-    }
-
-    if (fbit(d, probs, P_IS_REP + d.state) == 0) {
-        // ---- simple match, :215-668 ----
-        d.rep3 = d.rep2;
-        d.rep2 = d.rep1;
-        d.rep1 = d.rep0; // :216
-        length = flen(d, probs, P_LEN, pos_state, lane);
-        d.state = d.state < 7 ? 7 : 10; // stateUpdateMatch :431
-        const uint32_t len_state = length > 3 ? 3 : length;
-        const uint32_t pos_slot = ftree6(d, probs, P_POS_SLOT + (len_state << 6), lane) - 64; // :441-486
-        if (pos_slot < 4) {
-            d.rep0 = pos_slot; // :488-489
-        } else {
-            const uint32_t nbits = (pos_slot >> 1) - 1;
-            uint32_t dist = (2 | (pos_slot & 1)) << nbits; // :491-492
-            if (pos_slot < kEndPosModelIndex) {
-                // reverse bit tree over posDecoders :495-546
-                const uint32_t base = P_POS_DEC + dist - pos_slot;
-                uint32_t m = 1, sym = 0;
-                _Pragma("unroll 1") for (uint32_t k = 0; k < nbits; k++)
-                {
-                    const uint32_t b = fbit(d, probs, base + m);
-                    m = (m << 1) | b;
-                    sym |= b << k;
-                }
-                d.rep0 = dist + sym;
-            } else {
-                uint32_t res = 0; // DecodeDirectBits :549-577
-                _Pragma("unroll 1") for (uint32_t n = nbits - kNumAlignBits; n > 0; n--)
-                {
-                    d.range >>= 1;
-                    d.code -= d.range;
-                    const uint32_t t = 0u - (d.code >> 31);
-                    d.code += d.range & t;
-                    res = (res << 1) + (t + 1);
-                    fnorm(d);
-                }
-                dist += res << kNumAlignBits;
-                // reverse bit tree over alignDecoderProbs :579-625: m = 1 b0 b1 b2 b3
-                const uint32_t m = ftree4(d, probs, P_ALIGN, lane);
-                d.rep0 = dist + (__builtin_bitreverse32(m) >> 28); // :627-628
-            }
-        }
-        if (d.rep0 == 0xFFFFFFFFu) { // end marker :633-645
-            if (d.code == 0) {
-                if (d.size_defined && d.bytes_left > 0) return RUN_ERR_RESULT;
-                return RUN_END;
-            }
-            return RUN_ERR_RESULT;
-        }
-        if (bad_distance(d)) return RUN_ERR_RESULT; // :651-653
-        length += kMatchMinLen;                     // :656
-    } else {
-        // ---- rep match, :685-1123 ----
-        if (d.pos == d.wbase) return RUN_ERR_RESULT; // window.IsEmpty :690-692
-        if (fbit(d, probs, P_IS_REP_G0 + d.state) == 0) {   // :694-772
-            if (fbit(d, probs, P_IS_REP0_LONG + state2) == 0) { // short rep :715-739
-                d.state = d.state < 7 ? 9 : 11;
-                uint32_t dist = d.rep0 + 1;
-                if (dist == 0) dist = d.dict_size;
-                wave_copy<false>(out, d, dist, 1, lane);
-                d.pos++;
-                if (++d.wpos >= d.dict_size) d.wpos -= d.dict_size;
-                d.bytes_left--;
-                return RUN_CONTINUE;
-            }
-        } else {
-            uint32_t dist;
-            if (fbit_nn(d, probs, P_IS_REP_G1 + d.state) == 0) { // :777-813
-                dist = d.rep1;
-                d.rep1 = d.rep0;
-                d.rep0 = dist; // rotated before the normalise (:785-798)
-                fnorm(d);
-            } else {
-                fnorm(d);
-                if (fbit_nn(d, probs, P_IS_REP_G2 + d.state) == 0) { // :816-861
-                    dist = d.rep2;
-                    d.rep2 = d.rep1;
-                } else {
-                    dist = d.rep3;
-                    d.rep3 = d.rep2;
-                    d.rep2 = d.rep1;
-                }
-                d.rep1 = d.rep0;
-                d.rep0 = dist;
-                fnorm(d);
-            }
-        }
-        length = flen(d, probs, P_REP_LEN, pos_state, lane);
-        d.state = d.state < 7 ? 8 : 11; // stateUpdateRep :933,1027,1103
-        length += kMatchMinLen;
-    }
-
-    // window.CopyMatch, :664-667 etc. (no truncation / overflow possible here)
-    {
-        uint32_t dist = d.rep0 + 1;
-        if (dist == 0) dist = d.dict_size;
-        wave_copy<false>(out, d, dist, length, lane);
-        d.pos += length;
-        d.wpos += length;
-        if (d.wpos >= d.dict_size) d.wpos -= d.dict_size; // window.go:67-71
-        d.bytes_left -= length;
-    }
-    return RUN_CONTINUE;
+    uint32_t exitc;
+    asm volatile(
+#include "xlz_fastpath.inc"
+        : [range] "+s"(d.range), [code] "+s"(d.code), [cur] "+s"(d.cur), [arel] "+s"(d.arel), [state] "+s"(d.state),
+          [rep0] "+s"(d.rep0), [rep1] "+s"(d.rep1), [rep2] "+s"(d.rep2), [rep3] "+s"(d.rep3), [pos] "+s"(d.pos),
+          [wpos] "+s"(d.wpos), [prev] "+s"(d.prev_byte), [mb] "+s"(d.match_byte), [exitc] "=&s"(exitc),
+          [lenout] "=&s"(lenout)
+        : [arel_lim] "s"(arel_lim), [pos_lim] "s"(pos_lim), [dict] "s"(d.dict_size), [pos_mask] "s"(d.pos_mask),
+          [lp_mask] "s"(d.lp_mask), [lc] "s"(d.lc), [wbase] "s"(d.wbase), [outp] "s"(out), [vin] "v"(d.vin),
+          [vlane] "v"(lane)
+        : "scc", "memory", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
+          "s93", "s94", "s95", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+    return exitc;
 }
 
 // (*Reader1).decompress run to the end of the current LZMA chunk (decompress.go:8-1136)
@@ -825,14 +501,36 @@ __device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint8_t *__rest
         if (d.size_defined && d.bytes_left == 0 && d.code == 0) return RUN_END;
         // keep kFastInput bytes of window ahead of the packet
         if (d.arel > kInWindow - kFastInput) in_window(d, in_pos(d), lane);
-        const bool fast = (d.aend - in_pos(d)) >= kFastInput && (d.out_cap - d.pos) >= kFastOutput &&
+        const uint32_t in_left = d.aend - in_pos(d);
+        const bool fast = in_left >= kFastInput && (d.out_cap - d.pos) >= kFastOutput &&
                           (!d.size_defined || d.bytes_left >= kFastOutput);
-        int r;
-        if (fast)
-            r = lzma_packet_fast(d, probs, out, lane);
-        else
-            r = lzma_packet_checked(d, probs, out, lane);
-        if (r != RUN_CONTINUE) return r;
+        if (!fast) {
+            const int r = lzma_packet_checked(d, probs, out, lane);
+            if (r != RUN_CONTINUE) return r;
+            continue;
+        }
+        // a packet may START while arel <= arel_lim and pos < pos_lim
+        const uint32_t arel_lim = min(kInWindow - kFastInput, d.arel + (in_left - kFastInput));
+        uint32_t room = d.out_cap - d.pos - kFastOutput;
+        if (d.size_defined) room = min(room, d.bytes_left - kFastOutput);
+        const uint32_t pos0 = d.pos;
+        uint32_t len = 0;
+        const uint32_t ec = lzma_fast_loop(d, out, lane, arel_lim, pos0 + room + 1, len);
+        d.bytes_left -= d.pos - pos0; // :172,660,665 ... (wraps harmlessly when the size is undefined)
+        if (ec == FX_ERR) return RUN_ERR_RESULT; // :651-653, :690-692
+        if (ec == FX_MARKER) {                    // end marker :633-645 (bytesLeft > 0 here if defined)
+            if (d.code == 0 && !d.size_defined) return RUN_END;
+            return RUN_ERR_RESULT;
+        }
+        if (ec == FX_COPY) { // the packet is decoded, its window.CopyMatch is still to do
+            uint32_t dist = d.rep0 + 1;
+            if (dist == 0) dist = d.dict_size;
+            wave_copy<false>(out, d, dist, len, lane);
+            d.pos += len;
+            d.wpos += len;
+            if (d.wpos >= d.dict_size) d.wpos -= d.dict_size; // window.go:67-71
+            d.bytes_left -= len;
+        }
     }
 }
 
