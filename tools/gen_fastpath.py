@@ -22,6 +22,7 @@ Register conventions (fixed temporaries, declared as clobbers):
   s80,s81 core temps   s82 address temp   s83,s84 temps   s86 P (probability)   s87 BIT
   s88 M (tree index / symbol)   s89 LEN   s90 posState   s91 state2   s92 tree base (bytes)
   s93 dist   s94,s95 loop temps
+  v50..v53 tree blocks   v54 probabilities met on a walk   v55 temp   s85 2M+1
   v56 2*lane   v57 fbit address   v58 tree base (uniform)   v59 tree base + 2*lane
   v60 write-back address / copy dst   v61 children address / copy src   v62 loaded   v63 new prob
 """
@@ -108,19 +109,72 @@ def fbit_const(prob_index):
     fbit("s82")
 
 
-def tree_setup():
-    """tree base (LDS byte address) in s92 -> v58/v59, root prob -> s86, M = 1"""
+def walk_core():
+    """decision core without bit / probability update: SCC = (code < bound) on exit of the
+    two subtractions, range and code selected; the tree index is advanced by the caller"""
     emit("""
-    v_mov_b32 v58, s92
-    v_add_u32 v59, s92, v56
-    ds_read_u16 v62, v58 offset:2
-    s_mov_b32 s88, 1
-    s_waitcnt lgkmcnt(0)
-    v_readfirstlane_b32 s86, v62
+    s_lshr_b32 s80, %[range], 11
+    s_mul_i32 s80, s80, s86
+    s_sub_u32 s81, %[range], s80
+    s_sub_u32 s87, %[code], s80
+    s_cselect_b32 %[range], s80, s81
+    s_cselect_b32 %[code], %[code], s87
     """)
 
 
+def tree_update(nb):
+    """Apply the model updates of a finished tree walk in ONE vector operation.
+    s88 = final index (leading 1 + nb decided bits), v54 lane k = probability seen at level k,
+    v58 = tree base address.  nb: int, or the name of an SGPR holding the level count.
+    Lane k: node = s88 >> (nb-k), bit = (s88 >> (nb-k-1)) & 1,
+            new = p - ((p - (bit ? 0 : 2017)) >>a 5)   (decompress.go:30 / :177)."""
+    emit("""
+    v_sub_u32 v55, %s, %%[vlane]
+    v_lshrrev_b32 v60, v55, s88
+    v_add_u32 v61, -1, v55
+    v_lshrrev_b32 v61, v61, s88
+    v_and_b32 v61, 1, v61
+    v_lshl_add_u32 v60, v60, 1, v58
+    v_mul_u32_u24 v61, 0x7e1, v61
+    v_sub_u32 v61, 0x7e1, v61
+    v_sub_u32 v61, v54, v61
+    v_ashrrev_i32 v61, 5, v61
+    v_sub_u32 v61, v54, v61
+    """ % nb)
+    if isinstance(nb, int):
+        emit("s_mov_b64 exec, %d" % ((1 << nb) - 1))
+    else:
+        emit("s_bfm_b64 exec, %s, 0" % nb)
+    emit("ds_write_b16 v60, v61\ns_mov_b64 exec, -1")
+
+
+def tree(nbits):
+    """Bit tree of nbits levels rooted at LDS byte address s92 (bit_tree_decoder.go:18-40).
+    One LDS read fetches a whole 64-prob block of the tree (lane j = node 64b + j); a level is
+    then nine scalar instructions plus `v_readlane p, block, M` -- the lane select IS the node
+    index, so neither the decoded bit nor an address is ever materialised.  The probabilities
+    met on the way are parked in v54 (v_writelane) and updated together by tree_update."""
+    emit("v_add_u32 v59, s92, v56\nds_read_u16 v50, v59")
+    if nbits == 8:
+        emit("ds_read_u16 v51, v59 offset:128\nds_read_u16 v52, v59 offset:256\nds_read_u16 v53, v59 offset:384")
+    emit("v_mov_b32 v58, s92\ns_mov_b32 s88, 1\ns_waitcnt lgkmcnt(0)\nv_readlane_b32 s86, v50, 1")
+    for k in range(nbits):
+        emit("v_writelane_b32 v54, s86, %d\ns_lshl1_add_u32 s85, s88, 1" % k)
+        walk_core()
+        emit("s_subb_u32 s88, s85, 0")  # M = 2M + 1 - SCC = 2M + bit
+        nchk()
+        if k + 1 < nbits:
+            if k + 1 <= 5:
+                emit("v_readlane_b32 s86, v50, s88")
+            elif k + 1 == 6:
+                emit("v_readlane_b32 s86, v51, s88")
+            else:  # node 128..255: block 2 or 3 by bit 6 of M
+                emit("v_readlane_b32 s86, v52, s88\nv_readlane_b32 s84, v53, s88\ns_bitcmp1_b32 s88, 6\ns_cselect_b32 s86, s84, s86")
+    tree_update(nbits)
+
+
 def level(last=False):
+    """one level with child look-ahead and immediate update (used by the matched-literal tail)"""
     if not last:
         emit("v_lshl_add_u32 v61, s88, 2, v59\nds_read_u16 v62, v61")
     core()
@@ -128,12 +182,6 @@ def level(last=False):
     nchk()
     if not last:
         emit("s_waitcnt lgkmcnt(0)\nv_readlane_b32 s86, v62, s87")
-
-
-def tree(nbits):
-    tree_setup()
-    for k in range(nbits):
-        level(last=(k == nbits - 1))
 
 
 def len_decode(tag, base):
@@ -282,22 +330,27 @@ def gen():
     s_sub_u32 s84, s93, s88
     s_add_u32 s84, s84, %d
     s_lshl_b32 s92, s84, 1
-    s_mov_b32 s94, 1
-    s_mov_b32 s95, 0
     """ % (L("direct"), P_POS_DEC))
-    label("rt")  # reverse bit tree over posDecoders (:495-546)
-    emit("s_lshl_b32 s82, s94, 1\ns_add_u32 s82, s82, s92")
-    fbit("s82")
+    # reverse bit tree over posDecoders (:495-546): s83 levels (1..5) from base s92; block walk,
+    # unrolled with an early exit (v_writelane cannot take two different SGPRs)
+    emit("v_add_u32 v59, s92, v56\nds_read_u16 v50, v59\nv_mov_b32 v58, s92\ns_mov_b32 s88, 1\ns_waitcnt lgkmcnt(0)\nv_readlane_b32 s86, v50, 1")
+    for k in range(5):
+        emit("v_writelane_b32 v54, s86, %d\ns_lshl1_add_u32 s85, s88, 1" % k)
+        walk_core()
+        emit("s_subb_u32 s88, s85, 0")
+        nchk()
+        if k < 4:
+            emit("s_cmp_eq_u32 s83, %d\ns_cbranch_scc1 %s\nv_readlane_b32 s86, v50, s88" % (k + 1, L("rtdone")))
+    label("rtdone")
+    tree_update("s83")
+    # symbol = the s83 decided bits of M in reverse order (bit_tree_decoder.go:42-70)
     emit("""
-    s_lshl1_add_u32 s94, s94, s87
-    s_lshl_b32 s80, s87, s95
-    s_add_u32 s93, s93, s80
-    s_add_u32 s95, s95, 1
-    s_cmp_lt_u32 s95, s83
-    s_cbranch_scc1 %s
-    s_mov_b32 %%[rep0], s93
+    s_brev_b32 s80, s88
+    s_sub_u32 s81, 32, s83
+    s_lshr_b32 s80, s80, s81
+    s_add_u32 %%[rep0], s93, s80
     s_branch %s
-    """ % (L("rt"), L("distdone")))
+    """ % L("distdone"))
     label("direct")  # DecodeDirectBits (:549-577)
     emit("s_sub_u32 s83, s83, 4\ns_mov_b32 s84, 0")
     label("db")
