@@ -21,7 +21,7 @@ because no input exhaustion is possible inside the loop.
 Register conventions (fixed temporaries, declared as clobbers):
   s80,s81 core temps   s82 address temp   s83,s84 temps   s86 P (probability)   s87 BIT
   s88 M (tree index / symbol)   s89 LEN   s90 posState   s91 state2   s92 tree base (bytes)
-  s93 dist   s94,s95 loop temps
+  s93 dist   s94 copy pending   s95 its length   v48 its destination   v49 its bytes
   v50..v53 tree blocks   v54 probabilities met on a walk   v55 temp   s85 2M+1
   v56 2*lane   v57 fbit address   v58 tree base (uniform)   v59 tree base + 2*lane
   v60 write-back address / copy dst   v61 children address / copy src   v62 loaded   v63 new prob
@@ -204,6 +204,34 @@ def len_decode(tag, base):
     label(tag + "end")
 
 
+finish_sites = []
+
+
+def need_copy_done():
+    """The previous match copy's load is left in flight while the next packet decodes; whoever
+    needs its bytes (prevByte / matchByte for a literal, the next copy, any exit) comes here
+    first.  s94 = copy pending, v48 = its destination offsets, v49 = loaded bytes, s95 = len."""
+    uid[0] += 1
+    k = "f%d" % uid[0]
+    emit("s_cmp_eq_u32 s94, 0\ns_cbranch_scc0 %s" % L(k))
+    label(k + "b")
+    finish_sites.append(k)
+
+
+def emit_finish_blocks():
+    for k in finish_sites:
+        label(k)
+        emit("""
+        s_waitcnt vmcnt(0)
+        global_store_byte v48, v49, %%[outp]
+        s_sub_u32 s80, s95, 1
+        v_readlane_b32 %%[prev], v49, s80
+        v_readlane_b32 %%[mb], v49, s95
+        s_mov_b32 s94, 0
+        s_branch %s
+        """ % L(k + "b"))
+
+
 def wpos_advance(amount):
     emit("""
     s_add_u32 %%[wpos], %%[wpos], %s
@@ -214,7 +242,7 @@ def wpos_advance(amount):
 
 
 def gen():
-    emit("v_lshlrev_b32 v56, 1, %[vlane]")
+    emit("v_lshlrev_b32 v56, 1, %[vlane]\ns_mov_b32 s94, 0")
     # ------------------------------------------------------------- packet head
     label("pkt")
     emit("""
@@ -230,6 +258,7 @@ def gen():
     fbit("s82")  # isMatch[state2]  (P_IS_MATCH == 0)
     emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L("match"))
     # ------------------------------------------------------------- literal (decompress.go:44-175)
+    need_copy_done()
     emit("""
     s_and_b32 s83, %%[wpos], %%[lp_mask]
     s_lshl_b32 s83, s83, %%[lc]
@@ -444,28 +473,32 @@ def gen():
     s_sub_u32 s80, %%[pos], %%[wbase]
     s_cmp_lt_u32 s80, s93
     s_cbranch_scc1 %s
-    v_add_u32 v60, %%[pos], %%[vlane]
-    v_subrev_u32 v61, s93, v60
-    global_load_ubyte v62, v61, %%[outp]
-    s_sub_u32 s80, s89, 1
-    s_add_u32 %%[pos], %%[pos], s89
-    s_waitcnt vmcnt(0)
-    global_store_byte v60, v62, %%[outp]
-    v_readlane_b32 %%[prev], v62, s80
-    v_readlane_b32 %%[mb], v62, s89
     """ % (L("x3"), L("x3"), L("x3")))
+    need_copy_done()  # the new source may overlap the bytes the pending copy still has to store
+    emit("""
+    v_add_u32 v48, %[pos], %[vlane]
+    v_subrev_u32 v61, s93, v48
+    global_load_ubyte v49, v61, %[outp]
+    s_mov_b32 s94, 1
+    s_mov_b32 s95, s89
+    s_add_u32 %[pos], %[pos], s89
+    """)
     wpos_advance("s89")
     emit("s_branch %s" % L("pkt"))
     # ------------------------------------------------------------- exits
     label("x3")
-    emit("s_mov_b32 %%[lenout], s89\ns_mov_b32 %%[exitc], 3\ns_branch %s" % L("end"))
+    emit("s_mov_b32 %%[lenout], s89\ns_mov_b32 %%[exitc], 3\ns_branch %s" % L("fin"))
     label("x2")
-    emit("s_mov_b32 %%[lenout], s89\ns_mov_b32 %%[exitc], 2\ns_branch %s" % L("end"))
+    emit("s_mov_b32 %%[lenout], s89\ns_mov_b32 %%[exitc], 2\ns_branch %s" % L("fin"))
     label("x1")
-    emit("s_mov_b32 %%[exitc], 1\ns_branch %s" % L("end"))
+    emit("s_mov_b32 %%[exitc], 1\ns_branch %s" % L("fin"))
     label("x0")
-    emit("s_mov_b32 %%[exitc], 0\ns_branch %s" % L("end"))
+    emit("s_mov_b32 %[exitc], 0")
+    label("fin")
+    need_copy_done()
+    emit("s_branch %s" % L("end"))
     emit_stubs()
+    emit_finish_blocks()
     label("end")
 
 
