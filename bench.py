@@ -71,6 +71,10 @@ def main():
     ap.add_argument("--preset", type=int, default=6)
     ap.add_argument("--distinct", type=int, default=0,
                     help="generate only this many distinct streams and reuse them (dev runs; 0 = all distinct)")
+    ap.add_argument("--format", default="lzma1", choices=["lzma1", "lzma2"],
+                    help="lzma2: every stream is ONE raw LZMA2 stream made of --segments independently compressed "
+                         "segments of --size bytes (BASELINE config 4: chunk-parallel units)")
+    ap.add_argument("--segments", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=15.0)
     ap.add_argument("--verify", default="all", choices=["all", "sample", "none"])
@@ -88,13 +92,19 @@ def main():
     nd = args.distinct if args.distinct > 0 else args.streams
     ncpu = effective_cpus()
     workers = max(1, min((os.cpu_count() or 1) // max(1, min(world, 8)), 64))
-    comp, digests = corpus.make_alone_batch(args.family, nd, args.size, base_seed=1 + rank * 1_000_003,
-                                            workers=workers, dict_size=args.dict, lc=args.lc, lp=args.lp,
-                                            pb=args.pb, preset=args.preset)
+    out_size = args.size * (args.segments if args.format == "lzma2" else 1)  # decoded bytes per stream
+    if args.format == "lzma2":
+        comp, digests = corpus.make_lzma2_batch(args.family, nd, args.segments, args.size,
+                                                base_seed=1 + rank * 1_000_003, workers=workers, dict_size=args.dict,
+                                                lc=args.lc, lp=args.lp, pb=args.pb, preset=args.preset)
+    else:
+        comp, digests = corpus.make_alone_batch(args.family, nd, args.size, base_seed=1 + rank * 1_000_003,
+                                                workers=workers, dict_size=args.dict, lc=args.lc, lp=args.lp,
+                                                pb=args.pb, preset=args.preset)
     gen_s = time.time() - t0
     comp_bytes = sum(len(comp[i % nd]) for i in range(args.streams))
     log("[rank %d] corpus: %d streams (%d distinct) x %d B, ratio %.3f, generated in %.1f s with %d workers"
-        % (rank, args.streams, nd, args.size, comp_bytes / (args.streams * args.size), gen_s, workers))
+        % (rank, args.streams, nd, out_size, comp_bytes / (args.streams * out_size), gen_s, workers))
 
     import torch
     import torch.distributed as dist
@@ -111,7 +121,11 @@ def main():
     # ---- upload once: inputs resident in HBM before the timed region -------------------
     ctx = lzma_amd.Context(local_rank)
     t0 = time.time()
-    batch = lzma_amd.Batch(ctx, [lzma_amd.Stream(comp[i % nd], out_cap=args.size) for i in range(args.streams)])
+    if args.format == "lzma2":
+        batch = lzma_amd.Batch(ctx, [lzma_amd.Stream(comp[i % nd], lzma_amd.FMT_LZMA2_RAW, out_cap=out_size,
+                                                     dict_size=args.dict) for i in range(args.streams)])
+    else:
+        batch = lzma_amd.Batch(ctx, [lzma_amd.Stream(comp[i % nd], out_cap=out_size) for i in range(args.streams)])
     log("[rank %d] batch created + uploaded in %.1f s" % (rank, time.time() - t0))
 
     def barrier():
@@ -137,7 +151,7 @@ def main():
 
     # ---- verification, outside the timed region -----------------------------------------
     res = batch.results()
-    bad = [i for i in range(args.streams) if res[i][1] != 0 or res[i][0] != args.size]
+    bad = [i for i in range(args.streams) if res[i][1] != 0 or res[i][0] != out_size]
     if bad:
         raise SystemExit("rank %d: %d streams failed to decode (first: %d, status %d, out_len %d)"
                          % (rank, len(bad), bad[0], res[bad[0]][1], res[bad[0]][0]))
@@ -147,7 +161,7 @@ def main():
         t0 = time.time()
 
         def check(i):
-            return hashlib.sha256(batch.download(i, args.size)).digest() == digests[i % nd]
+            return hashlib.sha256(batch.download(i, out_size)).digest() == digests[i % nd]
         with ThreadPoolExecutor(max_workers=16) as ex:
             ok = list(ex.map(check, idx))
         if not all(ok):
@@ -158,28 +172,30 @@ def main():
     # ---- CPU baseline: rank 0, N = 1 only --------------------------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        fmt_code = 2 if args.format == "lzma2" else 0
         import oracle
         threads = int(os.environ.get("XLZ_BENCH_CPU_THREADS", "0")) or ncpu
         # calibrate on one stream per thread, then size the sample for ~cpu_target_s
         k = min(threads, args.streams)
-        _, _, per_round = oracle.decode_batch_mt([comp[i % nd] for i in range(k)], [args.size] * k, threads,
-                                                 timing=True)
+        _, _, per_round = oracle.decode_batch_mt([comp[i % nd] for i in range(k)], [out_size] * k, threads,
+                                                 fmt=fmt_code, dict_size=args.dict, timing=True)
         rounds = max(1, int(args.cpu_target_s / max(per_round, 1e-3)))
         n_sample = min(args.streams, max(k, rounds * k))
         sample = [comp[i % nd] for i in range(n_sample)]
-        outs, sts, dt = oracle.decode_batch_mt(sample, [args.size] * n_sample, threads, timing=True)
+        outs, sts, dt = oracle.decode_batch_mt(sample, [out_size] * n_sample, threads, fmt=fmt_code,
+                                               dict_size=args.dict, timing=True)
         assert all(s == 0 for s in sts)
         for i in range(0, n_sample, max(1, n_sample // 16)):
             buf, n_out = outs[i]
             assert hashlib.sha256(buf.raw[:n_out]).digest() == digests[i % nd]
-        cpu = {"value": round(n_sample * args.size / GIB / dt, 4), "unit": "GiB/s", "cores": threads, "kind": "port",
+        cpu = {"value": round(n_sample * out_size / GIB / dt, 4), "unit": "GiB/s", "cores": threads, "kind": "port",
                "sample": "%d of the %d streams (%d MiB decoded) in %.2f s of decode wall time; C restatement of the "
                          "Go reference's algorithm (oracle/xlz_oracle.c, gcc -O2), one stream per thread on all "
                          "%d host CPUs; Go toolchain absent" % (n_sample, args.streams, n_sample * args.size >> 20,
                                                                 dt, threads)}
 
     if rank == 0:
-        total_out = world * args.streams * args.size * args.steps
+        total_out = world * args.streams * out_size * args.steps
         value = total_out / GIB / t_max
         algo_bytes = cin + cout  # per launch: compressed bytes read once + decoded bytes written once
         achieved = algo_bytes / 1e9 / (kernel_ms / 1e3)
@@ -197,12 +213,14 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": "%d independent LZMA1 (.lzma) streams per GPU, lc=%d lp=%d pb=%d, %d KiB dict, %d B "
-                            "uncompressed each, family %s (corpus.py), liblzma preset %d, inputs resident in HBM"
-                            % (args.streams, args.lc, args.lp, args.pb, args.dict >> 10, args.size, args.family,
-                               args.preset),
-                "streams_per_gpu": args.streams, "bytes_per_stream": args.size,
-                "compression_ratio": round(comp_bytes / (args.streams * args.size), 4),
+                "workload": ("%d independent LZMA1 (.lzma) streams per GPU" % args.streams if args.format == "lzma1" else
+                             "%d raw LZMA2 stream(s) per GPU of %d dictionary-reset segments each" % (args.streams,
+                                                                                                     args.segments))
+                            + ", lc=%d lp=%d pb=%d, %d KiB dict, %d B uncompressed per stream, family %s (corpus.py), "
+                            "liblzma preset %d, inputs resident in HBM" % (args.lc, args.lp, args.pb, args.dict >> 10,
+                                                                           out_size, args.family, args.preset),
+                "streams_per_gpu": args.streams, "bytes_per_stream": out_size,
+                "compression_ratio": round(comp_bytes / (args.streams * out_size), 4),
                 "bit_exact": args.verify, "parallelism": "shard-by-stream x%d, no collective" % world,
             },
             "roofline": {

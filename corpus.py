@@ -144,3 +144,43 @@ def make_alone_batch(family, n_streams, size, base_seed=1, workers=None, **kw):
         with ProcessPoolExecutor(max_workers=workers) as ex:
             res = list(ex.map(_make_one, jobs, chunksize=max(1, n_streams // (workers * 8))))
     return [r[0] for r in res], [r[1] for r in res]
+
+
+def _make_one_lzma2(args):
+    family, seed, n_seg, seg_size, kw = args
+    segs = [plain(family, seed * 4099 + k, seg_size) for k in range(n_seg)]
+    h = hashlib.sha256()
+    for sg in segs:
+        h.update(sg)
+    return lzma2_concat(segs, **kw), h.digest()
+
+
+def make_lzma2_batch(family, n_streams, n_segments, seg_size, base_seed=1, workers=None, **kw):
+    """n_streams raw LZMA2 streams, each n_segments independently compressed segments."""
+    jobs = [(family, base_seed + i, n_segments, seg_size, kw) for i in range(n_streams)]
+    workers = workers or min(os.cpu_count() or 1, 32)
+    if n_streams >= 4 and workers > 1:
+        with ProcessPoolExecutor(max_workers=workers) as ex:
+            res = list(ex.map(_make_one_lzma2, jobs, chunksize=1))
+    elif workers > 1 and n_segments >= 8:
+        # few big streams: parallelise over segments instead
+        res = []
+        for (fam, seed, n_seg, seg_size_, kw_) in jobs:
+            with ProcessPoolExecutor(max_workers=workers) as ex:
+                parts = list(ex.map(_lzma2_segment, [(fam, seed * 4099 + k, seg_size_, kw_) for k in range(n_seg)],
+                                    chunksize=max(1, n_seg // (workers * 4))))
+            h = hashlib.sha256()
+            for _, pl in parts:
+                h.update(pl)
+            res.append((b"".join(c for c, _ in parts) + b"\x00", h.digest()))
+    else:
+        res = [_make_one_lzma2(j) for j in jobs]
+    return [r[0] for r in res], [r[1] for r in res]
+
+
+def _lzma2_segment(args):
+    family, seed, seg_size, kw = args
+    p = plain(family, seed, seg_size)
+    c = compress_raw_lzma2(p, **kw)
+    assert c[-1] == 0
+    return c[:-1], p
