@@ -475,8 +475,31 @@ static_assert(P_IS_MATCH == 0 && P_IS_REP == 192 && P_IS_REP_G0 == 204 && P_IS_R
 
 enum : uint32_t { FX_LIMIT = 0, FX_ERR = 1, FX_MARKER = 2, FX_COPY = 3 };
 
-__device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint32_t lane, uint32_t arel_lim,
-                                                   uint32_t pos_lim, uint32_t &lenout)
+// Per-lane constants of the head gather: lane j fetches the j-th context-selected probability a
+// packet can start with; its LDS byte address is hc + state * hms + state2 * hm2.
+struct HeadVec {
+    uint32_t hc, hms, hm2;
+};
+__device__ __forceinline__ HeadVec head_vectors(uint32_t lane)
+{
+    HeadVec h;
+    const uint32_t base = lane == 0 ? P_IS_MATCH
+                          : lane == 1 ? P_IS_REP
+                          : lane == 2 ? P_IS_REP_G0
+                          : lane == 3 ? P_IS_REP_G1
+                          : lane == 4 ? P_IS_REP_G2
+                          : lane == 5 ? P_IS_REP0_LONG
+                          : lane == 6 ? P_LEN + LEN_CHOICE
+                          : lane == 7 ? P_LEN + LEN_CHOICE2
+                          : lane == 8 ? P_REP_LEN + LEN_CHOICE : lane == 9 ? P_REP_LEN + LEN_CHOICE2 : 0u;
+    h.hc = base * 2;
+    h.hms = (lane >= 1 && lane <= 4) ? 2u : 0u; // indexed by state
+    h.hm2 = (lane == 0 || lane == 5) ? 2u : 0u; // indexed by state2 = (state << 4) + posState
+    return h;
+}
+
+__device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint32_t lane, const HeadVec &hv,
+                                                   uint32_t arel_lim, uint32_t pos_lim, uint32_t &lenout)
 {
     uint32_t exitc;
     asm volatile(
@@ -487,15 +510,17 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint32_
           [lenout] "=&s"(lenout)
         : [arel_lim] "s"(arel_lim), [pos_lim] "s"(pos_lim), [dict] "s"(d.dict_size), [pos_mask] "s"(d.pos_mask),
           [lp_mask] "s"(d.lp_mask), [lc] "s"(d.lc), [wbase] "s"(d.wbase), [outp] "s"(out), [vin] "v"(d.vin),
-          [vlane] "v"(lane)
+          [vlane] "v"(lane), [vhc] "v"(hv.hc), [vhms] "v"(hv.hms), [vhm2] "v"(hv.hm2)
         : "scc", "memory", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
-          "s93", "s94", "s95", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62",
+          "s93", "s94", "s95", "s96", "s97", "s98", "v35", "v36", "v37", "v40", "v41", "v42", "v43", "v44", "v45", "v46",
+          "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62",
           "v63");
     return exitc;
 }
 
 // (*Reader1).decompress run to the end of the current LZMA chunk (decompress.go:8-1136)
-__device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint8_t *__restrict__ out, uint32_t lane)
+__device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint8_t *__restrict__ out, uint32_t lane,
+                                        const HeadVec &hv)
 {
     for (;;) {
         // decompress.go:14-20
@@ -516,7 +541,7 @@ __device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint8_t *__rest
         if (d.size_defined) room = min(room, d.bytes_left - kFastOutput);
         const uint32_t pos0 = d.pos;
         uint32_t len = 0;
-        const uint32_t ec = lzma_fast_loop(d, out, lane, arel_lim, pos0 + room + 1, len);
+        const uint32_t ec = lzma_fast_loop(d, out, lane, hv, arel_lim, pos0 + room + 1, len);
         d.bytes_left -= d.pos - pos0; // :172,660,665 ... (wraps harmlessly when the size is undefined)
         if (ec == FX_ERR) return RUN_ERR_RESULT; // :651-653, :690-692
         if (ec == FX_MARKER) {                    // end marker :633-645 (bytesLeft > 0 here if defined)
@@ -697,6 +722,7 @@ __global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t probs[];
     const uint32_t lane = threadIdx.x;
+    const HeadVec hv = head_vectors(lane);
 
     for (;;) {
         // dequeue: lane 0 bumps the head; lanes 1..63 add 0 to pad words of the same
@@ -761,7 +787,7 @@ __global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
                 status = ST_ERR_RC_INIT;
                 break;
             }
-            const int r = lzma_run(d, probs, out, lane);
+            const int r = lzma_run(d, probs, out, lane, hv);
             status = r == RUN_END ? ST_OK
                                   : r == RUN_INPUT_EOF ? ST_OK_INPUT_EOF
                                                        : r == RUN_OUT_CAP ? ST_ERR_OUT_CAP : ST_ERR_RESULT;

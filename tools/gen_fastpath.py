@@ -2,9 +2,9 @@
 """Generates lzma_amd/csrc/xlz_fastpath.inc: the hand-scheduled gfx950 fast loop of the
 LZMA packet decoder as ONE inline-asm statement (run from the repo root).
 
-Why generated: ~50 decision sites each need the same 11-instruction core, a look-ahead
-variant inside bit trees, and an out-of-line normalisation stub with its own labels.  Writing
-that by hand invites typos; this script is the source, the .inc file is committed next to it.
+Why generated: ~60 decision sites each need the same scalar core, an out-of-line
+normalisation stub with its own labels, and the bit trees are unrolled.  Writing that by
+hand invites typos; this script is the source, the .inc file is committed next to it.
 
 The loop decodes whole packets (decompress.go:13 ff.) while
     arel <= arel_lim   (>= 32 readable bytes left in the 256-byte input window)
@@ -15,16 +15,33 @@ and leaves with an exit code:
     2  distance 0xFFFFFFFF decoded (end marker): caller applies decompress.go:633-645
     3  a match copy the loop does not do itself (len >= 64, overlapping, or reaching in
        front of the dictionary epoch): caller copies `lenout` bytes and carries on
-State mutations happen in the reference's order; normalisation order is irrelevant here
-because no input exhaustion is possible inside the loop.
+Every probability is read once and written once per packet, in the reference's order of
+decisions; normalisation order is irrelevant here because no input exhaustion is possible
+inside the loop.
 
-Register conventions (fixed temporaries, declared as clobbers):
-  s80,s81 core temps   s82 address temp   s83,s84 temps   s86 P (probability)   s87 BIT
-  s88 M (tree index / symbol)   s89 LEN   s90 posState   s91 state2   s92 tree base (bytes)
-  s93 dist   s94 copy pending   s95 its length   v48 its destination   v49 its bytes
-  v50..v53 tree blocks   v54 probabilities met on a walk   v55 temp   s85 2M+1
-  v56 2*lane   v57 fbit address   v58 tree base (uniform)   v59 tree base + 2*lane
-  v60 write-back address / copy dst   v61 children address / copy src   v62 loaded   v63 new prob
+How the 64 lanes are used (the wave is the register file of ONE decoder):
+  * head gather: one ds_read with per-lane addresses fetches the ten context-selected
+    probabilities a packet can start with (isMatch, isRep, isRepG0-2, isRep0Long, the four
+    length `choice` bits) into v40; a decision takes its probability with v_readlane.
+  * tree blocks: one ds_read fetches 64 consecutive probabilities of a bit tree (lane j =
+    node 64b + j).  A tree level is then nine scalar instructions plus
+    `v_readlane p, block, M`: the lane select IS the node index, so neither the decoded bit
+    nor an LDS address is ever formed.  Blocks are requested well before they are walked.
+  * the probabilities met on a walk are parked in v54 (v_writelane) and updated together
+    in one vector operation (tree_update), lanes = levels.
+  * match copy: one byte per lane; its completion (store + prevByte/matchByte) is deferred
+    behind the next packet's decode.
+
+Register conventions (fixed temporaries, declared as clobbers in xlz_kernel.hip):
+  s80,s81 core temps   s82,s83,s84 temps   s85 2M+1   s86 P   s87 BIT   s88 M (tree index)
+  s89 LEN   s90 posState   s91 state2   s92 table base (bytes)   s93 dist
+  s94 copy pending   s95 its length   s96 levels of the walk awaiting its update
+  s97 literal blocks prefetched   s98 posSlot / nbits
+  v35 align block   v36 posSlot block   v37 posDecoders block   v40 head probabilities
+  v41,v42 len low/mid blocks   v43..v46 len high blocks   v47 head addresses
+  v48,v49 pending copy (destination, bytes)   v50..v53 literal blocks   v54 walk record
+  v55 temp   v56 2*lane   v57 address temp   v58 walk base   v59 gather address
+  v60..v63 temps
 """
 import os
 
@@ -33,8 +50,12 @@ P_IS_MATCH, P_IS_REP, P_IS_REP_G0, P_IS_REP_G1, P_IS_REP_G2, P_IS_REP0_LONG = 0,
 P_POS_SLOT, P_POS_DEC, P_ALIGN, P_LEN, P_REP_LEN, P_LIT = 432, 688, 804, 820, 1336, 1852
 LEN_CHOICE, LEN_CHOICE2, LEN_LOW, LEN_MID, LEN_HIGH = 0, 1, 4, 132, 260
 
+# head gather lanes (the per-lane address constants are built in xlz_kernel.hip: head_vectors)
+H_IS_MATCH, H_IS_REP, H_G0, H_G1, H_G2, H_REP0_LONG, H_LEN_C, H_LEN_C2, H_REP_C, H_REP_C2 = range(10)
+
 lines = []
 stubs = []
+finish_sites = []
 uid = [0]
 
 
@@ -54,6 +75,8 @@ def L(name):
 
 
 def core():
+    """bound = (range >> 11) * p; the borrow of code - bound IS the decision (SCC).  Leaves
+    BIT in s87 and the updated probability p - ((p - k) >>a 5), k = bit ? 0 : 2017, in v63."""
     emit("""
     s_lshr_b32 s80, %[range], 11
     s_mul_i32 s80, s80, s86
@@ -66,6 +89,19 @@ def core():
     s_sub_u32 s81, s86, s81
     v_ashrrev_i32 v63, 5, s81
     v_sub_u32 v63, s86, v63
+    """)
+
+
+def walk_core():
+    """decision core of a tree level: range and code selected, SCC = (code < bound) kept for
+    the caller's s_subb that advances the tree index"""
+    emit("""
+    s_lshr_b32 s80, %[range], 11
+    s_mul_i32 s80, s80, s86
+    s_sub_u32 s81, %[range], s80
+    s_sub_u32 s87, %[code], s80
+    s_cselect_b32 %[range], s80, s81
+    s_cselect_b32 %[code], %[code], s87
     """)
 
 
@@ -96,117 +132,6 @@ def emit_stubs():
         """ % (L(k + "b"), L(k + "b")))
 
 
-def fbit(addr_sgpr):
-    """one decision on the prob at LDS byte address in addr_sgpr; result in s87"""
-    emit("v_mov_b32 v57, %s\nds_read_u16 v62, v57\ns_waitcnt lgkmcnt(0)\nv_readfirstlane_b32 s86, v62" % addr_sgpr)
-    core()
-    emit("ds_write_b16 v57, v63")
-    nchk()
-
-
-def fbit_const(prob_index):
-    emit("s_movk_i32 s82, %d" % (prob_index * 2))
-    fbit("s82")
-
-
-def walk_core():
-    """decision core without bit / probability update: SCC = (code < bound) on exit of the
-    two subtractions, range and code selected; the tree index is advanced by the caller"""
-    emit("""
-    s_lshr_b32 s80, %[range], 11
-    s_mul_i32 s80, s80, s86
-    s_sub_u32 s81, %[range], s80
-    s_sub_u32 s87, %[code], s80
-    s_cselect_b32 %[range], s80, s81
-    s_cselect_b32 %[code], %[code], s87
-    """)
-
-
-def tree_update(nb):
-    """Apply the model updates of a finished tree walk in ONE vector operation.
-    s88 = final index (leading 1 + nb decided bits), v54 lane k = probability seen at level k,
-    v58 = tree base address.  nb: int, or the name of an SGPR holding the level count.
-    Lane k: node = s88 >> (nb-k), bit = (s88 >> (nb-k-1)) & 1,
-            new = p - ((p - (bit ? 0 : 2017)) >>a 5)   (decompress.go:30 / :177)."""
-    emit("""
-    v_sub_u32 v55, %s, %%[vlane]
-    v_lshrrev_b32 v60, v55, s88
-    v_add_u32 v61, -1, v55
-    v_lshrrev_b32 v61, v61, s88
-    v_and_b32 v61, 1, v61
-    v_lshl_add_u32 v60, v60, 1, v58
-    v_mul_u32_u24 v61, 0x7e1, v61
-    v_sub_u32 v61, 0x7e1, v61
-    v_sub_u32 v61, v54, v61
-    v_ashrrev_i32 v61, 5, v61
-    v_sub_u32 v61, v54, v61
-    """ % nb)
-    if isinstance(nb, int):
-        emit("s_mov_b64 exec, %d" % ((1 << nb) - 1))
-    else:
-        emit("s_bfm_b64 exec, %s, 0" % nb)
-    emit("ds_write_b16 v60, v61\ns_mov_b64 exec, -1")
-
-
-def tree(nbits):
-    """Bit tree of nbits levels rooted at LDS byte address s92 (bit_tree_decoder.go:18-40).
-    One LDS read fetches a whole 64-prob block of the tree (lane j = node 64b + j); a level is
-    then nine scalar instructions plus `v_readlane p, block, M` -- the lane select IS the node
-    index, so neither the decoded bit nor an address is ever materialised.  The probabilities
-    met on the way are parked in v54 (v_writelane) and updated together by tree_update."""
-    emit("v_add_u32 v59, s92, v56\nds_read_u16 v50, v59")
-    if nbits == 8:
-        emit("ds_read_u16 v51, v59 offset:128\nds_read_u16 v52, v59 offset:256\nds_read_u16 v53, v59 offset:384")
-    emit("v_mov_b32 v58, s92\ns_mov_b32 s88, 1\ns_waitcnt lgkmcnt(0)\nv_readlane_b32 s86, v50, 1")
-    for k in range(nbits):
-        emit("v_writelane_b32 v54, s86, %d\ns_lshl1_add_u32 s85, s88, 1" % k)
-        walk_core()
-        emit("s_subb_u32 s88, s85, 0")  # M = 2M + 1 - SCC = 2M + bit
-        nchk()
-        if k + 1 < nbits:
-            if k + 1 <= 5:
-                emit("v_readlane_b32 s86, v50, s88")
-            elif k + 1 == 6:
-                emit("v_readlane_b32 s86, v51, s88")
-            else:  # node 128..255: block 2 or 3 by bit 6 of M
-                emit("v_readlane_b32 s86, v52, s88\nv_readlane_b32 s84, v53, s88\ns_bitcmp1_b32 s88, 6\ns_cselect_b32 s86, s84, s86")
-    tree_update(nbits)
-
-
-def level(last=False):
-    """one level with child look-ahead and immediate update (used by the matched-literal tail)"""
-    if not last:
-        emit("v_lshl_add_u32 v61, s88, 2, v59\nds_read_u16 v62, v61")
-    core()
-    emit("v_lshl_add_u32 v60, s88, 1, v58\nds_write_b16 v60, v63\ns_lshl1_add_u32 s88, s88, s87")
-    nchk()
-    if not last:
-        emit("s_waitcnt lgkmcnt(0)\nv_readlane_b32 s86, v62, s87")
-
-
-def len_decode(tag, base):
-    """lenDecoder.Decode (len_decoder.go:34-60): raw length -> s89.  posState in s90."""
-    fbit_const(base + LEN_CHOICE)
-    emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L(tag + "c2"))
-    emit("s_lshl_b32 s92, s90, 4\ns_add_u32 s92, s92, %d" % ((base + LEN_LOW) * 2))
-    tree(3)
-    emit("s_sub_u32 s89, s88, 8\ns_branch %s" % L(tag + "end"))
-    label(tag + "c2")
-    fbit_const(base + LEN_CHOICE2)
-    emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L(tag + "hi"))
-    emit("s_lshl_b32 s92, s90, 4\ns_add_u32 s92, s92, %d" % ((base + LEN_MID) * 2))
-    tree(3)
-    emit("s_mov_b32 s89, s88\ns_branch %s" % L(tag + "end"))
-    label(tag + "hi")
-    emit("s_movk_i32 s92, %d" % ((base + LEN_HIGH) * 2))
-    tree(8)
-    emit("s_sub_u32 s89, s88, 240")
-    label(tag + "end")
-
-
-finish_sites = []
-
-
 def need_copy_done():
     """The previous match copy's load is left in flight while the next packet decodes; whoever
     needs its bytes (prevByte / matchByte for a literal, the next copy, any exit) comes here
@@ -232,6 +157,118 @@ def emit_finish_blocks():
         """ % L(k + "b"))
 
 
+def fbit(addr_sgpr):
+    """one decision on the prob at LDS byte address in addr_sgpr (fetched here); bit in s87"""
+    emit("v_mov_b32 v57, %s\nds_read_u16 v62, v57\ns_waitcnt lgkmcnt(0)\nv_readfirstlane_b32 s86, v62" % addr_sgpr)
+    core()
+    emit("ds_write_b16 v57, v63")
+    nchk()
+
+
+def hbit(lane):
+    """one decision on head probability `lane` (already in v40); written back by that lane"""
+    emit("v_readlane_b32 s86, v40, %d" % lane)
+    core()
+    emit("s_mov_b64 exec, %d\nds_write_b16 v47, v63\ns_mov_b64 exec, -1" % (1 << lane))
+    nchk()
+
+
+def walk(nbits, blocks, early_exit=None):
+    """Walk nbits levels of the bit tree whose 64-prob blocks are already in `blocks`
+    (bit_tree_decoder.go:18-40).  s88 ends as 1 followed by the decided bits; the probability
+    of level k is parked in lane k of v54.  early_exit = (sgpr, label): leave after as many
+    levels as the SGPR says (reverse tree over posDecoders, 1..5 levels)."""
+    emit("s_mov_b32 s88, 1\nv_readlane_b32 s86, %s, 1" % blocks[0])
+    for k in range(nbits):
+        emit("v_writelane_b32 v54, s86, %d\ns_lshl1_add_u32 s85, s88, 1" % k)
+        walk_core()
+        emit("s_subb_u32 s88, s85, 0")  # M = 2M + 1 - SCC = 2M + bit
+        nchk()
+        if k + 1 < nbits:
+            if early_exit:
+                emit("s_cmp_eq_u32 %s, %d\ns_cbranch_scc1 %s" % (early_exit[0], k + 1, early_exit[1]))
+            if k + 1 <= 5:
+                emit("v_readlane_b32 s86, %s, s88" % blocks[0])
+            elif k + 1 == 6:
+                emit("v_readlane_b32 s86, %s, s88" % blocks[1])
+            else:  # node 128..255: block 2 or 3 by bit 6 of M
+                emit("v_readlane_b32 s86, %s, s88\nv_readlane_b32 s84, %s, s88\ns_bitcmp1_b32 s88, 6\n"
+                     "s_cselect_b32 s86, s84, s86" % (blocks[2], blocks[3]))
+
+
+def tree_update(nb):
+    """Apply the model updates of a finished walk in ONE vector operation.  s88 = final index,
+    v54 lane k = probability seen at level k, v58 = byte address of the tree base.
+    nb: int, or the name of an SGPR holding the level count.
+    Lane k: node = s88 >> (nb-k), bit = (s88 >> (nb-k-1)) & 1,
+            new = p - ((p - (bit ? 0 : 2017)) >>a 5)   (decompress.go:30 / :177)."""
+    emit("""
+    v_sub_u32 v55, %s, %%[vlane]
+    v_lshrrev_b32 v60, v55, s88
+    v_add_u32 v61, -1, v55
+    v_lshrrev_b32 v61, v61, s88
+    v_and_b32 v61, 1, v61
+    v_lshl_add_u32 v60, v60, 1, v58
+    v_mul_u32_u24 v61, 0x7e1, v61
+    v_sub_u32 v61, 0x7e1, v61
+    v_sub_u32 v61, v54, v61
+    v_ashrrev_i32 v61, 5, v61
+    v_sub_u32 v61, v54, v61
+    """ % nb)
+    if isinstance(nb, int):
+        emit("s_mov_b64 exec, %d" % ((1 << nb) - 1))
+    else:
+        emit("s_bfm_b64 exec, %s, 0" % nb)
+    emit("ds_write_b16 v60, v61\ns_mov_b64 exec, -1")
+
+
+def level_lookahead():
+    """one level with child look-ahead and immediate update (matched-literal tail, v58/v59 set)"""
+    emit("v_lshl_add_u32 v61, s88, 2, v59\nds_read_u16 v62, v61")
+    core()
+    emit("v_lshl_add_u32 v60, s88, 1, v58\nds_write_b16 v60, v63\ns_lshl1_add_u32 s88, s88, s87")
+    nchk()
+    emit("s_waitcnt lgkmcnt(0)\nv_readlane_b32 s86, v62, s87")
+
+
+def len_prefetch(base):
+    """request the three length trees of this posState (blocks v41..v46)"""
+    emit("""
+    s_lshl_b32 s92, s90, 4
+    v_add_u32 v59, s92, v56
+    ds_read_u16 v41, v59 offset:%d
+    ds_read_u16 v42, v59 offset:%d
+    ds_read_u16 v43, v56 offset:%d
+    ds_read_u16 v44, v56 offset:%d
+    ds_read_u16 v45, v56 offset:%d
+    ds_read_u16 v46, v56 offset:%d
+    """ % ((base + LEN_LOW) * 2, (base + LEN_MID) * 2, (base + LEN_HIGH) * 2, (base + LEN_HIGH) * 2 + 128,
+           (base + LEN_HIGH) * 2 + 256, (base + LEN_HIGH) * 2 + 384))
+
+
+def len_decode(tag, base, lane_c, lane_c2):
+    """lenDecoder.Decode (len_decoder.go:34-60): raw length -> s89; the walked tree's update is
+    left pending (s96 = its level count, v58 = its base, s88 / v54 = the walk)."""
+    hbit(lane_c)
+    emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L(tag + "c2"))
+    emit("s_lshl_b32 s92, s90, 4\ns_add_u32 s92, s92, %d\nv_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)"
+         % ((base + LEN_LOW) * 2))
+    walk(3, ["v41"])
+    emit("s_sub_u32 s89, s88, 8\ns_mov_b32 s96, 3\ns_branch %s" % L(tag + "end"))
+    label(tag + "c2")
+    hbit(lane_c2)
+    emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L(tag + "hi"))
+    emit("s_lshl_b32 s92, s90, 4\ns_add_u32 s92, s92, %d\nv_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)"
+         % ((base + LEN_MID) * 2))
+    walk(3, ["v42"])
+    emit("s_mov_b32 s89, s88\ns_mov_b32 s96, 3\ns_branch %s" % L(tag + "end"))
+    label(tag + "hi")
+    emit("s_movk_i32 s92, %d\nv_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)" % ((base + LEN_HIGH) * 2))
+    walk(8, ["v43", "v44", "v45", "v46"])
+    emit("s_sub_u32 s89, s88, 240\ns_mov_b32 s96, 8")
+    label(tag + "end")
+
+
 def wpos_advance(amount):
     emit("""
     s_add_u32 %%[wpos], %%[wpos], %s
@@ -239,6 +276,24 @@ def wpos_advance(amount):
     s_cselect_b32 s80, %%[dict], 0
     s_sub_u32 %%[wpos], %%[wpos], s80
     """ % amount)
+
+
+def literal_context():
+    """literal table base -> s92 (decompress.go:56-57) and its four 64-prob blocks requested"""
+    emit("""
+    s_and_b32 s83, %%[wpos], %%[lp_mask]
+    s_lshl_b32 s83, s83, %%[lc]
+    s_sub_u32 s84, 8, %%[lc]
+    s_lshr_b32 s84, %%[prev], s84
+    s_add_u32 s83, s83, s84
+    s_mulk_i32 s83, 0x600
+    s_add_u32 s92, s83, %d
+    v_add_u32 v59, s92, v56
+    ds_read_u16 v50, v59
+    ds_read_u16 v51, v59 offset:128
+    ds_read_u16 v52, v59 offset:256
+    ds_read_u16 v53, v59 offset:384
+    """ % (P_LIT * 2))
 
 
 def gen():
@@ -253,24 +308,28 @@ def gen():
     s_and_b32 s90, %%[wpos], %%[pos_mask]
     s_lshl_b32 s91, %%[state], 4
     s_add_u32 s91, s91, s90
-    s_lshl_b32 s82, s91, 1
-    """ % (L("x0"), L("x0")))
-    fbit("s82")  # isMatch[state2]  (P_IS_MATCH == 0)
+    v_mad_u32_u24 v47, %%[state], %%[vhms], %%[vhc]
+    v_mad_u32_u24 v47, s91, %%[vhm2], v47
+    ds_read_u16 v40, v47
+    s_mov_b32 s97, 0
+    s_cmp_lg_u32 s94, 0
+    s_cbranch_scc1 %s
+    s_mov_b32 s97, 1
+    """ % (L("x0"), L("x0"), L("nopf")))
+    literal_context()  # speculative: prevByte is known (no copy pending)
+    label("nopf")
+    emit("s_waitcnt lgkmcnt(0)")
+    hbit(H_IS_MATCH)
     emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L("match"))
     # ------------------------------------------------------------- literal (decompress.go:44-175)
     need_copy_done()
-    emit("""
-    s_and_b32 s83, %%[wpos], %%[lp_mask]
-    s_lshl_b32 s83, s83, %%[lc]
-    s_sub_u32 s84, 8, %%[lc]
-    s_lshr_b32 s84, %%[prev], s84
-    s_add_u32 s83, s83, s84
-    s_mulk_i32 s83, 0x600
-    s_add_u32 s92, s83, %d
-    s_cmp_ge_u32 %%[state], 7
-    s_cbranch_scc1 %s
-    """ % (P_LIT * 2, L("mlit")))
-    tree(8)
+    emit("s_cmp_lg_u32 s97, 0\ns_cbranch_scc1 %s" % L("litready"))
+    literal_context()
+    emit("s_waitcnt lgkmcnt(0)")
+    label("litready")
+    emit("s_cmp_ge_u32 %%[state], 7\ns_cbranch_scc1 %s\nv_mov_b32 v58, s92" % L("mlit"))
+    walk(8, ["v50", "v51", "v52", "v53"])
+    tree_update(8)
     label("litdone")
     emit("""
     s_and_b32 %[prev], s88, 0xff
@@ -322,65 +381,67 @@ def gen():
     v_readfirstlane_b32 s86, v62
     """ % L("litdone"))
     label("mlr")
-    level()
+    level_lookahead()
     emit("s_cmpk_lt_u32 s88, 0x100\ns_cbranch_scc1 %s\ns_branch %s" % (L("mlr"), L("litdone")))
     # ------------------------------------------------------------- match or rep
     label("match")
-    emit("s_add_u32 s82, %%[state], %d\ns_lshl_b32 s82, s82, 1" % P_IS_REP)
-    fbit("s82")
+    hbit(H_IS_REP)
     emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L("rep"))
     # simple match (:215-668)
     emit("s_mov_b32 %[rep3], %[rep2]\ns_mov_b32 %[rep2], %[rep1]\ns_mov_b32 %[rep1], %[rep0]")
-    len_decode("lm", P_LEN)
+    len_prefetch(P_LEN)
+    emit("ds_read_u16 v35, v56 offset:%d" % (P_ALIGN * 2))
+    len_decode("lm", P_LEN, H_LEN_C, H_LEN_C2)
     emit("""
     s_cmp_lt_u32 %%[state], 7
     s_cselect_b32 %%[state], 7, 10
     s_min_u32 s83, s89, 3
     s_lshl_b32 s83, s83, 7
     s_add_u32 s92, s83, %d
+    v_add_u32 v59, s92, v56
+    ds_read_u16 v36, v59
     """ % (P_POS_SLOT * 2))
-    tree(6)
+    tree_update("s96")  # the length tree, while the posSlot block is on its way
+    emit("v_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)")
+    walk(6, ["v36"])
     emit("""
-    s_sub_u32 s88, s88, 64
-    s_cmp_lt_u32 s88, 4
+    s_sub_u32 s98, s88, 64
+    s_cmp_lt_u32 s98, 4
     s_cbranch_scc0 %s
-    s_mov_b32 %%[rep0], s88
-    s_branch %s
-    """ % (L("dist"), L("distdone")))
+    s_mov_b32 %%[rep0], s98
+    """ % L("dist"))
+    tree_update(6)
+    emit("s_branch %s" % L("distdone"))
     label("dist")
     emit("""
-    s_lshr_b32 s83, s88, 1
+    s_lshr_b32 s83, s98, 1
     s_sub_u32 s83, s83, 1
-    s_and_b32 s84, s88, 1
+    s_and_b32 s84, s98, 1
     s_or_b32 s84, s84, 2
     s_lshl_b32 s93, s84, s83
-    s_cmp_lt_u32 s88, 14
+    s_cmp_lt_u32 s98, 14
     s_cbranch_scc0 %s
-    s_sub_u32 s84, s93, s88
+    s_sub_u32 s84, s93, s98
     s_add_u32 s84, s84, %d
     s_lshl_b32 s92, s84, 1
+    v_add_u32 v59, s92, v56
+    ds_read_u16 v37, v59
     """ % (L("direct"), P_POS_DEC))
-    # reverse bit tree over posDecoders (:495-546): s83 levels (1..5) from base s92; block walk,
-    # unrolled with an early exit (v_writelane cannot take two different SGPRs)
-    emit("v_add_u32 v59, s92, v56\nds_read_u16 v50, v59\nv_mov_b32 v58, s92\ns_mov_b32 s88, 1\ns_waitcnt lgkmcnt(0)\nv_readlane_b32 s86, v50, 1")
-    for k in range(5):
-        emit("v_writelane_b32 v54, s86, %d\ns_lshl1_add_u32 s85, s88, 1" % k)
-        walk_core()
-        emit("s_subb_u32 s88, s85, 0")
-        nchk()
-        if k < 4:
-            emit("s_cmp_eq_u32 s83, %d\ns_cbranch_scc1 %s\nv_readlane_b32 s86, v50, s88" % (k + 1, L("rtdone")))
+    tree_update(6)  # posSlot tree, while the posDecoders block is on its way
+    # reverse bit tree over posDecoders (:495-546): s83 levels (1..5)
+    emit("v_mov_b32 v58, s92\ns_mov_b32 s98, s83\ns_waitcnt lgkmcnt(0)")
+    walk(5, ["v37"], early_exit=("s98", L("rtdone")))
     label("rtdone")
-    tree_update("s83")
-    # symbol = the s83 decided bits of M in reverse order (bit_tree_decoder.go:42-70)
+    tree_update("s98")
     emit("""
     s_brev_b32 s80, s88
-    s_sub_u32 s81, 32, s83
+    s_sub_u32 s81, 32, s98
     s_lshr_b32 s80, s80, s81
     s_add_u32 %%[rep0], s93, s80
     s_branch %s
     """ % L("distdone"))
     label("direct")  # DecodeDirectBits (:549-577)
+    tree_update(6)  # posSlot tree
     emit("s_sub_u32 s83, s83, 4\ns_mov_b32 s84, 0")
     label("db")
     emit("""
@@ -389,9 +450,8 @@ def gen():
     s_ashr_i32 s80, %[code], 31
     s_and_b32 s81, %[range], s80
     s_add_u32 %[code], %[code], s81
-    s_lshl_b32 s84, s84, 1
+    s_lshl1_add_u32 s84, s84, 1
     s_add_u32 s84, s84, s80
-    s_add_u32 s84, s84, 1
     """)
     nchk()
     emit("""
@@ -401,8 +461,10 @@ def gen():
     s_lshl_b32 s84, s84, 4
     s_add_u32 s93, s93, s84
     s_movk_i32 s92, %d
+    v_mov_b32 v58, s92
     """ % (L("db"), P_ALIGN * 2))
-    tree(4)  # reverse tree over alignDecoderProbs (:579-625): M = 1 b0 b1 b2 b3
+    walk(4, ["v35"])  # reverse tree over alignDecoderProbs (:579-625): M = 1 b0 b1 b2 b3
+    tree_update(4)
     emit("s_brev_b32 s80, s88\ns_lshr_b32 s80, s80, 28\ns_add_u32 %[rep0], s93, s80")
     label("distdone")
     emit("""
@@ -421,11 +483,9 @@ def gen():
     # ------------------------------------------------------------- rep match (:685-1123)
     label("rep")
     emit("s_cmp_eq_u32 %%[pos], %%[wbase]\ns_cbranch_scc1 %s" % L("x1"))
-    emit("s_add_u32 s82, %%[state], %d\ns_lshl_b32 s82, s82, 1" % P_IS_REP_G0)
-    fbit("s82")
+    hbit(H_G0)
     emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L("g1"))
-    emit("s_add_u32 s82, s91, %d\ns_lshl_b32 s82, s82, 1" % P_IS_REP0_LONG)
-    fbit("s82")
+    hbit(H_REP0_LONG)
     emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L("replen"))
     emit("""
     s_cmp_lt_u32 %%[state], 7
@@ -434,13 +494,11 @@ def gen():
     s_branch %s
     """ % L("copy"))  # short rep: one byte
     label("g1")
-    emit("s_add_u32 s82, %%[state], %d\ns_lshl_b32 s82, s82, 1" % P_IS_REP_G1)
-    fbit("s82")
+    hbit(H_G1)
     emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L("g2"))
     emit("s_mov_b32 s80, %%[rep1]\ns_mov_b32 %%[rep1], %%[rep0]\ns_mov_b32 %%[rep0], s80\ns_branch %s" % L("replen"))
     label("g2")
-    emit("s_add_u32 s82, %%[state], %d\ns_lshl_b32 s82, s82, 1" % P_IS_REP_G2)
-    fbit("s82")
+    hbit(H_G2)
     emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L("g3"))
     emit("""
     s_mov_b32 s80, %%[rep2]
@@ -458,7 +516,9 @@ def gen():
     s_mov_b32 %[rep0], s80
     """)
     label("replen")
-    len_decode("lr", P_REP_LEN)
+    len_prefetch(P_REP_LEN)
+    len_decode("lr", P_REP_LEN, H_REP_C, H_REP_C2)
+    tree_update("s96")
     emit("s_cmp_lt_u32 %[state], 7\ns_cselect_b32 %[state], 8, 11\ns_add_u32 s89, s89, 2")
     # ------------------------------------------------------------- window.CopyMatch (window.go:55-87)
     label("copy")
