@@ -199,6 +199,18 @@ def main():
         value = total_out / GIB / t_max
         algo_bytes = cin + cout  # per launch: compressed bytes read once + decoded bytes written once
         achieved = algo_bytes / 1e9 / (kernel_ms / 1e3)
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes over this same
+        # command (tools/profile_bench.sh); bench.py cannot profile itself, so it reports the committed
+        # measurement when it was taken on the same workload, else null.
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_default.json")))
+            workload_now = ("%d independent LZMA1 (.lzma) streams per GPU" % args.streams if args.format == "lzma1" else "")
+            if args.format == "lzma1" and tj["workload"].startswith(workload_now) and \
+                    ("%d B uncompressed per stream, family %s" % (out_size, args.family)) in tj["workload"]:
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         line = {
             "metric": "decompressed GiB/s (aggregate batch)",
             "value": round(value, 4),
@@ -225,7 +237,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "kernel": "xlz::xlz_decode_kernel", "kernel_ms": round(kernel_ms, 3),
                 "algorithmic_bytes_per_launch": algo_bytes, "units_per_launch": units,
             },
