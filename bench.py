@@ -110,9 +110,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the decode path has no CPU fallback)")
+    # rehearsal knobs (one-GPU box): XLZ_BENCH_DEVICE pins every rank to one device,
+    # XLZ_BENCH_BACKEND=gloo replaces RCCL for the barrier / max-reduce (RCCL refuses two ranks per GPU)
+    if os.environ.get("XLZ_BENCH_DEVICE"):
+        local_rank = int(os.environ["XLZ_BENCH_DEVICE"])
+    backend = os.environ.get("XLZ_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import lzma_amd
     from lzma_amd import build
@@ -147,7 +155,7 @@ def main():
     barrier()
     kernel_ms = ctx.event_elapsed_ms(0, 1) / max(1, args.steps)  # HIP events on the kernel's stream
 
-    t_max = multigpu.max_over_ranks(t_local, dist, device="cuda")
+    t_max = multigpu.max_over_ranks(t_local, dist, device="cuda" if backend == "nccl" else "cpu")
 
     # ---- verification, outside the timed region -----------------------------------------
     res = batch.results()
