@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libxlz.so")
 SOURCES = ["xlz_kernel.hip", "xlz_host.hip"]
-HEADERS = ["xlz_format.h", os.path.join("..", "..", "include", "xlz.h")]
+HEADERS = ["xlz_format.h", "xlz_fastpath.inc", os.path.join("..", "..", "include", "xlz.h")]
 ARCH = "gfx950"
 
 

@@ -296,8 +296,25 @@ def literal_context():
     """ % (P_LIT * 2))
 
 
+def head_issue():
+    """posState / state2 of the packet about to start (-> s90, s91) and its head gather"""
+    emit("""
+    s_and_b32 s90, %[wpos], %[pos_mask]
+    s_lshl_b32 s91, %[state], 4
+    s_add_u32 s91, s91, s90
+    v_mad_u32_u24 v47, %[state], %[vhms], %[vhc]
+    v_mad_u32_u24 v47, s91, %[vhm2], v47
+    ds_read_u16 v40, v47
+    """)
+
+
 def gen():
+    # The gathers of packet n+1 are issued from the tail of packet n (software pipelining):
+    # by the time the loop top has done its limit checks the probabilities have arrived.
     emit("v_lshlrev_b32 v56, 1, %[vlane]\ns_mov_b32 s94, 0")
+    head_issue()
+    literal_context()  # no copy is pending on entry: prevByte is valid
+    emit("s_mov_b32 s97, 1")
     # ------------------------------------------------------------- packet head
     label("pkt")
     emit("""
@@ -305,20 +322,8 @@ def gen():
     s_cbranch_scc1 %s
     s_cmp_ge_u32 %%[pos], %%[pos_lim]
     s_cbranch_scc1 %s
-    s_and_b32 s90, %%[wpos], %%[pos_mask]
-    s_lshl_b32 s91, %%[state], 4
-    s_add_u32 s91, s91, s90
-    v_mad_u32_u24 v47, %%[state], %%[vhms], %%[vhc]
-    v_mad_u32_u24 v47, s91, %%[vhm2], v47
-    ds_read_u16 v40, v47
-    s_mov_b32 s97, 0
-    s_cmp_lg_u32 s94, 0
-    s_cbranch_scc1 %s
-    s_mov_b32 s97, 1
-    """ % (L("x0"), L("x0"), L("nopf")))
-    literal_context()  # speculative: prevByte is known (no copy pending)
-    label("nopf")
-    emit("s_waitcnt lgkmcnt(0)")
+    s_waitcnt lgkmcnt(0)
+    """ % (L("x0"), L("x0")))
     hbit(H_IS_MATCH)
     emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L("match"))
     # ------------------------------------------------------------- literal (decompress.go:44-175)
@@ -329,7 +334,29 @@ def gen():
     label("litready")
     emit("s_cmp_ge_u32 %%[state], 7\ns_cbranch_scc1 %s\nv_mov_b32 v58, s92" % L("mlit"))
     walk(8, ["v50", "v51", "v52", "v53"])
+    # tail of a plain literal: window.PutByte (:168), state (:171), then the next packet's head
+    # gather, this literal's model update, and the next packet's literal blocks (which may be
+    # the very table just updated, hence after the update's store)
+    emit("""
+    s_and_b32 %[prev], s88, 0xff
+    v_mov_b32 v60, %[prev]
+    v_mov_b32 v61, %[pos]
+    global_store_byte v61, v60, %[outp]
+    s_add_u32 %[pos], %[pos], 1
+    """)
+    wpos_advance("1")
+    emit("""
+    s_cmp_lt_u32 %[state], 10
+    s_cselect_b32 s80, 3, 6
+    s_sub_u32 s80, %[state], s80
+    s_cmp_lt_u32 %[state], 4
+    s_cselect_b32 %[state], 0, s80
+    """)
+    head_issue()
     tree_update(8)
+    literal_context()
+    emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
+    # tail of a matched literal (its model updates were immediate)
     label("litdone")
     emit("""
     s_and_b32 %[prev], s88, 0xff
@@ -340,13 +367,15 @@ def gen():
     """)
     wpos_advance("1")
     emit("""
-    s_cmp_lt_u32 %%[state], 10
+    s_cmp_lt_u32 %[state], 10
     s_cselect_b32 s80, 3, 6
-    s_sub_u32 s80, %%[state], s80
-    s_cmp_lt_u32 %%[state], 4
-    s_cselect_b32 %%[state], 0, s80
-    s_branch %s
-    """ % L("pkt"))
+    s_sub_u32 s80, %[state], s80
+    s_cmp_lt_u32 %[state], 4
+    s_cselect_b32 %[state], 0, s80
+    """)
+    head_issue()
+    literal_context()
+    emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
     # ------------------------------------------------------------- matched literal (:59-114)
     label("mlit")
     emit("s_mov_b32 s88, 1\ns_mov_b32 s89, %[mb]")
@@ -544,7 +573,8 @@ def gen():
     s_add_u32 %[pos], %[pos], s89
     """)
     wpos_advance("s89")
-    emit("s_branch %s" % L("pkt"))
+    head_issue()  # next packet's head gather; its literal blocks wait for the copy (prevByte)
+    emit("s_mov_b32 s97, 0\ns_branch %s" % L("pkt"))
     # ------------------------------------------------------------- exits
     label("x3")
     emit("s_mov_b32 %%[lenout], s89\ns_mov_b32 %%[exitc], 3\ns_branch %s" % L("fin"))
@@ -556,7 +586,7 @@ def gen():
     emit("s_mov_b32 %[exitc], 0")
     label("fin")
     need_copy_done()
-    emit("s_branch %s" % L("end"))
+    emit("s_waitcnt lgkmcnt(0)\ns_branch %s" % L("end"))
     emit_stubs()
     emit_finish_blocks()
     label("end")
