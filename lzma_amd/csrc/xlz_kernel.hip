@@ -15,7 +15,7 @@
 //
 // Two decoders of one packet exist (lzma_packet_checked / lzma_packet_fast).
 // The fast one is hand-scheduled GCN assembly and assumes what lzma_run has
-// verified for it: >= 32 input bytes, >= 288 bytes of output room and bytesLeft.
+// verified for it: >= 32 input bytes, >= 336 bytes of output room and bytesLeft.
 // The checked one is plain C++ with every end-of-input / capacity test of the
 // reference and runs only within a few bytes of a stream's or chunk's end.
 //
@@ -53,7 +53,8 @@ constexpr uint32_t kMatchMinLen = 2;            // types.go:24
 
 constexpr uint32_t kInWindow = 256;   // bytes of compressed input held in one VGPR (64 lanes x 4)
 constexpr uint32_t kFastInput = 32;   // >= lzmaRequiredInputMax = 20 (types.go:38), with slack
-constexpr uint32_t kFastOutput = 288; // >= maxMatchLen = 273 (types.go:46)
+constexpr uint32_t kFastOutput = 336; // >= maxMatchLen 273 (types.go:46) + 63: the fast path's copies store whole
+                                      // 64-lane rows and must stay inside the unit's own output range
 
 enum : int { RUN_END = 0, RUN_INPUT_EOF = 1, RUN_ERR_RESULT = 2, RUN_OUT_CAP = 3, RUN_CONTINUE = 4 };
 

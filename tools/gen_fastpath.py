@@ -8,7 +8,7 @@ hand invites typos; this script is the source, the .inc file is committed next t
 
 The loop decodes whole packets (decompress.go:13 ff.) while
     arel <= arel_lim   (>= 32 readable bytes left in the 256-byte input window)
-    pos  <  pos_lim    (>= 288 bytes of output room and of bytesLeft)
+    pos  <  pos_lim    (>= 336 bytes of output room and of bytesLeft)
 and leaves with an exit code:
     0  a limit was reached at a packet boundary (caller refills the window / re-checks)
     1  ErrResultError condition (bad distance, rep match on an empty window)
