@@ -44,8 +44,8 @@ enum {
     XLZ_ERR_OUT_CAP = -6,        /* new: out_cap smaller than the decoded size; out_len==out_cap */
     XLZ_ERR_BAD_ARG = -7,        /* new: NULL pointer / unknown format                           */
     XLZ_ERR_DEVICE = -8,         /* new: HIP runtime failure or no gfx950 device                 */
-    XLZ_ERR_UNSUPPORTED = -9,    /* new: stream outside what the GPU path implements (listed in
-                                    DESIGN.md: >= 4 GiB per stream, lc+lp > 6)                  */
+    XLZ_ERR_UNSUPPORTED = -9,    /* new: stream outside what the GPU path implements (DESIGN.md
+                                    section 5: >= 4 GiB of input or output per stream)          */
     XLZ_ERR_CLOSED = -10,        /* errAlreadyClosed (readcloser.go:14)                          */
     XLZ_ERR_NEED_ONE_READER = -11, /* errNeedOneReader (reader1.go:26)                           */
     XLZ_ERR_INSUFFICIENT_PROPS = -12 /* errInsufficientProperties (reader2.go:43)                */

@@ -36,6 +36,8 @@ static inline constexpr uint32_t num_probs(uint32_t lc_plus_lp) { return P_LIT +
 
 constexpr uint32_t kMaxLdsBytes = 160u * 1024u; // MI355X LDS per CU
 constexpr uint32_t kWave = 64;
+constexpr uint32_t kMaxLcLpLds = 6;  // 0x300 << 6 probs = 98 KiB still fits one CU's LDS
+constexpr uint32_t kMaxLcLp = 12;    // reference limit: lc <= 8, lp <= 4 (reader1.go:210-221)
 
 // ---- unit of work: one LZMA1 stream, or one run of LZMA2 chunks ------------
 enum : uint32_t {
@@ -45,7 +47,8 @@ enum : uint32_t {
 
 enum : uint32_t {
     UNIT_F_LAST = 1,        // the parent stream's input ends with this unit
-    UNIT_F_HAVE_READER = 2  // not the stream's first unit: Reader2.lzmaReader already exists
+    UNIT_F_HAVE_READER = 2, // not the stream's first unit: Reader2.lzmaReader already exists
+    UNIT_F_BIG_MODEL = 4    // model does not fit LDS: decoded by the HBM-model launch
 };
 
 struct Unit {
@@ -93,11 +96,18 @@ struct LaunchParams {
     UnitResult *results;
     uint32_t *queue;       // one zeroed word per launch
     uint32_t n_units;
-    uint32_t max_lc_lp;    // sizes the dynamic LDS
+    uint32_t max_lc_lp;    // sizes the model: dynamic LDS, or one scratch slot per workgroup
+    // "big model" launch (lc+lp too large for 160 KiB of LDS; the reference allows lc<=8, lp<=4):
+    // the model lives in HBM, one slot of scratch_stride probs per workgroup, and only the
+    // plain C++ packet decoder runs.  nullptr for the normal LDS launch.
+    uint16_t *scratch;
+    uint32_t scratch_stride;
+    uint32_t order_base;   // first entry of `order` this launch works on
 };
 
 // implemented in xlz_kernel.hip
 int launch_decode(const LaunchParams &p, int num_cus, void *stream /* hipStream_t */);
 uint32_t decode_lds_bytes(uint32_t max_lc_lp);
+uint32_t big_model_grid(int num_cus);
 
 } // namespace xlz

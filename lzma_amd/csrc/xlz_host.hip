@@ -81,7 +81,11 @@ struct xlz_batch {
     uint32_t *d_order = nullptr;
     UnitResult *d_results = nullptr;
     size_t in_bytes = 0, out_bytes = 0;
-    uint32_t max_lc_lp = 0;
+    uint32_t max_lc_lp = 0;     // over the units whose model fits LDS
+    uint32_t max_lc_lp_big = 0; // over the units decoded with an HBM-resident model
+    uint32_t n_normal = 0;      // order[0, n_normal) = LDS units, the rest = big-model units
+    uint16_t *d_scratch = nullptr;
+    uint32_t scratch_stride = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ran = false;
     uint64_t algo_in = 0; // compressed payload bytes handed to the device
@@ -338,6 +342,7 @@ int batch_free(xlz_batch *b)
     if (b->d_units) (void)hipFree(b->d_units);
     if (b->d_order) (void)hipFree(b->d_order);
     if (b->d_results) (void)hipFree(b->d_results);
+    if (b->d_scratch) (void)hipFree(b->d_scratch);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     delete b;
@@ -392,11 +397,11 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
             std::vector<Lz2Unit> lu;
             uint32_t mx = 0;
             scan_lzma2(s.in, s.in_len, lu, mx);
-            if (decode_lds_bytes(mx) > kMaxLdsBytes) {
-                pl.host_status = XLZ_ERR_UNSUPPORTED;
-                continue;
-            }
-            b->max_lc_lp = std::max(b->max_lc_lp, mx);
+            const bool big = mx > kMaxLcLpLds; // model too large for LDS: HBM-model launch
+            if (big)
+                b->max_lc_lp_big = std::max(b->max_lc_lp_big, mx);
+            else
+                b->max_lc_lp = std::max(b->max_lc_lp, mx);
             pl.lzma2 = true;
             pl.in_off = in_cursor;
             pl.in_len = (uint32_t)s.in_len;
@@ -415,7 +420,7 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
                 v.out_cap = (uint32_t)(last ? room : std::min<uint64_t>(room, lu[k].expect_out));
                 v.expect_out = (uint32_t)lu[k].expect_out;
                 v.stream = (uint32_t)i;
-                v.flags = (last ? UNIT_F_LAST : 0u) | (k ? UNIT_F_HAVE_READER : 0u);
+                v.flags = (last ? UNIT_F_LAST : 0u) | (k ? UNIT_F_HAVE_READER : 0u) | (big ? UNIT_F_BIG_MODEL : 0u);
                 b->units.push_back(v);
                 unit_src_off.push_back(lu[k].in_start);
             }
@@ -431,24 +436,27 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
             cap = u.unpack_size; // a defined size bounds the output (decompress.go:657-662)
         // 32-bit byte counters on the device: a defined size must fit them
         const bool size_too_big = u.unpack_size != kUnknownSize && u.unpack_size > kMaxUnitBytes;
-        if (payload > kMaxUnitBytes || cap > kMaxUnitBytes || size_too_big ||
-            decode_lds_bytes((uint32_t)u.lc + u.lp) > kMaxLdsBytes) {
+        if (payload > kMaxUnitBytes || cap > kMaxUnitBytes || size_too_big) {
             pl.host_status = XLZ_ERR_UNSUPPORTED;
             continue;
         }
+        const bool big = (uint32_t)u.lc + u.lp > kMaxLcLpLds;
         u.in_off = in_cursor;
         u.in_len = (uint32_t)payload;
         u.out_off = out_cursor;
         u.out_cap = (uint32_t)cap;
         u.stream = (uint32_t)i;
-        u.flags = UNIT_F_LAST;
+        u.flags = UNIT_F_LAST | (big ? UNIT_F_BIG_MODEL : 0u);
         pl.first_unit = (uint32_t)b->units.size();
         pl.n_units = 1;
         pl.out_off = out_cursor;
         pl.out_cap = cap;
         b->units.push_back(u);
         unit_src_off.push_back(pl.header_len);
-        b->max_lc_lp = std::max(b->max_lc_lp, (uint32_t)u.lc + u.lp);
+        if (big)
+            b->max_lc_lp_big = std::max(b->max_lc_lp_big, (uint32_t)u.lc + u.lp);
+        else
+            b->max_lc_lp = std::max(b->max_lc_lp, (uint32_t)u.lc + u.lp);
         b->algo_in += payload;
         in_cursor += align_up(payload + 16, kArenaAlign);
         out_cursor += align_up((size_t)cap + kOutTailPad, kArenaAlign);
@@ -460,8 +468,13 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     // binary decisions, which tracks compressed size)
     b->order.resize(b->units.size());
     std::iota(b->order.begin(), b->order.end(), 0u);
-    std::stable_sort(b->order.begin(), b->order.end(),
-                     [&](uint32_t a, uint32_t c) { return b->units[a].in_len > b->units[c].in_len; });
+    std::stable_sort(b->order.begin(), b->order.end(), [&](uint32_t a, uint32_t c) {
+        const bool ba = b->units[a].flags & UNIT_F_BIG_MODEL, bc = b->units[c].flags & UNIT_F_BIG_MODEL;
+        if (ba != bc) return !ba; // LDS-model units first
+        return b->units[a].in_len > b->units[c].in_len;
+    });
+    for (uint32_t idx : b->order)
+        if (!(b->units[idx].flags & UNIT_F_BIG_MODEL)) b->n_normal++;
 
     // ---- device memory + upload ----------------------------------------
     const size_t nu = b->units.size();
@@ -478,6 +491,12 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     }
     if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess)
         return fail(XLZ_ERR_DEVICE);
+    if (b->n_normal < nu) { // some models live in HBM: one scratch slot per workgroup of that launch
+        b->scratch_stride = num_probs(b->max_lc_lp_big);
+        if (hipMalloc(&b->d_scratch, (size_t)big_model_grid(ctx->num_cus) * b->scratch_stride * sizeof(uint16_t)) !=
+            hipSuccess)
+            return fail(XLZ_ERR_DEVICE);
+    }
     {
         // pack the payloads into one staging image, then a single H2D copy
         uint8_t *stage = nullptr;
@@ -508,16 +527,29 @@ extern "C" int xlz_batch_run(xlz_batch *b)
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
     HIP_TRY(hipEventRecord(b->ev0, ctx->stream));
-    if (!b->units.empty()) {
-        LaunchParams p;
-        p.in_arena = b->d_in;
-        p.out_arena = b->d_out;
-        p.units = b->d_units;
-        p.order = b->d_order;
-        p.results = b->d_results;
-        p.queue = ctx->queue;
-        p.n_units = (uint32_t)b->units.size();
+    const uint32_t nu = (uint32_t)b->units.size();
+    LaunchParams p;
+    p.in_arena = b->d_in;
+    p.out_arena = b->d_out;
+    p.units = b->d_units;
+    p.order = b->d_order;
+    p.results = b->d_results;
+    p.queue = ctx->queue;
+    if (b->n_normal) { // models in LDS
+        p.n_units = b->n_normal;
         p.max_lc_lp = b->max_lc_lp;
+        p.scratch = nullptr;
+        p.scratch_stride = 0;
+        p.order_base = 0;
+        if (launch_decode(p, ctx->num_cus, ctx->stream) != 0) return XLZ_ERR_DEVICE;
+    }
+    if (nu > b->n_normal) { // models in HBM (lc+lp > 6)
+        HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
+        p.n_units = nu - b->n_normal;
+        p.max_lc_lp = b->max_lc_lp_big;
+        p.scratch = b->d_scratch;
+        p.scratch_stride = b->scratch_stride;
+        p.order_base = b->n_normal;
         if (launch_decode(p, ctx->num_cus, ctx->stream) != 0) return XLZ_ERR_DEVICE;
     }
     HIP_TRY(hipEventRecord(b->ev1, ctx->stream));
@@ -546,7 +578,7 @@ extern "C" int xlz_batch_last_kernel_ms(xlz_batch *b, float *ms)
 namespace {
 
 // Launch `units` (already laid out against the batch's arenas) and fetch their results.
-int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResult> &res)
+int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResult> &res, bool big)
 {
     xlz_ctx *ctx = b->ctx;
     const size_t n = units.size();
@@ -571,7 +603,10 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
         p.results = d_res;
         p.queue = ctx->queue;
         p.n_units = (uint32_t)n;
-        p.max_lc_lp = b->max_lc_lp;
+        p.max_lc_lp = big ? b->max_lc_lp_big : b->max_lc_lp;
+        p.scratch = big ? b->d_scratch : nullptr;
+        p.scratch_stride = big ? b->scratch_stride : 0;
+        p.order_base = 0;
         if (launch_decode(p, ctx->num_cus, ctx->stream) == 0 && hipStreamSynchronize(ctx->stream) == hipSuccess &&
             hipMemcpy(res.data(), d_res, n * sizeof(UnitResult), hipMemcpyDeviceToHost) == hipSuccess)
             st = XLZ_OK;
@@ -639,9 +674,13 @@ int collect(xlz_batch *b)
             }
         }
     }
-    if (!redo.empty()) {
+    for (int pass = 0; pass < 2 && !redo.empty(); pass++) {
+        const bool big = pass == 1;
         std::vector<Unit> units;
+        std::vector<size_t> idx;
         for (size_t i : redo) {
+            if (((b->units[b->plans[i].first_unit].flags & UNIT_F_BIG_MODEL) != 0) != big) continue;
+            idx.push_back(i);
             const StreamPlan &pl = b->plans[i];
             Unit u;
             memset(&u, 0, sizeof u);
@@ -653,14 +692,15 @@ int collect(xlz_batch *b)
             u.dict_size = pl.dict_size;
             u.unpack_size = kUnknownSize;
             u.stream = (uint32_t)i;
-            u.flags = UNIT_F_LAST;
+            u.flags = UNIT_F_LAST | (big ? UNIT_F_BIG_MODEL : 0u);
             units.push_back(u);
         }
+        if (units.empty()) continue;
         std::vector<UnitResult> res;
-        int st = run_units(b, units, res);
+        int st = run_units(b, units, res, big);
         if (st != XLZ_OK) return st;
-        for (size_t k = 0; k < redo.size(); k++) {
-            xlz_result &r = b->final_results[redo[k]];
+        for (size_t k = 0; k < idx.size(); k++) {
+            xlz_result &r = b->final_results[idx[k]];
             r.status = res[k].status;
             r.out_len = res[k].out_len;
             r.in_consumed = res[k].in_consumed;

@@ -521,7 +521,7 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint32_
 
 // (*Reader1).decompress run to the end of the current LZMA chunk (decompress.go:8-1136)
 __device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint8_t *__restrict__ out, uint32_t lane,
-                                        const HeadVec &hv)
+                                        const HeadVec &hv, bool allow_fast)
 {
     for (;;) {
         // decompress.go:14-20
@@ -529,7 +529,7 @@ __device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint8_t *__rest
         // keep kFastInput bytes of window ahead of the packet
         if (d.arel > kInWindow - kFastInput) in_window(d, in_pos(d), lane);
         const uint32_t in_left = d.aend - in_pos(d);
-        const bool fast = in_left >= kFastInput && (d.out_cap - d.pos) >= kFastOutput &&
+        const bool fast = allow_fast && in_left >= kFastInput && (d.out_cap - d.pos) >= kFastOutput &&
                           (!d.size_defined || d.bytes_left >= kFastOutput);
         if (!fast) {
             const int r = lzma_packet_checked(d, probs, out, lane);
@@ -719,11 +719,15 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
     }
 }
 
-__global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
+// BIG = false: the model is this workgroup's LDS (the asm fast loop addresses it from LDS offset
+// 0).  BIG = true (lc+lp > 6): the model is a slot of HBM scratch and only the checked C++
+// packet decoder runs -- slow, but the reference's whole parameter range decodes.
+template <bool BIG>
+__device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *probs)
 {
-    extern __shared__ __attribute__((aligned(16))) uint16_t probs[];
     const uint32_t lane = threadIdx.x;
     const HeadVec hv = head_vectors(lane);
+    constexpr bool big = BIG;
 
     for (;;) {
         // dequeue: lane 0 bumps the head; lanes 1..63 add 0 to pad words of the same
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
         const uint32_t q = RFL(atomicAdd(p.queue + lane, lane == 0 ? 1u : 0u));
         if (q >= p.n_units) break; // every wave reaches this once the queue is drained
 
-        const uint32_t ui = RFL(p.order[q]);
+        const uint32_t ui = RFL(p.order[p.order_base + q]);
         const Unit *up = p.units + ui;
         Dec d;
         Walk w;
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
                 status = ST_ERR_RC_INIT;
                 break;
             }
-            const int r = lzma_run(d, probs, out, lane, hv);
+            const int r = lzma_run(d, probs, out, lane, hv, !big);
             status = r == RUN_END ? ST_OK
                                   : r == RUN_INPUT_EOF ? ST_OK_INPUT_EOF
                                                        : r == RUN_OUT_CAP ? ST_ERR_OUT_CAP : ST_ERR_RESULT;
@@ -807,10 +811,30 @@ __global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
     }
 }
 
+__global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds_probs[];
+    decode_units<false>(p, lds_probs);
+}
+
+__global__ __launch_bounds__(64) void xlz_decode_kernel_hbm_model(LaunchParams p)
+{
+    decode_units<true>(p, p.scratch + (size_t)blockIdx.x * p.scratch_stride);
+}
+
 uint32_t decode_lds_bytes(uint32_t max_lc_lp) { return num_probs(max_lc_lp) * 2u + 128u; }
+
+uint32_t big_model_grid(int num_cus) { return (uint32_t)num_cus; } // one workgroup per CU
 
 int launch_decode(const LaunchParams &p, int num_cus, void *stream)
 {
+    if (p.scratch) { // HBM-resident model
+        uint32_t grid = big_model_grid(num_cus);
+        if (grid > p.n_units) grid = p.n_units;
+        if (grid == 0) return 0;
+        hipLaunchKernelGGL(xlz_decode_kernel_hbm_model, dim3(grid), dim3(kWave), 0, (hipStream_t)stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     const uint32_t lds = decode_lds_bytes(p.max_lc_lp);
     if (lds > kMaxLdsBytes) return -1;
     uint32_t per_cu = kMaxLdsBytes / lds;

@@ -323,3 +323,46 @@ def test_multi_device_driver_on_gpu(ctx):
     streams = [Stream(corpus.compress_alone(p), out_cap=len(p)) for p in ps]
     res = multigpu.decode_batch_multi(streams, [0, 0])   # two host threads, two contexts, one GPU
     assert [r[0] for r in res] == ps and all(r[1] == 0 for r in res)
+
+
+# ------------------------------------------------ models too large for LDS (lc+lp > 6) ----
+def test_large_lc_lp_models_live_in_hbm(ctx):
+    """The reference accepts lc <= 8, lp <= 4 (reader1.go:210-221): up to 0x300 << 12 probs.
+    liblzma refuses to ENCODE lc+lp > 4, so these streams are ordinary payloads relabelled with
+    a large-model props byte: the decode is garbage, but deterministic garbage, and it must
+    equal the oracle's byte for byte (both walk the same 12-bit literal contexts)."""
+    import random
+    rnd = random.Random(5)
+    blobs = []
+    for i, (lc, lp, pb) in enumerate([(8, 4, 2), (7, 0, 0), (8, 0, 4), (4, 4, 1), (3, 4, 2), (6, 1, 0)]):
+        p = corpus.plain("TRMZ"[i % 4], 1100 + i, 30_000)
+        c = bytearray(corpus.compress_alone(p))
+        c[0] = corpus.props_byte(lc, lp, pb)
+        if i % 2:
+            c[5:13] = struct.pack("<Q", 20_000)   # defined size
+        blobs.append(bytes(c))
+    # plus pure noise payloads
+    for i in range(4):
+        hdr = bytes([corpus.props_byte(8, 4, 4)]) + struct.pack("<IQ", 1 << 16, 50_000)
+        blobs.append(hdr + b"\x00" + bytes(rnd.randrange(256) for _ in range(4000)))
+    # an all-zero payload decodes to a long run of literals in every parameter set (Code stays 0)
+    for lc, lp, pb in [(8, 4, 4), (7, 2, 0), (3, 0, 2)]:
+        blobs.append(bytes([corpus.props_byte(lc, lp, pb)]) + struct.pack("<IQ", 1 << 16, 0xFFFFFFFFFFFFFFFF) +
+                     bytes(3000))
+    got = _check_against_oracle(ctx, blobs, [60_000] * len(blobs))
+    assert any(len(g[0]) > 10_000 for g in got)
+    # mixed batch: LDS-model and HBM-model streams together
+    p = corpus.plain("T", 1200, 40_000)
+    mixed = [corpus.compress_alone(p), blobs[0], corpus.compress_alone(p, lc=2, lp=2, pb=0), blobs[7]]
+    _check_against_oracle(ctx, mixed, [60_000] * 4)
+
+
+def test_lzma2_many_small_units_share_one_output_range(ctx):
+    # hundreds of tiny dictionary-reset units packed back to back in ONE output range: a copy
+    # that stored past its unit's end would corrupt the neighbour (64-lane rows, DESIGN.md 3)
+    segs = [corpus.plain("ZTZM"[i % 4], 1300 + i, 700 + 37 * (i % 23)) for i in range(600)]
+    blob = corpus.lzma2_concat(segs, dict_size=1 << 16, preset=1)
+    want = b"".join(segs)
+    for _ in range(3):
+        got = _check_lzma2(ctx, [blob], [1 << 16], [len(want)])
+        assert got[0][0] == want
