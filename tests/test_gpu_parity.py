@@ -366,3 +366,24 @@ def test_lzma2_many_small_units_share_one_output_range(ctx):
     for _ in range(3):
         got = _check_lzma2(ctx, [blob], [1 << 16], [len(want)])
         assert got[0][0] == want
+
+
+# ------------------------------------------- BASELINE-sized batches: size-independent properties ----
+def test_baseline_shape_roundtrip_and_idempotence(ctx):
+    """4096 streams (the stream count of BASELINE config 2; 64 KiB each so the corpus builds in
+    seconds): decode(compress(x)) == x for every stream by SHA-256, a second run of the same
+    device-resident batch gives identical bytes (idempotence), and the batch's byte accounting
+    adds up (sum of out_len == sum of plaintext sizes, in_consumed == payload sizes)."""
+    n, size = 4096, 65536
+    comp, digests = corpus.make_alone_batch("M", n, size, base_seed=7000, preset=1)
+    b = lzma_amd.Batch(ctx, [Stream(c, FMT_LZMA_ALONE, out_cap=size) for c in comp])
+    b.run()
+    res = b.results()
+    assert all(r[1] == 0 and r[0] == size for r in res)
+    first = [hashlib.sha256(b.download(i, size)).digest() for i in range(n)]
+    assert first == digests
+    b.run()
+    assert [hashlib.sha256(b.download(i, size)).digest() for i in range(0, n, 7)] == first[::7]
+    cin, cout, units = b.stats()
+    assert cout == n * size and units == n and cin == sum(len(c) - 13 for c in comp)
+    b.close()
