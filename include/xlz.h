@@ -101,6 +101,14 @@ int xlz_ctx_device(const xlz_ctx *ctx);
 int xlz_ctx_event_record(xlz_ctx *ctx, int slot);
 int xlz_ctx_event_elapsed_ms(xlz_ctx *ctx, int slot_a, int slot_b, float *ms);
 
+/* Coalescing of pull-style readers.  The reference's readers are
+ * independent single-goroutine objects; many goroutines each doing io.Copy(dst, NewReader1(src))
+ * would each occupy one wave of the GPU.  After this call, every reader created on `ctx` hands
+ * its stream to a background thread that waits up to `window_us` for more readers (at most
+ * `max_streams`) and decodes them as ONE batch; xlz_reader_read blocks until its stream is done. */
+int xlz_ctx_enable_batching(xlz_ctx *ctx, uint32_t window_us, uint32_t max_streams);
+int xlz_ctx_batching_stats(xlz_ctx *ctx, uint64_t *batches, uint64_t *streams);
+
 /* ---- one-shot batch decode: host buffers in, host buffers out -------------- */
 /* Replaces a loop of `r, _ := NewReader1(src); io.Copy(dst, r)` over n independent
  * streams (reader1_test.go:76-80).  One bad stream never fails the batch: the return

@@ -63,6 +63,19 @@ class Context:
         if st != OK:
             raise LzmaError(st, "xlz_ctx_create(device=%d)" % device)
 
+    def enable_batching(self, window_us=500, max_streams=4096):
+        """Readers created on this context from now on are decoded together (xlz_ctx_enable_batching)."""
+        st = N.lib().xlz_ctx_enable_batching(self._h, window_us, max_streams)
+        if st != OK:
+            raise LzmaError(st, "xlz_ctx_enable_batching")
+
+    def batching_stats(self):
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        st = N.lib().xlz_ctx_batching_stats(self._h, ctypes.byref(a), ctypes.byref(b))
+        if st != OK:
+            raise LzmaError(st, "xlz_ctx_batching_stats")
+        return a.value, b.value
+
     def event_record(self, slot):
         st = N.lib().xlz_ctx_event_record(self._h, slot)
         if st != OK:

@@ -36,7 +36,8 @@ UNKNOWN_SIZE = 0xFFFFFFFFFFFFFFFF
 EXPORTS = [
     "xlz_version", "xlz_strerror", "xlz_device_count", "xlz_decode_prop", "xlz_decode_dict_size",
     "xlz_decode_dict_size2", "xlz_decode_unpack_size", "xlz_ctx_create", "xlz_ctx_destroy",
-    "xlz_ctx_device", "xlz_ctx_event_record", "xlz_ctx_event_elapsed_ms", "xlz_decode_batch", "xlz_batch_create", "xlz_batch_run", "xlz_batch_sync",
+    "xlz_ctx_device", "xlz_ctx_event_record", "xlz_ctx_event_elapsed_ms", "xlz_ctx_enable_batching",
+    "xlz_ctx_batching_stats", "xlz_decode_batch", "xlz_batch_create", "xlz_batch_run", "xlz_batch_sync",
     "xlz_batch_results", "xlz_batch_download", "xlz_batch_device_output", "xlz_batch_last_kernel_ms",
     "xlz_batch_stats", "xlz_batch_destroy", "xlz_new_reader1", "xlz_new_reader2",
     "xlz_new_lzma_decompressor_for_sevenzip", "xlz_new_lzma2_decompressor_for_sevenzip",
@@ -96,6 +97,8 @@ def lib():
     L.xlz_ctx_destroy.argtypes = [vp]
     L.xlz_ctx_destroy.restype = None
     L.xlz_ctx_device.argtypes = [vp]
+    L.xlz_ctx_enable_batching.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32]
+    L.xlz_ctx_batching_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     L.xlz_ctx_event_record.argtypes = [vp, i32]
     L.xlz_ctx_event_elapsed_ms.argtypes = [vp, i32, i32, ctypes.POINTER(ctypes.c_float)]
     L.xlz_decode_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), sz, ctypes.POINTER(Result)]

@@ -10,7 +10,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <deque>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -46,7 +50,12 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 } // namespace
 
+struct xlz_reader;
+struct Batcher;
+static void batcher_shutdown(Batcher *bt); // defined next to the readers
+
 struct xlz_ctx {
+    Batcher *batcher = nullptr; // coalesces pull-style readers into batches (xlz_ctx_enable_batching)
     int device = 0;
     int num_cus = 0;
     hipStream_t stream = nullptr;
@@ -187,6 +196,7 @@ extern "C" int xlz_ctx_create(int device, xlz_ctx **out)
 extern "C" void xlz_ctx_destroy(xlz_ctx *c)
 {
     if (!c) return;
+    if (c->batcher) batcher_shutdown(c->batcher);
     (void)hipSetDevice(c->device);
     if (c->queue) (void)hipFree(c->queue);
     for (hipEvent_t e : c->ev)
@@ -793,6 +803,23 @@ struct xlz_reader {
     bool closed = false;
     bool is_closer = false; // built by a *ForSevenZip constructor: wraps errors like readCloser
     int32_t status = XLZ_OK;
+    // batching: the stream is queued at construction and decoded by the context's batcher thread
+    bool queued = false;
+    int call_status = XLZ_OK;
+    uint64_t cap = 0;
+    bool cap_known = false;
+};
+
+// Background coalescer of readers (one per context).
+struct Batcher {
+    xlz_ctx *ctx = nullptr;
+    uint32_t window_us = 500, max_streams = 4096;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<xlz_reader *> pending;
+    bool stop = false;
+    uint64_t n_batches = 0, n_streams = 0;
+    std::thread th;
 };
 
 namespace {
@@ -816,40 +843,112 @@ int check_rc_init(const uint8_t *p, size_t n)
     return XLZ_OK;
 }
 
-int reader_decode(xlz_reader *r)
+void reader_initial_cap(xlz_reader *r)
 {
-    if (r->decoded) return XLZ_OK;
     // Output size: the header's, or a guess that is grown until it fits.
-    uint64_t cap;
-    bool known = false;
+    r->cap_known = false;
     if (r->desc.format == XLZ_FMT_LZMA_ALONE) {
         uint64_t u = xlz_decode_unpack_size(r->in.data() + 5);
         if (u != kUnknownSize) {
-            known = true;
-            cap = u;
+            r->cap_known = true;
+            r->cap = u;
         }
     } else if (r->desc.format == XLZ_FMT_LZMA_RAW && r->desc.unpack_size != kUnknownSize) {
-        known = true;
-        cap = r->desc.unpack_size;
+        r->cap_known = true;
+        r->cap = r->desc.unpack_size;
     }
-    if (!known) cap = std::max<uint64_t>(1u << 16, (uint64_t)r->in.size() * 6);
-    if (cap > kMaxUnitBytes) cap = kMaxUnitBytes;
+    if (!r->cap_known) r->cap = std::max<uint64_t>(1u << 16, (uint64_t)r->in.size() * 6);
+    if (r->cap > kMaxUnitBytes) r->cap = kMaxUnitBytes;
+}
+
+void reader_fill_desc(xlz_reader *r)
+{
+    r->out.resize((size_t)r->cap);
+    r->desc.in = r->in.data();
+    r->desc.in_len = r->in.size();
+    r->desc.out = r->out.data();
+    r->desc.out_cap = r->out.size();
+}
+
+// true: finished; false: the guessed capacity was too small, try again with a larger one
+bool reader_take_result(xlz_reader *r, const xlz_result &res)
+{
+    if (res.status == XLZ_ERR_OUT_CAP && !r->cap_known && r->cap < kMaxUnitBytes) {
+        r->cap = std::min<uint64_t>(r->cap * 4, kMaxUnitBytes);
+        return false;
+    }
+    r->status = res.status;
+    r->out.resize((size_t)res.out_len);
+    return true;
+}
+
+void batcher_loop(Batcher *bt)
+{
+    std::unique_lock<std::mutex> lk(bt->mu);
     for (;;) {
-        r->out.resize((size_t)cap);
-        r->desc.in = r->in.data();
-        r->desc.in_len = r->in.size();
-        r->desc.out = r->out.data();
-        r->desc.out_cap = r->out.size();
+        bt->cv_work.wait(lk, [&] { return bt->stop || !bt->pending.empty(); });
+        if (bt->stop && bt->pending.empty()) return;
+        // give concurrent constructors a moment to join this batch
+        bt->cv_work.wait_for(lk, std::chrono::microseconds(bt->window_us),
+                             [&] { return bt->stop || bt->pending.size() >= bt->max_streams; });
+        std::vector<xlz_reader *> work;
+        while (!bt->pending.empty() && work.size() < bt->max_streams) {
+            work.push_back(bt->pending.front());
+            bt->pending.pop_front();
+        }
+        lk.unlock();
+        std::vector<xlz_stream_desc> descs(work.size());
+        std::vector<xlz_result> res(work.size());
+        for (size_t i = 0; i < work.size(); i++) {
+            reader_fill_desc(work[i]);
+            descs[i] = work[i]->desc;
+        }
+        const int st = xlz_decode_batch(bt->ctx, descs.data(), descs.size(), res.data());
+        lk.lock();
+        bt->n_batches++;
+        bt->n_streams += work.size();
+        for (size_t i = 0; i < work.size(); i++) {
+            xlz_reader *r = work[i];
+            if (st != XLZ_OK) {
+                r->call_status = st;
+                r->decoded = true;
+            } else if (reader_take_result(r, res[i])) {
+                r->decoded = true;
+            } else {
+                bt->pending.push_back(r); // larger output buffer next round
+            }
+        }
+        bt->cv_done.notify_all();
+    }
+}
+
+void reader_enqueue(xlz_reader *r)
+{
+    Batcher *bt = r->ctx->batcher;
+    if (!bt) return;
+    reader_initial_cap(r);
+    std::lock_guard<std::mutex> lk(bt->mu);
+    r->queued = true;
+    bt->pending.push_back(r);
+    bt->cv_work.notify_one();
+}
+
+int reader_decode(xlz_reader *r)
+{
+    if (r->queued) { // the batcher thread decodes it together with its contemporaries
+        Batcher *bt = r->ctx->batcher;
+        std::unique_lock<std::mutex> lk(bt->mu);
+        bt->cv_done.wait(lk, [&] { return r->decoded; });
+        return r->call_status;
+    }
+    if (r->decoded) return XLZ_OK;
+    reader_initial_cap(r);
+    for (;;) {
+        reader_fill_desc(r);
         xlz_result res;
         int st = xlz_decode_batch(r->ctx, &r->desc, 1, &res);
         if (st != XLZ_OK) return st;
-        if (res.status == XLZ_ERR_OUT_CAP && !known && cap < kMaxUnitBytes) {
-            cap = std::min<uint64_t>(cap * 4, kMaxUnitBytes);
-            continue;
-        }
-        r->status = res.status;
-        r->out.resize((size_t)res.out_len);
-        break;
+        if (reader_take_result(r, res)) break;
     }
     r->decoded = true;
     return XLZ_OK;
@@ -874,8 +973,10 @@ extern "C" xlz_reader *xlz_new_reader1(xlz_ctx *ctx, const uint8_t *in, size_t i
         r = reader_new(ctx, in, in_len);
         if (!r)
             e = XLZ_ERR_BAD_ARG;
-        else
+        else {
             r->desc.format = XLZ_FMT_LZMA_ALONE;
+            reader_enqueue(r);
+        }
     }
     if (err) *err = e;
     return r;
@@ -916,6 +1017,7 @@ extern "C" xlz_reader *xlz_new_reader2(xlz_ctx *ctx, const uint8_t *in, size_t i
             } else {
                 r->desc.format = XLZ_FMT_LZMA2_RAW;
                 r->desc.dict_size = (uint32_t)dict_size;
+                reader_enqueue(r);
             }
         }
     }
@@ -949,6 +1051,7 @@ extern "C" xlz_reader *xlz_new_lzma_decompressor_for_sevenzip(xlz_ctx *ctx, cons
                 r->desc.dict_size = xlz_decode_dict_size(props + 1);
                 r->desc.unpack_size = unpack_size;
                 r->is_closer = true;
+                reader_enqueue(r);
             }
         }
     }
@@ -1004,6 +1107,7 @@ extern "C" int xlz_reader_close(xlz_reader *r)
 {
     if (!r) return XLZ_ERR_BAD_ARG;
     if (r->closed) return XLZ_ERR_CLOSED;
+    if (r->queued) (void)reader_decode(r); // its buffers are in use until the batch is done
     r->closed = true;
     r->in.clear();
     r->in.shrink_to_fit();
@@ -1012,4 +1116,41 @@ extern "C" int xlz_reader_close(xlz_reader *r)
     return XLZ_OK;
 }
 
-extern "C" void xlz_reader_free(xlz_reader *r) { delete r; }
+extern "C" void xlz_reader_free(xlz_reader *r)
+{
+    if (r && r->queued) (void)reader_decode(r);
+    delete r;
+}
+
+static void batcher_shutdown(Batcher *bt)
+{
+    {
+        std::lock_guard<std::mutex> lk(bt->mu);
+        bt->stop = true;
+        bt->cv_work.notify_all();
+    }
+    bt->th.join();
+    delete bt;
+}
+
+extern "C" int xlz_ctx_enable_batching(xlz_ctx *ctx, uint32_t window_us, uint32_t max_streams)
+{
+    if (!ctx || ctx->batcher) return XLZ_ERR_BAD_ARG;
+    Batcher *bt = new (std::nothrow) Batcher;
+    if (!bt) return XLZ_ERR_BAD_ARG;
+    bt->ctx = ctx;
+    bt->window_us = window_us;
+    bt->max_streams = max_streams ? max_streams : 1;
+    bt->th = std::thread(batcher_loop, bt);
+    ctx->batcher = bt;
+    return XLZ_OK;
+}
+
+extern "C" int xlz_ctx_batching_stats(xlz_ctx *ctx, uint64_t *batches, uint64_t *streams)
+{
+    if (!ctx || !ctx->batcher) return XLZ_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->batcher->mu);
+    if (batches) *batches = ctx->batcher->n_batches;
+    if (streams) *streams = ctx->batcher->n_streams;
+    return XLZ_OK;
+}

@@ -387,3 +387,33 @@ def test_baseline_shape_roundtrip_and_idempotence(ctx):
     cin, cout, units = b.stats()
     assert cout == n * size and units == n and cin == sum(len(c) - 13 for c in comp)
     b.close()
+
+
+def test_concurrent_readers_are_coalesced_into_batches(xlz_so):
+    """many threads each doing the reference's `NewReader1(src)` + io.Copy get
+    decoded as a few GPU batches instead of one launch per reader."""
+    import threading
+    c2 = lzma_amd.Context(0)
+    c2.enable_batching(window_us=20_000, max_streams=256)
+    ps = [corpus.plain("TRMZ"[i % 4], 1500 + i, 20_000 + 501 * i) for i in range(48)]
+    blobs = [corpus.compress_alone(p, known_size=(i % 3 == 0)) for i, p in enumerate(ps)]
+    blobs[5] = blobs[5][:200]                       # truncated: clean EOF, short output
+    bad = bytearray(blobs[9]); bad[40] ^= 0x55; blobs[9] = bytes(bad)
+    outs, errs = [None] * 48, [None] * 48
+
+    def work(i):
+        r, err = lzma_amd.NewReader1(c2, blobs[i])
+        assert err is None
+        outs[i], errs[i] = r.read_all(chunk=4096 + i)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(48)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(48):
+        want = oracle.lzma1_alone(blobs[i], len(ps[i]) * 8 + 65536)
+        assert outs[i] == want[0], i
+        assert (errs[i] is None) == (want[1] >= 0), i
+    batches, streams = c2.batching_stats()
+    assert streams >= 48 and batches <= 24, (batches, streams)
+    c2.close()
