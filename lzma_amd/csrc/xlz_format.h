@@ -29,14 +29,21 @@ constexpr uint32_t LEN_HIGH = 4 + 256;
 constexpr uint32_t LEN_CODER_SIZE = 4 + 256 + 256; // 516
 constexpr uint32_t P_LEN = 820;
 constexpr uint32_t P_REP_LEN = P_LEN + LEN_CODER_SIZE; // 1336
-constexpr uint32_t P_LIT = P_REP_LEN + LEN_CODER_SIZE; // 1852; litProbs 0x300 << (lc+lp)
-constexpr uint32_t kLitCoderSize = 0x300;
+constexpr uint32_t P_LIT = P_REP_LEN + LEN_CODER_SIZE; // 1852
+// The reference's literal coder has 0x300 probs per literal state (state.go:4,49): 0x100 for the
+// plain 8-bit tree and 0x200 used only by the FIRST literal after a match ("matched literal",
+// decompress.go:59-114).  The plain part stays in the LDS model; the matched part lives in an
+// HBM scratch slot of the workgroup, fetched by one 8-lane gather when needed.  Halving the
+// LDS model is what lets 16 instead of 10 units be resident per CU.
+constexpr uint32_t kLitPlain = 0x100;   // per literal state, in LDS at P_LIT
+constexpr uint32_t kLitMatched = 0x200; // per literal state, in HBM: index (matchBit << 8) + symbol
 
-static inline constexpr uint32_t num_probs(uint32_t lc_plus_lp) { return P_LIT + (kLitCoderSize << lc_plus_lp); }
+static inline constexpr uint32_t num_probs(uint32_t lc_plus_lp) { return P_LIT + (kLitPlain << lc_plus_lp); }
+static inline constexpr uint32_t num_matched_probs(uint32_t lc_plus_lp) { return kLitMatched << lc_plus_lp; }
 
 constexpr uint32_t kMaxLdsBytes = 160u * 1024u; // MI355X LDS per CU
 constexpr uint32_t kWave = 64;
-constexpr uint32_t kMaxLcLpLds = 6;  // 0x300 << 6 probs = 98 KiB still fits one CU's LDS
+constexpr uint32_t kMaxLcLpLds = 8;  // (1852 + (0x100 << 8)) probs = 132 KiB still fits one CU's LDS
 constexpr uint32_t kMaxLcLp = 12;    // reference limit: lc <= 8, lp <= 4 (reader1.go:210-221)
 
 // ---- unit of work: one LZMA1 stream, or one run of LZMA2 chunks ------------
@@ -103,11 +110,16 @@ struct LaunchParams {
     uint16_t *scratch;
     uint32_t scratch_stride;
     uint32_t order_base;   // first entry of `order` this launch works on
+    // matched-literal probabilities: one slot of mlit_stride probs per workgroup (normal launch;
+    // the HBM-model launch keeps them behind the model inside its scratch slot)
+    uint16_t *mlit;
+    uint32_t mlit_stride;
 };
 
 // implemented in xlz_kernel.hip
 int launch_decode(const LaunchParams &p, int num_cus, void *stream /* hipStream_t */);
 uint32_t decode_lds_bytes(uint32_t max_lc_lp);
 uint32_t big_model_grid(int num_cus);
+uint32_t decode_grid(uint32_t max_lc_lp, int num_cus); // resident workgroups of the LDS-model launch
 
 } // namespace xlz

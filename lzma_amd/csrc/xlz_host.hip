@@ -93,8 +93,10 @@ struct xlz_batch {
     uint32_t max_lc_lp = 0;     // over the units whose model fits LDS
     uint32_t max_lc_lp_big = 0; // over the units decoded with an HBM-resident model
     uint32_t n_normal = 0;      // order[0, n_normal) = LDS units, the rest = big-model units
-    uint16_t *d_scratch = nullptr;
+    uint16_t *d_scratch = nullptr; // HBM-model launch: model + matched-literal part per workgroup
     uint32_t scratch_stride = 0;
+    uint16_t *d_mlit = nullptr;    // LDS-model launch: matched-literal part per workgroup
+    uint32_t mlit_stride = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ran = false;
     uint64_t algo_in = 0; // compressed payload bytes handed to the device
@@ -353,6 +355,7 @@ int batch_free(xlz_batch *b)
     if (b->d_order) (void)hipFree(b->d_order);
     if (b->d_results) (void)hipFree(b->d_results);
     if (b->d_scratch) (void)hipFree(b->d_scratch);
+    if (b->d_mlit) (void)hipFree(b->d_mlit);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     delete b;
@@ -502,8 +505,14 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess)
         return fail(XLZ_ERR_DEVICE);
     if (b->n_normal < nu) { // some models live in HBM: one scratch slot per workgroup of that launch
-        b->scratch_stride = num_probs(b->max_lc_lp_big);
+        b->scratch_stride = num_probs(b->max_lc_lp_big) + num_matched_probs(b->max_lc_lp_big);
         if (hipMalloc(&b->d_scratch, (size_t)big_model_grid(ctx->num_cus) * b->scratch_stride * sizeof(uint16_t)) !=
+            hipSuccess)
+            return fail(XLZ_ERR_DEVICE);
+    }
+    if (b->n_normal) { // the matched-literal half of every resident model (xlz_format.h)
+        b->mlit_stride = num_matched_probs(b->max_lc_lp);
+        if (hipMalloc(&b->d_mlit, (size_t)decode_grid(b->max_lc_lp, ctx->num_cus) * b->mlit_stride * sizeof(uint16_t)) !=
             hipSuccess)
             return fail(XLZ_ERR_DEVICE);
     }
@@ -550,6 +559,8 @@ extern "C" int xlz_batch_run(xlz_batch *b)
         p.max_lc_lp = b->max_lc_lp;
         p.scratch = nullptr;
         p.scratch_stride = 0;
+        p.mlit = b->d_mlit;
+        p.mlit_stride = b->mlit_stride;
         p.order_base = 0;
         if (launch_decode(p, ctx->num_cus, ctx->stream) != 0) return XLZ_ERR_DEVICE;
     }
@@ -559,6 +570,8 @@ extern "C" int xlz_batch_run(xlz_batch *b)
         p.max_lc_lp = b->max_lc_lp_big;
         p.scratch = b->d_scratch;
         p.scratch_stride = b->scratch_stride;
+        p.mlit = nullptr;
+        p.mlit_stride = 0;
         p.order_base = b->n_normal;
         if (launch_decode(p, ctx->num_cus, ctx->stream) != 0) return XLZ_ERR_DEVICE;
     }
@@ -616,6 +629,8 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
         p.max_lc_lp = big ? b->max_lc_lp_big : b->max_lc_lp;
         p.scratch = big ? b->d_scratch : nullptr;
         p.scratch_stride = big ? b->scratch_stride : 0;
+        p.mlit = big ? nullptr : b->d_mlit;
+        p.mlit_stride = big ? 0 : b->mlit_stride;
         p.order_base = 0;
         if (launch_decode(p, ctx->num_cus, ctx->stream) == 0 && hipStreamSynchronize(ctx->stream) == hipSuccess &&
             hipMemcpy(res.data(), d_res, n * sizeof(UnitResult), hipMemcpyDeviceToHost) == hipSuccess)

@@ -298,7 +298,8 @@ __device__ __forceinline__ bool bad_distance(const Dec &d)
 
 // ONE packet of (*Reader1).decompress (one iteration of the loop at decompress.go:13),
 // every mutation in the reference's order, every test of the reference present.
-__device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint8_t *__restrict__ out, uint32_t lane)
+__device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint16_t *__restrict__ mprobs,
+                                                   uint8_t *__restrict__ out, uint32_t lane)
 {
     uint32_t bit, length;
 
@@ -310,14 +311,20 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
         // ---- literal, decompress.go:44-175 ----
         if (d.size_defined && d.bytes_left == 0) return RUN_ERR_RESULT; // :45-47
         const uint32_t lit_state = ((d.wpos & d.lp_mask) << d.lc) + (d.prev_byte >> (8 - d.lc)); // :56
-        const uint32_t lbase = P_LIT + kLitCoderSize * lit_state;                              // :57
+        const uint32_t lbase = P_LIT + kLitPlain * lit_state;                                  // :57
         uint32_t symbol = 1;
-        if (d.state >= 7) { // matched literal :59-114
+        if (d.state >= 7) { // matched literal :59-114: probs[((1 + matchBit) << 8) + symbol] of the
+                            // reference's table = mprobs[(matchBit << 8) + symbol] of this state
+            uint16_t *mp = mprobs + kLitMatched * lit_state;
             uint32_t mb = d.match_byte;
             do {
                 const uint32_t match_bit = (mb >> 7) & 1;
                 mb <<= 1;
-                BIT(lbase + ((1 + match_bit) << 8) + symbol, bit);
+                uint16_t *pp = mp + (match_bit << 8) + symbol;
+                uint32_t p_ = RFL(*pp);
+                bit = rc_core(d.range, d.code, p_);
+                *pp = (uint16_t)p_;
+                NORMALIZE();
                 symbol = (symbol << 1) | bit;
                 if (match_bit != bit) break;
             } while (symbol < 0x100);
@@ -499,8 +506,9 @@ __device__ __forceinline__ HeadVec head_vectors(uint32_t lane)
     return h;
 }
 
-__device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint32_t lane, const HeadVec &hv,
-                                                   uint32_t arel_lim, uint32_t pos_lim, uint32_t &lenout)
+__device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_t *mprobs, uint32_t lane,
+                                                   const HeadVec &hv, uint32_t arel_lim, uint32_t pos_lim,
+                                                   uint32_t &lenout)
 {
     uint32_t exitc;
     asm volatile(
@@ -510,7 +518,7 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint32_
           [wpos] "+s"(d.wpos), [prev] "+s"(d.prev_byte), [mb] "+s"(d.match_byte), [exitc] "=&s"(exitc),
           [lenout] "=&s"(lenout)
         : [arel_lim] "s"(arel_lim), [pos_lim] "s"(pos_lim), [dict] "s"(d.dict_size), [pos_mask] "s"(d.pos_mask),
-          [lp_mask] "s"(d.lp_mask), [lc] "s"(d.lc), [wbase] "s"(d.wbase), [outp] "s"(out), [vin] "v"(d.vin),
+          [lp_mask] "s"(d.lp_mask), [lc] "s"(d.lc), [wbase] "s"(d.wbase), [outp] "s"(out), [mptr] "s"(mprobs), [vin] "v"(d.vin),
           [vlane] "v"(lane), [vhc] "v"(hv.hc), [vhms] "v"(hv.hms), [vhm2] "v"(hv.hm2)
         : "scc", "memory", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
           "s93", "s94", "s95", "s96", "s97", "s98", "v35", "v36", "v37", "v40", "v41", "v42", "v43", "v44", "v45", "v46",
@@ -520,8 +528,8 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint32_
 }
 
 // (*Reader1).decompress run to the end of the current LZMA chunk (decompress.go:8-1136)
-__device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint8_t *__restrict__ out, uint32_t lane,
-                                        const HeadVec &hv, bool allow_fast)
+__device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint16_t *__restrict__ mprobs,
+                                        uint8_t *__restrict__ out, uint32_t lane, const HeadVec &hv, bool allow_fast)
 {
     for (;;) {
         // decompress.go:14-20
@@ -532,7 +540,7 @@ __device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint8_t *__rest
         const bool fast = allow_fast && in_left >= kFastInput && (d.out_cap - d.pos) >= kFastOutput &&
                           (!d.size_defined || d.bytes_left >= kFastOutput);
         if (!fast) {
-            const int r = lzma_packet_checked(d, probs, out, lane);
+            const int r = lzma_packet_checked(d, probs, mprobs, out, lane);
             if (r != RUN_CONTINUE) return r;
             continue;
         }
@@ -542,7 +550,7 @@ __device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint8_t *__rest
         if (d.size_defined) room = min(room, d.bytes_left - kFastOutput);
         const uint32_t pos0 = d.pos;
         uint32_t len = 0;
-        const uint32_t ec = lzma_fast_loop(d, out, lane, hv, arel_lim, pos0 + room + 1, len);
+        const uint32_t ec = lzma_fast_loop(d, out, mprobs, lane, hv, arel_lim, pos0 + room + 1, len);
         d.bytes_left -= d.pos - pos0; // :172,660,665 ... (wraps harmlessly when the size is undefined)
         if (ec == FX_ERR) return RUN_ERR_RESULT; // :651-653, :690-692
         if (ec == FX_MARKER) {                    // end marker :633-645 (bytesLeft > 0 here if defined)
@@ -621,9 +629,20 @@ __device__ __forceinline__ void reload_context(Dec &d, const uint8_t *__restrict
     if (d.pos == d.wbase) d.prev_byte = 0; // window.IsEmpty (decompress.go:50-53)
 }
 
-__device__ __forceinline__ void state_reset(Dec &d, uint16_t *probs, uint32_t lc_lp, uint32_t lane)
+// the matched-literal part of the model (HBM): 16 bytes per lane and step
+__device__ __forceinline__ void mprobs_reset(uint16_t *__restrict__ mprobs, uint32_t n, uint32_t lane)
+{
+    uint4 *w = reinterpret_cast<uint4 *>(mprobs);
+    const uint32_t nw = n / 8; // 8 probs per 16 bytes; n is a multiple of 512
+    const uint4 v = make_uint4(kProbInitPair, kProbInitPair, kProbInitPair, kProbInitPair);
+    for (uint32_t base = 0; base < nw; base += kWave) w[base + lane] = v;
+}
+
+__device__ __forceinline__ void state_reset(Dec &d, uint16_t *probs, uint16_t *__restrict__ mprobs, uint32_t lc_lp,
+                                            uint32_t lane)
 {
     probs_reset(probs, num_probs(lc_lp), lane); // state.Reset, state.go:79-121
+    mprobs_reset(mprobs, num_matched_probs(lc_lp), lane);
     d.state = 0;
     d.rep0 = d.rep1 = d.rep2 = d.rep3 = 0;
 }
@@ -640,7 +659,8 @@ enum : int32_t { WALK_RUN_CHUNK = 1000 }; // lzma2_next: a compressed chunk is s
 
 // Reader2.startChunk (reader2.go:100-173) plus the stored-chunk body.  Returns
 // WALK_RUN_CHUNK when an LZMA chunk is ready for lzma_run, otherwise the unit's final status.
-__device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, const uint8_t *__restrict__ in_bytes,
+__device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, uint16_t *__restrict__ mprobs,
+                                              const uint8_t *__restrict__ in_bytes,
                                               uint8_t *__restrict__ out, uint32_t max_lc_lp, uint32_t lane,
                                               uint32_t &aux)
 {
@@ -705,9 +725,9 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
             d.lp_mask = (1u << lp) - 1;
             d.pos_mask = (1u << pb) - 1;
             w.lc_lp = lc + lp;
-            state_reset(d, probs, w.lc_lp, lane);
+            state_reset(d, probs, mprobs, w.lc_lp, lane);
         } else if (sub == 5) {
-            state_reset(d, probs, w.lc_lp, lane); // :156-157
+            state_reset(d, probs, mprobs, w.lc_lp, lane); // :156-157
         }
         w.first_chunk = !w.have_reader;
         w.have_reader = true;
@@ -723,7 +743,7 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
 // 0).  BIG = true (lc+lp > 6): the model is a slot of HBM scratch and only the checked C++
 // packet decoder runs -- slow, but the reference's whole parameter range decodes.
 template <bool BIG>
-__device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *probs)
+__device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *probs, uint16_t *__restrict__ mprobs)
 {
     const uint32_t lane = threadIdx.x;
     const HeadVec hv = head_vectors(lane);
@@ -771,14 +791,17 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
         w.last_unit = (flags & UNIT_F_LAST) != 0;
         w.have_reader = (flags & UNIT_F_HAVE_READER) != 0;
         w.first_chunk = true;
-        if (!lzma2) probs_reset(probs, num_probs(lc + lp), lane); // newState -> Reset (state.go:47-61)
+        if (!lzma2) { // newState -> Reset (state.go:47-61)
+            probs_reset(probs, num_probs(lc + lp), lane);
+            mprobs_reset(mprobs, num_matched_probs(lc + lp), lane);
+        }
 
         int32_t status;
         uint32_t aux = 0;
         // LZMA1: exactly one "chunk" (the whole stream).  LZMA2: one per compressed chunk.
         for (bool once = true;; once = false) {
             if (lzma2) {
-                status = lzma2_next(d, w, probs, p.in_arena + in_off, out, p.max_lc_lp, lane, aux);
+                status = lzma2_next(d, w, probs, mprobs, p.in_arena + in_off, out, p.max_lc_lp, lane, aux);
                 if (status != WALK_RUN_CHUNK) break;
             } else if (!once) {
                 break;
@@ -792,7 +815,7 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
                 status = ST_ERR_RC_INIT;
                 break;
             }
-            const int r = lzma_run(d, probs, out, lane, hv, !big);
+            const int r = lzma_run(d, probs, mprobs, out, lane, hv, !big);
             status = r == RUN_END ? ST_OK
                                   : r == RUN_INPUT_EOF ? ST_OK_INPUT_EOF
                                                        : r == RUN_OUT_CAP ? ST_ERR_OUT_CAP : ST_ERR_RESULT;
@@ -814,17 +837,25 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
 __global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds_probs[];
-    decode_units<false>(p, lds_probs);
+    decode_units<false>(p, lds_probs, p.mlit + (size_t)blockIdx.x * p.mlit_stride);
 }
 
 __global__ __launch_bounds__(64) void xlz_decode_kernel_hbm_model(LaunchParams p)
 {
-    decode_units<true>(p, p.scratch + (size_t)blockIdx.x * p.scratch_stride);
+    uint16_t *slot = p.scratch + (size_t)blockIdx.x * p.scratch_stride; // model, then its matched part
+    decode_units<true>(p, slot, slot + num_probs(p.max_lc_lp));
 }
 
 uint32_t decode_lds_bytes(uint32_t max_lc_lp) { return num_probs(max_lc_lp) * 2u + 128u; }
 
 uint32_t big_model_grid(int num_cus) { return (uint32_t)num_cus; } // one workgroup per CU
+uint32_t decode_grid(uint32_t max_lc_lp, int num_cus)
+{
+    uint32_t per_cu = kMaxLdsBytes / decode_lds_bytes(max_lc_lp);
+    if (per_cu > 16) per_cu = 16;
+    if (per_cu > 4) per_cu &= ~3u;
+    return per_cu * (uint32_t)num_cus;
+}
 
 int launch_decode(const LaunchParams &p, int num_cus, void *stream)
 {
@@ -838,7 +869,8 @@ int launch_decode(const LaunchParams &p, int num_cus, void *stream)
     const uint32_t lds = decode_lds_bytes(p.max_lc_lp);
     if (lds > kMaxLdsBytes) return -1;
     uint32_t per_cu = kMaxLdsBytes / lds;
-    if (per_cu > 16) per_cu = 16;
+    if (per_cu > 16) per_cu = 16;        // measured: 16 resident waves (4 per SIMD) is the sweet spot
+    if (per_cu > 4) per_cu &= ~3u;       // equal load on the four SIMDs
     if (const char *e = getenv("XLZ_PER_CU")) { // tuning knob: resident units per CU
         const uint32_t v = (uint32_t)atoi(e);
         if (v >= 1 && v < per_cu) per_cu = v;

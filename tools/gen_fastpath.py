@@ -157,14 +157,6 @@ def emit_finish_blocks():
         """ % L(k + "b"))
 
 
-def fbit(addr_sgpr):
-    """one decision on the prob at LDS byte address in addr_sgpr (fetched here); bit in s87"""
-    emit("v_mov_b32 v57, %s\nds_read_u16 v62, v57\ns_waitcnt lgkmcnt(0)\nv_readfirstlane_b32 s86, v62" % addr_sgpr)
-    core()
-    emit("ds_write_b16 v57, v63")
-    nchk()
-
-
 def hbit(lane):
     """one decision on head probability `lane` (already in v40); written back by that lane"""
     emit("v_readlane_b32 s86, v40, %d" % lane)
@@ -173,13 +165,32 @@ def hbit(lane):
     nchk()
 
 
-def walk(nbits, blocks, early_exit=None):
+def fetch_level(k, blocks):
+    """probability of tree node s88 at level k (0-based) of an 8-level tree -> s86"""
+    if k <= 5:
+        emit("v_readlane_b32 s86, %s, s88" % blocks[0])
+    elif k == 6:
+        emit("v_readlane_b32 s86, %s, s88" % blocks[1])
+    else:  # node 128..255: block 2 or 3 by bit 6 of M
+        emit("v_readlane_b32 s86, %s, s88\nv_readlane_b32 s84, %s, s88\ns_bitcmp1_b32 s88, 6\n"
+             "s_cselect_b32 s86, s84, s86" % (blocks[2], blocks[3]))
+
+
+def walk(nbits, blocks, early_exit=None, entries=None):
     """Walk nbits levels of the bit tree whose 64-prob blocks are already in `blocks`
     (bit_tree_decoder.go:18-40).  s88 ends as 1 followed by the decided bits; the probability
     of level k is parked in lane k of v54.  early_exit = (sgpr, label): leave after as many
-    levels as the SGPR says (reverse tree over posDecoders, 1..5 levels)."""
-    emit("s_mov_b32 s88, 1\nv_readlane_b32 s86, %s, 1" % blocks[0])
+    levels as the SGPR says (reverse tree over posDecoders, 1..5 levels).
+    entries = label prefix: the walk is only ever entered at level k >= 1 through <prefix>k,
+    with s88 = the tree index reached so far."""
+    if not entries:
+        emit("s_mov_b32 s88, 1\nv_readlane_b32 s86, %s, 1" % blocks[0])
     for k in range(nbits):
+        if entries:
+            if k == 0:
+                continue
+            label("%s%d" % (entries, k))
+            fetch_level(k, blocks)
         emit("v_writelane_b32 v54, s86, %d\ns_lshl1_add_u32 s85, s88, 1" % k)
         walk_core()
         emit("s_subb_u32 s88, s85, 0")  # M = 2M + 1 - SCC = 2M + bit
@@ -187,16 +198,11 @@ def walk(nbits, blocks, early_exit=None):
         if k + 1 < nbits:
             if early_exit:
                 emit("s_cmp_eq_u32 %s, %d\ns_cbranch_scc1 %s" % (early_exit[0], k + 1, early_exit[1]))
-            if k + 1 <= 5:
-                emit("v_readlane_b32 s86, %s, s88" % blocks[0])
-            elif k + 1 == 6:
-                emit("v_readlane_b32 s86, %s, s88" % blocks[1])
-            else:  # node 128..255: block 2 or 3 by bit 6 of M
-                emit("v_readlane_b32 s86, %s, s88\nv_readlane_b32 s84, %s, s88\ns_bitcmp1_b32 s88, 6\n"
-                     "s_cselect_b32 s86, s84, s86" % (blocks[2], blocks[3]))
+            if not entries:
+                fetch_level(k + 1, blocks)
 
 
-def tree_update(nb):
+def tree_update(nb, store=True):
     """Apply the model updates of a finished walk in ONE vector operation.  s88 = final index,
     v54 lane k = probability seen at level k, v58 = byte address of the tree base.
     nb: int, or the name of an SGPR holding the level count.
@@ -215,20 +221,13 @@ def tree_update(nb):
     v_ashrrev_i32 v61, 5, v61
     v_sub_u32 v61, v54, v61
     """ % nb)
+    if not store:
+        return
     if isinstance(nb, int):
         emit("s_mov_b64 exec, %d" % ((1 << nb) - 1))
     else:
         emit("s_bfm_b64 exec, %s, 0" % nb)
     emit("ds_write_b16 v60, v61\ns_mov_b64 exec, -1")
-
-
-def level_lookahead():
-    """one level with child look-ahead and immediate update (matched-literal tail, v58/v59 set)"""
-    emit("v_lshl_add_u32 v61, s88, 2, v59\nds_read_u16 v62, v61")
-    core()
-    emit("v_lshl_add_u32 v60, s88, 1, v58\nds_write_b16 v60, v63\ns_lshl1_add_u32 s88, s88, s87")
-    nchk()
-    emit("s_waitcnt lgkmcnt(0)\nv_readlane_b32 s86, v62, s87")
 
 
 def len_prefetch(base):
@@ -286,7 +285,7 @@ def literal_context():
     s_sub_u32 s84, 8, %%[lc]
     s_lshr_b32 s84, %%[prev], s84
     s_add_u32 s83, s83, s84
-    s_mulk_i32 s83, 0x600
+    s_lshl_b32 s83, s83, 9
     s_add_u32 s92, s83, %d
     v_add_u32 v59, s92, v56
     ds_read_u16 v50, v59
@@ -356,8 +355,45 @@ def gen():
     tree_update(8)
     literal_context()
     emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
-    # tail of a matched literal (its model updates were immediate)
-    label("litdone")
+    # ------------------------------------------------------------- matched literal (:59-114)
+    # The matched half of the literal coder lives in HBM (xlz_format.h): ONE gather fetches the
+    # eight probabilities the walk meets as long as the decoded bits follow matchByte (lane k =
+    # level k: symbol (1 << k) | (mb >> (8 - k)), matchBit (mb >> (7 - k)) & 1).  At the first
+    # bit that differs the walk carries on in the plain table (:116-165), whose blocks are
+    # already in v50..v53.  s98 = levels decided in the matched table.
+    label("mlit")
+    emit("""
+    s_sub_u32 s83, s92, %d
+    s_lshl_b32 s83, s83, 1
+    v_min_u32 v55, 7, %%[vlane]
+    v_sub_u32 v60, 8, v55
+    v_lshrrev_b32 v60, v60, %%[mb]
+    v_lshlrev_b32 v61, v55, 1
+    v_or_b32 v60, v60, v61
+    v_sub_u32 v61, 7, v55
+    v_lshrrev_b32 v61, v61, %%[mb]
+    v_and_b32 v61, 1, v61
+    v_lshl_or_b32 v60, v61, 8, v60
+    v_lshl_add_u32 v57, v60, 1, s83
+    global_load_ushort v54, v57, %%[mptr]
+    s_or_b32 s89, %%[mb], 0x100
+    s_mov_b32 s88, 1
+    v_mov_b32 v58, s92
+    s_waitcnt vmcnt(0)
+    """ % (P_LIT * 2))
+    for k in range(8):
+        emit("v_readlane_b32 s86, v54, %d\ns_lshl1_add_u32 s85, s88, 1" % k)
+        walk_core()
+        emit("s_subb_u32 s88, s85, 0")
+        nchk()
+        if k < 7:  # still on matchByte's path?  s88 == (0x100 | mb) >> (7 - k)
+            emit("s_lshr_b32 s80, s89, %d\ns_cmp_lg_u32 s80, s88\ns_cbranch_scc1 %s" % (7 - k, L("mx%d" % (k + 1))))
+    emit("s_mov_b32 s98, 8\ns_branch %s" % L("mlfin"))
+    for k in range(1, 8):
+        label("mx%d" % k)
+        emit("s_mov_b32 s98, %d\ns_branch %s" % (k, L("pw%d" % k)))
+    walk(8, ["v50", "v51", "v52", "v53"], entries="pw")
+    label("mlfin")
     emit("""
     s_and_b32 %[prev], s88, 0xff
     v_mov_b32 v60, %[prev]
@@ -369,49 +405,20 @@ def gen():
     emit("""
     s_cmp_lt_u32 %[state], 10
     s_cselect_b32 s80, 3, 6
-    s_sub_u32 s80, %[state], s80
-    s_cmp_lt_u32 %[state], 4
-    s_cselect_b32 %[state], 0, s80
+    s_sub_u32 %[state], %[state], s80
     """)
     head_issue()
+    tree_update(8, store=False)  # lanes < s98 -> matched table (HBM), the rest -> plain table (LDS)
+    emit("""
+    s_bfm_b64 exec, s98, 0
+    global_store_short v57, v61, %[mptr]
+    s_sub_u32 s80, 8, s98
+    s_bfm_b64 exec, s80, s98
+    ds_write_b16 v60, v61
+    s_mov_b64 exec, -1
+    """)
     literal_context()
     emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
-    # ------------------------------------------------------------- matched literal (:59-114)
-    label("mlit")
-    emit("s_mov_b32 s88, 1\ns_mov_b32 s89, %[mb]")
-    label("ml")
-    emit("""
-    s_bfe_u32 s83, s89, 0x10007
-    s_lshl_b32 s89, s89, 1
-    s_add_u32 s84, s83, 1
-    s_lshl_b32 s84, s84, 9
-    s_add_u32 s84, s84, s92
-    s_lshl_b32 s82, s88, 1
-    s_add_u32 s82, s82, s84
-    """)
-    fbit("s82")
-    emit("""
-    s_lshl1_add_u32 s88, s88, s87
-    s_cmp_lg_u32 s83, s87
-    s_cbranch_scc1 %s
-    s_cmpk_lt_u32 s88, 0x100
-    s_cbranch_scc1 %s
-    s_branch %s
-    """ % (L("mlrest"), L("ml"), L("litdone")))
-    label("mlrest")
-    emit("""
-    s_cmpk_lt_u32 s88, 0x100
-    s_cbranch_scc0 %s
-    v_mov_b32 v58, s92
-    v_add_u32 v59, s92, v56
-    v_lshl_add_u32 v60, s88, 1, v58
-    ds_read_u16 v62, v60
-    s_waitcnt lgkmcnt(0)
-    v_readfirstlane_b32 s86, v62
-    """ % L("litdone"))
-    label("mlr")
-    level_lookahead()
-    emit("s_cmpk_lt_u32 s88, 0x100\ns_cbranch_scc1 %s\ns_branch %s" % (L("mlr"), L("litdone")))
     # ------------------------------------------------------------- match or rep
     label("match")
     hbit(H_IS_REP)
