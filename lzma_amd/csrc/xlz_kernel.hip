@@ -499,7 +499,9 @@ __device__ __forceinline__ HeadVec head_vectors(uint32_t lane)
                           : lane == 5 ? P_IS_REP0_LONG
                           : lane == 6 ? P_LEN + LEN_CHOICE
                           : lane == 7 ? P_LEN + LEN_CHOICE2
-                          : lane == 8 ? P_REP_LEN + LEN_CHOICE : lane == 9 ? P_REP_LEN + LEN_CHOICE2 : 0u;
+                          : lane == 8 ? P_REP_LEN + LEN_CHOICE
+                          : lane == 9 ? P_REP_LEN + LEN_CHOICE2
+                                      : P_LEN + 2; // lanes 10..63: an unused slot (their v40 is stored too)
     h.hc = base * 2;
     h.hms = (lane >= 1 && lane <= 4) ? 2u : 0u; // indexed by state
     h.hm2 = (lane == 0 || lane == 5) ? 2u : 0u; // indexed by state2 = (state << 4) + posState
@@ -520,7 +522,7 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_
         : [arel_lim] "s"(arel_lim), [pos_lim] "s"(pos_lim), [dict] "s"(d.dict_size), [pos_mask] "s"(d.pos_mask),
           [lp_mask] "s"(d.lp_mask), [lc] "s"(d.lc), [wbase] "s"(d.wbase), [outp] "s"(out), [mptr] "s"(mprobs), [vin] "v"(d.vin),
           [vlane] "v"(lane), [vhc] "v"(hv.hc), [vhms] "v"(hv.hms), [vhm2] "v"(hv.hm2)
-        : "scc", "memory", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
+        : "scc", "vcc", "memory", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
           "s93", "s94", "s95", "s96", "s97", "s98", "v35", "v36", "v37", "v40", "v41", "v42", "v43", "v44", "v45", "v46",
           "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62",
           "v63");
@@ -849,13 +851,21 @@ __global__ __launch_bounds__(64) void xlz_decode_kernel_hbm_model(LaunchParams p
 uint32_t decode_lds_bytes(uint32_t max_lc_lp) { return num_probs(max_lc_lp) * 2u + 128u; }
 
 uint32_t big_model_grid(int num_cus) { return (uint32_t)num_cus; } // one workgroup per CU
-uint32_t decode_grid(uint32_t max_lc_lp, int num_cus)
+// resident single-wave workgroups per CU of the LDS-model launch
+static uint32_t decode_per_cu(uint32_t max_lc_lp)
 {
-    uint32_t per_cu = kMaxLdsBytes / decode_lds_bytes(max_lc_lp);
-    if (per_cu > 16) per_cu = 16;
-    if (per_cu > 4) per_cu &= ~3u;
-    return per_cu * (uint32_t)num_cus;
+    const uint32_t fit = kMaxLdsBytes / decode_lds_bytes(max_lc_lp);
+    uint32_t per_cu = fit;
+    if (per_cu > 16) per_cu = 16;  // measured: 12..16 resident waves is the plateau
+    if (per_cu > 4) per_cu &= ~3u; // equal load on the four SIMDs
+    if (const char *e = getenv("XLZ_PER_CU")) { // tuning knob
+        const uint32_t v = (uint32_t)atoi(e);
+        if (v >= 1 && v <= fit && v <= 32) per_cu = v;
+    }
+    return per_cu;
 }
+
+uint32_t decode_grid(uint32_t max_lc_lp, int num_cus) { return decode_per_cu(max_lc_lp) * (uint32_t)num_cus; }
 
 int launch_decode(const LaunchParams &p, int num_cus, void *stream)
 {
@@ -868,14 +878,7 @@ int launch_decode(const LaunchParams &p, int num_cus, void *stream)
     }
     const uint32_t lds = decode_lds_bytes(p.max_lc_lp);
     if (lds > kMaxLdsBytes) return -1;
-    uint32_t per_cu = kMaxLdsBytes / lds;
-    if (per_cu > 16) per_cu = 16;        // measured: 16 resident waves (4 per SIMD) is the sweet spot
-    if (per_cu > 4) per_cu &= ~3u;       // equal load on the four SIMDs
-    if (const char *e = getenv("XLZ_PER_CU")) { // tuning knob: resident units per CU
-        const uint32_t v = (uint32_t)atoi(e);
-        if (v >= 1 && v < per_cu) per_cu = v;
-    }
-    uint32_t grid = (uint32_t)num_cus * per_cu;
+    uint32_t grid = decode_grid(p.max_lc_lp, num_cus);
     if (grid > p.n_units) grid = p.n_units;
     if (grid == 0) return 0;
     if (lds > 64u * 1024u &&

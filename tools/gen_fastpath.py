@@ -157,11 +157,37 @@ def emit_finish_blocks():
         """ % L(k + "b"))
 
 
-def hbit(lane):
-    """one decision on head probability `lane` (already in v40); written back by that lane"""
-    emit("v_readlane_b32 s86, v40, %d" % lane)
-    core()
-    emit("s_mov_b64 exec, %d\nds_write_b16 v47, v63\ns_mov_b64 exec, -1" % (1 << lane))
+def head_update(lane, bit):
+    """new value of head probability `lane` (decompress.go:30 / :177), VALU only: the lanes of v40
+    all compute it from their own value, lane `lane` keeps it.  v40 goes back to LDS in one
+    store when the packet is over (head_issue / exit)."""
+    if bit == 0:
+        emit("v_add_u32 v63, 0xfffff81f, v40\nv_ashrrev_i32 v63, 5, v63")
+    else:
+        emit("v_ashrrev_i32 v63, 5, v40")
+    emit("v_sub_u32 v63, v40, v63\nv_cmp_eq_u32 vcc, %d, %%[vlane]\nv_cndmask_b32 v40, v40, v63, vcc" % lane)
+
+
+def hbit(lane, one):
+    """One decision on head probability `lane` (already in v40), both outcomes specialised: the
+    borrow of code - bound is branched on directly.  Bit 0 falls through; bit 1 goes to label
+    `one`, where the caller emits hbit_one(lane) first."""
+    emit("""
+    v_readlane_b32 s86, v40, %d
+    s_lshr_b32 s80, %%[range], 11
+    s_mul_i32 s80, s80, s86
+    s_sub_u32 s81, %%[range], s80
+    s_sub_u32 s87, %%[code], s80
+    s_cbranch_scc0 %s
+    s_mov_b32 %%[range], s80
+    """ % (lane, one))
+    head_update(lane, 0)
+    nchk()
+
+
+def hbit_one(lane):
+    emit("s_mov_b32 %[code], s87\ns_mov_b32 %[range], s81")
+    head_update(lane, 1)
     nchk()
 
 
@@ -248,20 +274,20 @@ def len_prefetch(base):
 def len_decode(tag, base, lane_c, lane_c2):
     """lenDecoder.Decode (len_decoder.go:34-60): raw length -> s89; the walked tree's update is
     left pending (s96 = its level count, v58 = its base, s88 / v54 = the walk)."""
-    hbit(lane_c)
-    emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L(tag + "c2"))
+    hbit(lane_c, L(tag + "c2"))
     emit("s_lshl_b32 s92, s90, 4\ns_add_u32 s92, s92, %d\nv_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)"
          % ((base + LEN_LOW) * 2))
     walk(3, ["v41"])
     emit("s_sub_u32 s89, s88, 8\ns_mov_b32 s96, 3\ns_branch %s" % L(tag + "end"))
     label(tag + "c2")
-    hbit(lane_c2)
-    emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L(tag + "hi"))
+    hbit_one(lane_c)
+    hbit(lane_c2, L(tag + "hi"))
     emit("s_lshl_b32 s92, s90, 4\ns_add_u32 s92, s92, %d\nv_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)"
          % ((base + LEN_MID) * 2))
     walk(3, ["v42"])
     emit("s_mov_b32 s89, s88\ns_mov_b32 s96, 3\ns_branch %s" % L(tag + "end"))
     label(tag + "hi")
+    hbit_one(lane_c2)
     emit("s_movk_i32 s92, %d\nv_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)" % ((base + LEN_HIGH) * 2))
     walk(8, ["v43", "v44", "v45", "v46"])
     emit("s_sub_u32 s89, s88, 240\ns_mov_b32 s96, 8")
@@ -295,8 +321,11 @@ def literal_context():
     """ % (P_LIT * 2))
 
 
-def head_issue():
-    """posState / state2 of the packet about to start (-> s90, s91) and its head gather"""
+def head_issue(first=False):
+    """the finished packet's head probabilities go back to LDS; posState / state2 of the packet
+    about to start (-> s90, s91) and its head gather"""
+    if not first:
+        emit("ds_write_b16 v47, v40")
     emit("""
     s_and_b32 s90, %[wpos], %[pos_mask]
     s_lshl_b32 s91, %[state], 4
@@ -311,7 +340,7 @@ def gen():
     # The gathers of packet n+1 are issued from the tail of packet n (software pipelining):
     # by the time the loop top has done its limit checks the probabilities have arrived.
     emit("v_lshlrev_b32 v56, 1, %[vlane]\ns_mov_b32 s94, 0")
-    head_issue()
+    head_issue(first=True)
     literal_context()  # no copy is pending on entry: prevByte is valid
     emit("s_mov_b32 s97, 1")
     # ------------------------------------------------------------- packet head
@@ -323,8 +352,7 @@ def gen():
     s_cbranch_scc1 %s
     s_waitcnt lgkmcnt(0)
     """ % (L("x0"), L("x0")))
-    hbit(H_IS_MATCH)
-    emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L("match"))
+    hbit(H_IS_MATCH, L("match"))
     # ------------------------------------------------------------- literal (decompress.go:44-175)
     need_copy_done()
     emit("s_cmp_lg_u32 s97, 0\ns_cbranch_scc1 %s" % L("litready"))
@@ -421,8 +449,8 @@ def gen():
     emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
     # ------------------------------------------------------------- match or rep
     label("match")
-    hbit(H_IS_REP)
-    emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L("rep"))
+    hbit_one(H_IS_MATCH)
+    hbit(H_IS_REP, L("rep"))
     # simple match (:215-668)
     emit("s_mov_b32 %[rep3], %[rep2]\ns_mov_b32 %[rep2], %[rep1]\ns_mov_b32 %[rep1], %[rep0]")
     len_prefetch(P_LEN)
@@ -518,24 +546,26 @@ def gen():
     emit("s_add_u32 s89, s89, 2\ns_branch %s" % L("copy"))
     # ------------------------------------------------------------- rep match (:685-1123)
     label("rep")
+    hbit_one(H_IS_REP)
     emit("s_cmp_eq_u32 %%[pos], %%[wbase]\ns_cbranch_scc1 %s" % L("x1"))
-    hbit(H_G0)
-    emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L("g1"))
-    hbit(H_REP0_LONG)
-    emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L("replen"))
+    hbit(H_G0, L("g1"))
+    hbit(H_REP0_LONG, L("r0long"))
     emit("""
     s_cmp_lt_u32 %%[state], 7
     s_cselect_b32 %%[state], 9, 11
     s_mov_b32 s89, 1
     s_branch %s
     """ % L("copy"))  # short rep: one byte
+    label("r0long")
+    hbit_one(H_REP0_LONG)
+    emit("s_branch %s" % L("replen"))
     label("g1")
-    hbit(H_G1)
-    emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L("g2"))
+    hbit_one(H_G0)
+    hbit(H_G1, L("g2"))
     emit("s_mov_b32 s80, %%[rep1]\ns_mov_b32 %%[rep1], %%[rep0]\ns_mov_b32 %%[rep0], s80\ns_branch %s" % L("replen"))
     label("g2")
-    hbit(H_G2)
-    emit("s_cmp_lg_u32 s87, 0\ns_cbranch_scc1 %s" % L("g3"))
+    hbit_one(H_G1)
+    hbit(H_G2, L("g3"))
     emit("""
     s_mov_b32 s80, %%[rep2]
     s_mov_b32 %%[rep2], %%[rep1]
@@ -544,6 +574,7 @@ def gen():
     s_branch %s
     """ % L("replen"))
     label("g3")
+    hbit_one(H_G2)
     emit("""
     s_mov_b32 s80, %[rep3]
     s_mov_b32 %[rep3], %[rep2]
@@ -593,7 +624,7 @@ def gen():
     emit("s_mov_b32 %[exitc], 0")
     label("fin")
     need_copy_done()
-    emit("s_waitcnt lgkmcnt(0)\ns_branch %s" % L("end"))
+    emit("s_waitcnt lgkmcnt(0)\nds_write_b16 v47, v40\ns_waitcnt lgkmcnt(0)\ns_branch %s" % L("end"))
     emit_stubs()
     emit_finish_blocks()
     label("end")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes over the default bench command (run on the GPU box via gpurun).
 #   tools/profile_bench.sh <tag> [extra bench args]
-# 1) --kernel-trace --stats  2) --pmc FETCH_SIZE  3) --pmc WRITE_SIZE  4) SQ instruction mix
+# 1) --kernel-trace --stats  2) --pmc FETCH_SIZE  3) --pmc WRITE_SIZE  4) SQ instruction mix  5) SQ issue activity
 # Counter passes are separate runs and never combined with tracing (pool rule).
 TAG=${1:-r01}; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
@@ -12,5 +12,6 @@ rocprofv3 --kernel-trace --stats -d $O/kt --output-format csv -- python3 $R/benc
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py $ARGS > $O/fetch.json 2> $O/fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py $ARGS > $O/write.json 2> $O/write.err || exit 1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/sq --output-format csv -- python3 $R/bench.py $ARGS > $O/sq.json 2> $O/sq.err || exit 1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_IFETCH SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $O/sq2 --output-format csv -- python3 $R/bench.py $ARGS > $O/sq2.json 2> $O/sq2.err || exit 1
 python3 $R/tools/summarize_prof.py $O > $O/summary.md
 cat $O/summary.md

@@ -10,7 +10,7 @@ def kernel_rows(sub, pattern):
 
 print("# rocprofv3 summary (%s)\n" % os.path.basename(O))
 print("command: `python3 bench.py %s`\n" % open(os.path.join(O, "command.txt")).read().strip().replace("bench args: ", ""))
-for name in ("kt", "fetch", "write", "sq"):
+for name in ("kt", "fetch", "write", "sq", "sq2"):
     p = os.path.join(O, name + ".json")
     if os.path.exists(p) and os.path.getsize(p):
         j = json.loads(open(p).read().strip().splitlines()[-1])
@@ -23,7 +23,7 @@ for r in kernel_rows("kt", "*kernel_stats.csv"):
     print("| %s | %s | %s | %.0f | %s |" % (r["Name"][:60], r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
 print("\n## PMC (per launch of xlz_decode_kernel, summed over the device)\n")
 vals = collections.defaultdict(list)
-for sub in ("fetch", "write", "sq"):
+for sub in ("fetch", "write", "sq", "sq2"):
     for r in kernel_rows(sub, "*counter_collection.csv"):
         if "xlz_decode" in r["Kernel_Name"]:
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
