@@ -506,27 +506,39 @@ def gen():
     """ % L("distdone"))
     label("direct")  # DecodeDirectBits (:549-577)
     tree_update(6)  # posSlot tree
-    emit("s_sub_u32 s83, s83, 4\ns_mov_b32 s84, 0")
-    label("db")
+    # numDirectBits - 4 = s83 - 4 (2..26) halvings, unrolled; entered through a branch table so
+    # that no loop counter is kept.  Exactly the reference's arithmetic: t = sign(code - range).
+    # s84 collects the complemented bits (2 * acc + SCC).
     emit("""
-    s_lshr_b32 %[range], %[range], 1
-    s_sub_u32 %[code], %[code], %[range]
-    s_ashr_i32 s80, %[code], 31
-    s_and_b32 s81, %[range], s80
-    s_add_u32 %[code], %[code], s81
-    s_lshl1_add_u32 s84, s84, 1
-    s_add_u32 s84, s84, s80
-    """)
-    nchk()
+    s_getpc_b64 s[80:81]
+    s_sub_u32 s82, 35, s83
+    s_lshl2_add_u32 s80, s82, s80
+    s_addc_u32 s81, s81, 0
+    s_mov_b32 s84, 0
+    s_setpc_b64 s[80:81]
+    """)  # s_getpc returns the address of the s_sub; the table starts 5 instructions (all 4 bytes) later:
+    # entry e = 26 - (s83 - 4) is at +4 * (e + 5) = 4 * (35 - s83)
+    for k in range(26, 0, -1):
+        emit("s_branch %s" % L("db%d" % k))
+    for k in range(26, 0, -1):
+        label("db%d" % k)
+        emit("""
+        s_lshr_b32 %[range], %[range], 1
+        s_sub_u32 s81, %[code], %[range]
+        s_cmp_lt_i32 s81, 0
+        s_cselect_b32 %[code], %[code], s81
+        s_addc_u32 s84, s84, s84
+        """)
+        nchk()
     emit("""
-    s_sub_u32 s83, s83, 1
-    s_cmp_lg_u32 s83, 0
-    s_cbranch_scc1 %s
+    s_sub_u32 s83, s83, 4
+    s_bfm_b32 s80, s83, 0
+    s_andn2_b32 s84, s80, s84
     s_lshl_b32 s84, s84, 4
     s_add_u32 s93, s93, s84
     s_movk_i32 s92, %d
     v_mov_b32 v58, s92
-    """ % (L("db"), P_ALIGN * 2))
+    """ % (P_ALIGN * 2))
     walk(4, ["v35"])  # reverse tree over alignDecoderProbs (:579-625): M = 1 b0 b1 b2 b3
     tree_update(4)
     emit("s_brev_b32 s80, s88\ns_lshr_b32 s80, s80, 28\ns_add_u32 %[rep0], s93, s80")
