@@ -240,6 +240,13 @@ __device__ __forceinline__ uint32_t rc_core(uint32_t &range, uint32_t &code, uin
         NORMALIZE();                                                                              \
     } while (0)
 
+// Where a tree node lives.  The reference indexes a bit tree by m = 1 b0 b1 .. (decided bits after a
+// leading 1).  This build stores node m at tree_slot(m): the same leading 1 followed by the
+// COMPLEMENTED bits, because the fast path's index step is `s_addc m, m, m` with SCC = (code < bound)
+// = !bit (xlz_fastpath.inc).  A permutation inside every tree level; every table starts out as
+// kProbInit everywhere, so nothing else changes.
+__device__ __forceinline__ uint32_t tree_slot(uint32_t m, uint32_t level) { return m ^ ((1u << level) - 1); }
+
 // forward bit tree (bit_tree_decoder.go:18-40): M keeps the leading 1
 #define TREE(BASE, NB, M)                                                                         \
     do {                                                                                          \
@@ -247,7 +254,7 @@ __device__ __forceinline__ uint32_t rc_core(uint32_t &range, uint32_t &code, uin
         _Pragma("unroll 1") for (uint32_t k_ = 0; k_ < (NB); k_++)                                \
         {                                                                                         \
             uint32_t tb_;                                                                         \
-            BIT((BASE) + (M), tb_);                                                               \
+            BIT((BASE) + tree_slot((M), k_), tb_);                                                \
             (M) = ((M) << 1) | tb_;                                                               \
         }                                                                                         \
     } while (0)
@@ -260,7 +267,7 @@ __device__ __forceinline__ uint32_t rc_core(uint32_t &range, uint32_t &code, uin
         _Pragma("unroll 1") for (uint32_t k_ = 0; k_ < (NB); k_++)                                \
         {                                                                                         \
             uint32_t tb_;                                                                         \
-            BIT((BASE) + m_, tb_);                                                                \
+            BIT((BASE) + tree_slot(m_, k_), tb_);                                                 \
             m_ = (m_ << 1) | tb_;                                                                 \
             (SYM) |= tb_ << k_;                                                                   \
         }                                                                                         \
@@ -317,10 +324,11 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
                             // reference's table = mprobs[(matchBit << 8) + symbol] of this state
             uint16_t *mp = mprobs + kLitMatched * lit_state;
             uint32_t mb = d.match_byte;
+            uint32_t level = 0;
             do {
                 const uint32_t match_bit = (mb >> 7) & 1;
                 mb <<= 1;
-                uint16_t *pp = mp + (match_bit << 8) + symbol;
+                uint16_t *pp = mp + (match_bit << 8) + tree_slot(symbol, level++);
                 uint32_t p_ = RFL(*pp);
                 bit = rc_core(d.range, d.code, p_);
                 *pp = (uint16_t)p_;
@@ -329,8 +337,8 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
                 if (match_bit != bit) break;
             } while (symbol < 0x100);
         }
-        while (symbol < 0x100) { // :127-166
-            BIT(lbase + symbol, bit);
+        for (uint32_t level = 31 - __clz(symbol); symbol < 0x100; level++) { // :127-166
+            BIT(lbase + tree_slot(symbol, level), bit);
             symbol = (symbol << 1) | bit;
         }
         symbol &= 0xFF;

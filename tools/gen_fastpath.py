@@ -24,7 +24,7 @@ How the 64 lanes are used (the wave is the register file of ONE decoder):
     probabilities a packet can start with (isMatch, isRep, isRepG0-2, isRep0Long, the four
     length `choice` bits) into v40; a decision takes its probability with v_readlane.
   * tree blocks: one ds_read fetches 64 consecutive probabilities of a bit tree (lane j =
-    node 64b + j).  A tree level is then nine scalar instructions plus
+    slot 64b + j).  A tree level is then eight scalar instructions plus
     `v_readlane p, block, M`: the lane select IS the node index, so neither the decoded bit
     nor an LDS address is ever formed.  Blocks are requested well before they are walked.
   * the probabilities met on a walk are parked in v54 (v_writelane) and updated together
@@ -33,7 +33,7 @@ How the 64 lanes are used (the wave is the register file of ONE decoder):
     behind the next packet's decode.
 
 Register conventions (fixed temporaries, declared as clobbers in xlz_kernel.hip):
-  s80,s81 core temps   s82,s83,s84 temps   s85 2M+1   s86 P   s87 BIT   s88 M (tree index)
+  s80,s81 core temps   s82,s83,s84,s85 temps   s86 P   s87 code - bound   s88 tree slot (1, then !bits)
   s89 LEN   s90 posState   s91 state2   s92 table base (bytes)   s93 dist
   s94 copy pending   s95 its length   s96 levels of the walk awaiting its update
   s97 literal blocks prefetched   s98 posSlot / nbits
@@ -94,7 +94,7 @@ def core():
 
 def walk_core():
     """decision core of a tree level: range and code selected, SCC = (code < bound) kept for
-    the caller's s_subb that advances the tree index"""
+    the caller's s_addc that advances the tree index"""
     emit("""
     s_lshr_b32 s80, %[range], 11
     s_mul_i32 s80, s80, s86
@@ -204,7 +204,8 @@ def fetch_level(k, blocks):
 
 def walk(nbits, blocks, early_exit=None, entries=None):
     """Walk nbits levels of the bit tree whose 64-prob blocks are already in `blocks`
-    (bit_tree_decoder.go:18-40).  s88 ends as 1 followed by the decided bits; the probability
+    (bit_tree_decoder.go:18-40).  s88 ends as 1 followed by the COMPLEMENTED decided bits (the tree
+    slot order of xlz_kernel.hip: tree_slot); the probability
     of level k is parked in lane k of v54.  early_exit = (sgpr, label): leave after as many
     levels as the SGPR says (reverse tree over posDecoders, 1..5 levels).
     entries = label prefix: the walk is only ever entered at level k >= 1 through <prefix>k,
@@ -217,9 +218,9 @@ def walk(nbits, blocks, early_exit=None, entries=None):
                 continue
             label("%s%d" % (entries, k))
             fetch_level(k, blocks)
-        emit("v_writelane_b32 v54, s86, %d\ns_lshl1_add_u32 s85, s88, 1" % k)
+        emit("v_writelane_b32 v54, s86, %d" % k)
         walk_core()
-        emit("s_subb_u32 s88, s85, 0")  # M = 2M + 1 - SCC = 2M + bit
+        emit("s_addc_u32 s88, s88, s88")  # J = 2J + SCC = 2J + !bit (tree_slot order, xlz_kernel.hip)
         nchk()
         if k + 1 < nbits:
             if early_exit:
@@ -232,7 +233,7 @@ def tree_update(nb, store=True):
     """Apply the model updates of a finished walk in ONE vector operation.  s88 = final index,
     v54 lane k = probability seen at level k, v58 = byte address of the tree base.
     nb: int, or the name of an SGPR holding the level count.
-    Lane k: node = s88 >> (nb-k), bit = (s88 >> (nb-k-1)) & 1,
+    Lane k: slot = s88 >> (nb-k), !bit = (s88 >> (nb-k-1)) & 1  (s88 holds complemented bits),
             new = p - ((p - (bit ? 0 : 2017)) >>a 5)   (decompress.go:30 / :177)."""
     emit("""
     v_sub_u32 v55, %s, %%[vlane]
@@ -242,7 +243,6 @@ def tree_update(nb, store=True):
     v_and_b32 v61, 1, v61
     v_lshl_add_u32 v60, v60, 1, v58
     v_mul_u32_u24 v61, 0x7e1, v61
-    v_sub_u32 v61, 0x7e1, v61
     v_sub_u32 v61, v54, v61
     v_ashrrev_i32 v61, 5, v61
     v_sub_u32 v61, v54, v61
@@ -278,19 +278,19 @@ def len_decode(tag, base, lane_c, lane_c2):
     emit("s_lshl_b32 s92, s90, 4\ns_add_u32 s92, s92, %d\nv_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)"
          % ((base + LEN_LOW) * 2))
     walk(3, ["v41"])
-    emit("s_sub_u32 s89, s88, 8\ns_mov_b32 s96, 3\ns_branch %s" % L(tag + "end"))
+    emit("s_andn2_b32 s89, 7, s88\ns_mov_b32 s96, 3\ns_branch %s" % L(tag + "end"))
     label(tag + "c2")
     hbit_one(lane_c)
     hbit(lane_c2, L(tag + "hi"))
     emit("s_lshl_b32 s92, s90, 4\ns_add_u32 s92, s92, %d\nv_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)"
          % ((base + LEN_MID) * 2))
     walk(3, ["v42"])
-    emit("s_mov_b32 s89, s88\ns_mov_b32 s96, 3\ns_branch %s" % L(tag + "end"))
+    emit("s_xor_b32 s89, s88, 7\ns_mov_b32 s96, 3\ns_branch %s" % L(tag + "end"))
     label(tag + "hi")
     hbit_one(lane_c2)
     emit("s_movk_i32 s92, %d\nv_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)" % ((base + LEN_HIGH) * 2))
     walk(8, ["v43", "v44", "v45", "v46"])
-    emit("s_sub_u32 s89, s88, 240\ns_mov_b32 s96, 8")
+    emit("s_andn2_b32 s89, 0xff, s88\ns_add_u32 s89, s89, 16\ns_mov_b32 s96, 8")
     label(tag + "end")
 
 
@@ -365,7 +365,7 @@ def gen():
     # gather, this literal's model update, and the next packet's literal blocks (which may be
     # the very table just updated, hence after the update's store)
     emit("""
-    s_and_b32 %[prev], s88, 0xff
+    s_andn2_b32 %[prev], 0xff, s88
     v_mov_b32 v60, %[prev]
     v_mov_b32 v61, %[pos]
     global_store_byte v61, v60, %[outp]
@@ -386,35 +386,33 @@ def gen():
     # ------------------------------------------------------------- matched literal (:59-114)
     # The matched half of the literal coder lives in HBM (xlz_format.h): ONE gather fetches the
     # eight probabilities the walk meets as long as the decoded bits follow matchByte (lane k =
-    # level k: symbol (1 << k) | (mb >> (8 - k)), matchBit (mb >> (7 - k)) & 1).  At the first
+    # level k: tree slot (0x1ff ^ mb) >> (8 - k), matchBit (mb >> (7 - k)) & 1).  At the first
     # bit that differs the walk carries on in the plain table (:116-165), whose blocks are
     # already in v50..v53.  s98 = levels decided in the matched table.
     label("mlit")
     emit("""
     s_sub_u32 s83, s92, %d
     s_lshl_b32 s83, s83, 1
+    s_xor_b32 s89, %%[mb], 0x1ff
     v_min_u32 v55, 7, %%[vlane]
     v_sub_u32 v60, 8, v55
-    v_lshrrev_b32 v60, v60, %%[mb]
-    v_lshlrev_b32 v61, v55, 1
-    v_or_b32 v60, v60, v61
+    v_lshrrev_b32 v60, v60, s89
     v_sub_u32 v61, 7, v55
     v_lshrrev_b32 v61, v61, %%[mb]
     v_and_b32 v61, 1, v61
     v_lshl_or_b32 v60, v61, 8, v60
     v_lshl_add_u32 v57, v60, 1, s83
     global_load_ushort v54, v57, %%[mptr]
-    s_or_b32 s89, %%[mb], 0x100
     s_mov_b32 s88, 1
     v_mov_b32 v58, s92
     s_waitcnt vmcnt(0)
     """ % (P_LIT * 2))
     for k in range(8):
-        emit("v_readlane_b32 s86, v54, %d\ns_lshl1_add_u32 s85, s88, 1" % k)
+        emit("v_readlane_b32 s86, v54, %d" % k)
         walk_core()
-        emit("s_subb_u32 s88, s85, 0")
+        emit("s_addc_u32 s88, s88, s88")
         nchk()
-        if k < 7:  # still on matchByte's path?  s88 == (0x100 | mb) >> (7 - k)
+        if k < 7:  # still on matchByte's path?  s88 == (0x1ff ^ mb) >> (7 - k)  (complemented bits)
             emit("s_lshr_b32 s80, s89, %d\ns_cmp_lg_u32 s80, s88\ns_cbranch_scc1 %s" % (7 - k, L("mx%d" % (k + 1))))
     emit("s_mov_b32 s98, 8\ns_branch %s" % L("mlfin"))
     for k in range(1, 8):
@@ -423,7 +421,7 @@ def gen():
     walk(8, ["v50", "v51", "v52", "v53"], entries="pw")
     label("mlfin")
     emit("""
-    s_and_b32 %[prev], s88, 0xff
+    s_andn2_b32 %[prev], 0xff, s88
     v_mov_b32 v60, %[prev]
     v_mov_b32 v61, %[pos]
     global_store_byte v61, v60, %[outp]
@@ -469,7 +467,7 @@ def gen():
     emit("v_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)")
     walk(6, ["v36"])
     emit("""
-    s_sub_u32 s98, s88, 64
+    s_andn2_b32 s98, 63, s88
     s_cmp_lt_u32 s98, 4
     s_cbranch_scc0 %s
     s_mov_b32 %%[rep0], s98
@@ -498,7 +496,8 @@ def gen():
     label("rtdone")
     tree_update("s98")
     emit("""
-    s_brev_b32 s80, s88
+    s_not_b32 s80, s88
+    s_brev_b32 s80, s80
     s_sub_u32 s81, 32, s98
     s_lshr_b32 s80, s80, s81
     s_add_u32 %%[rep0], s93, s80
@@ -541,7 +540,7 @@ def gen():
     """ % (P_ALIGN * 2))
     walk(4, ["v35"])  # reverse tree over alignDecoderProbs (:579-625): M = 1 b0 b1 b2 b3
     tree_update(4)
-    emit("s_brev_b32 s80, s88\ns_lshr_b32 s80, s80, 28\ns_add_u32 %[rep0], s93, s80")
+    emit("s_not_b32 s80, s88\ns_brev_b32 s80, s80\ns_lshr_b32 s80, s80, 28\ns_add_u32 %[rep0], s93, s80")
     label("distdone")
     emit("""
     s_cmp_eq_u32 %%[rep0], -1
