@@ -494,7 +494,7 @@ enum : uint32_t { FX_LIMIT = 0, FX_ERR = 1, FX_MARKER = 2, FX_COPY = 3 };
 // Per-lane constants of the head gather: lane j fetches the j-th context-selected probability a
 // packet can start with; its LDS byte address is hc + state * hms + state2 * hm2.
 struct HeadVec {
-    uint32_t hc, hms, hm2;
+    uint32_t hc, hms, hm2, lit_next;
 };
 __device__ __forceinline__ HeadVec head_vectors(uint32_t lane)
 {
@@ -511,6 +511,7 @@ __device__ __forceinline__ HeadVec head_vectors(uint32_t lane)
                           : lane == 9 ? P_REP_LEN + LEN_CHOICE2
                                       : P_LEN + 2; // lanes 10..63: an unused slot (their v40 is stored too)
     h.hc = base * 2;
+    h.lit_next = upd_literal(lane < 12 ? lane : 0); // stateUpdateLiteral as a table: lane = old state
     h.hms = (lane >= 1 && lane <= 4) ? 2u : 0u; // indexed by state
     h.hm2 = (lane == 0 || lane == 5) ? 2u : 0u; // indexed by state2 = (state << 4) + posState
     return h;
@@ -521,6 +522,8 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_
                                                    uint32_t &lenout)
 {
     uint32_t exitc;
+    uint32_t vlpm; // lp_mask in a VGPR: the literal context is computed on the VALU
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vlpm) : "s"(d.lp_mask));
     asm volatile(
 #include "xlz_fastpath.inc"
         : [range] "+s"(d.range), [code] "+s"(d.code), [cur] "+s"(d.cur), [arel] "+s"(d.arel), [state] "+s"(d.state),
@@ -528,10 +531,11 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_
           [wpos] "+s"(d.wpos), [prev] "+s"(d.prev_byte), [mb] "+s"(d.match_byte), [exitc] "=&s"(exitc),
           [lenout] "=&s"(lenout)
         : [arel_lim] "s"(arel_lim), [pos_lim] "s"(pos_lim), [dict] "s"(d.dict_size), [pos_mask] "s"(d.pos_mask),
-          [lp_mask] "s"(d.lp_mask), [lc] "s"(d.lc), [wbase] "s"(d.wbase), [outp] "s"(out), [mptr] "s"(mprobs), [vin] "v"(d.vin),
-          [vlane] "v"(lane), [vhc] "v"(hv.hc), [vhms] "v"(hv.hms), [vhm2] "v"(hv.hm2)
+          [lc] "s"(d.lc), [lc8] "s"(8u - d.lc), [wbase] "s"(d.wbase), [outp] "s"(out), [mptr] "s"(mprobs),
+          [vin] "v"(d.vin), [vlane] "v"(lane), [vhc] "v"(hv.hc), [vhms] "v"(hv.hms), [vhm2] "v"(hv.hm2),
+          [vlitnext] "v"(hv.lit_next), [vlpm] "v"(vlpm)
         : "scc", "vcc", "memory", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
-          "s93", "s94", "s95", "s96", "s97", "s98", "v35", "v36", "v37", "v40", "v41", "v42", "v43", "v44", "v45", "v46",
+          "s93", "s94", "s95", "s96", "s97", "s98", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46",
           "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62",
           "v63");
     return exitc;

@@ -229,31 +229,28 @@ def walk(nbits, blocks, early_exit=None, entries=None):
                 fetch_level(k + 1, blocks)
 
 
-def tree_update(nb, store=True):
-    """Apply the model updates of a finished walk in ONE vector operation.  s88 = final index,
-    v54 lane k = probability seen at level k, v58 = byte address of the tree base.
+def tree_update(nb, base="v58", store=True):
+    """Apply the model updates of a finished walk in ONE vector operation.  s88 = final slot,
+    v54 lane k = probability seen at level k, `base` = byte address of the tree base.
     nb: int, or the name of an SGPR holding the level count.
     Lane k: slot = s88 >> (nb-k), !bit = (s88 >> (nb-k-1)) & 1  (s88 holds complemented bits),
-            new = p - ((p - (bit ? 0 : 2017)) >>a 5)   (decompress.go:30 / :177)."""
+            new = p - ((p - (bit ? 0 : 2017)) >>a 5)   (decompress.go:30 / :177).
+    Lanes >= nb store to the unused slot whose address is in v38."""
     emit("""
     v_sub_u32 v55, %s, %%[vlane]
     v_lshrrev_b32 v60, v55, s88
     v_add_u32 v61, -1, v55
     v_lshrrev_b32 v61, v61, s88
     v_and_b32 v61, 1, v61
-    v_lshl_add_u32 v60, v60, 1, v58
+    v_lshl_add_u32 v60, v60, 1, %s
     v_mul_u32_u24 v61, 0x7e1, v61
     v_sub_u32 v61, v54, v61
     v_ashrrev_i32 v61, 5, v61
     v_sub_u32 v61, v54, v61
-    """ % nb)
+    """ % (nb, base))
     if not store:
         return
-    if isinstance(nb, int):
-        emit("s_mov_b64 exec, %d" % ((1 << nb) - 1))
-    else:
-        emit("s_bfm_b64 exec, %s, 0" % nb)
-    emit("ds_write_b16 v60, v61\ns_mov_b64 exec, -1")
+    emit("v_cmp_gt_u32 vcc, %s, %%[vlane]\nv_cndmask_b32 v60, v38, v60, vcc\nds_write_b16 v60, v61" % nb)
 
 
 def len_prefetch(base):
@@ -294,31 +291,43 @@ def len_decode(tag, base, lane_c, lane_c2):
     label(tag + "end")
 
 
+wstubs = []
+
+
 def wpos_advance(amount):
-    emit("""
-    s_add_u32 %%[wpos], %%[wpos], %s
-    s_cmp_ge_u32 %%[wpos], %%[dict]
-    s_cselect_b32 s80, %%[dict], 0
-    s_sub_u32 %%[wpos], %%[wpos], s80
-    """ % amount)
+    """window.pos += amount with the wrap of window.go:38-41 out of line"""
+    uid[0] += 1
+    k = "w%d" % uid[0]
+    emit("s_add_u32 %%[wpos], %%[wpos], %s\ns_cmp_ge_u32 %%[wpos], %%[dict]\ns_cbranch_scc1 %s" % (amount, L(k)))
+    label(k + "b")
+    wstubs.append(k)
 
 
-def literal_context():
-    """literal table base -> s92 (decompress.go:56-57) and its four 64-prob blocks requested"""
+def emit_wstubs():
+    for k in wstubs:
+        label(k)
+        emit("s_sub_u32 %%[wpos], %%[wpos], %%[dict]\ns_branch %s" % L(k + "b"))
+
+
+def literal_context(prev_v=None):
+    """literal table base -> v39 (decompress.go:56-57; byte address in LDS) and its four 64-prob
+    blocks requested.  All on the VALU: the scalar port is the busy one.  prev_v = VGPR that
+    already holds prevByte."""
+    if prev_v is None:
+        emit("v_mov_b32 v55, %[prev]")
+        prev_v = "v55"
     emit("""
-    s_and_b32 s83, %%[wpos], %%[lp_mask]
-    s_lshl_b32 s83, s83, %%[lc]
-    s_sub_u32 s84, 8, %%[lc]
-    s_lshr_b32 s84, %%[prev], s84
-    s_add_u32 s83, s83, s84
-    s_lshl_b32 s83, s83, 9
-    s_add_u32 s92, s83, %d
-    v_add_u32 v59, s92, v56
+    v_and_b32 v57, %%[wpos], %%[vlpm]
+    v_lshlrev_b32 v57, %%[lc], v57
+    v_lshrrev_b32 v55, %%[lc8], %s
+    v_add_lshl_u32 v57, v57, v55, 9
+    v_add_u32 v39, %d, v57
+    v_add_u32 v59, v39, v56
     ds_read_u16 v50, v59
     ds_read_u16 v51, v59 offset:128
     ds_read_u16 v52, v59 offset:256
     ds_read_u16 v53, v59 offset:384
-    """ % (P_LIT * 2))
+    """ % (prev_v, P_LIT * 2))
 
 
 def head_issue(first=False):
@@ -336,13 +345,51 @@ def head_issue(first=False):
     """)
 
 
+def literal_tail():
+    """window.PutByte (:168), state (:171), then the next packet's head gather; the caller then
+    applies the model update and requests the next literal blocks (which may be the very table
+    just updated, hence after the update's store).  v62 = the byte."""
+    emit("""
+    s_andn2_b32 %[prev], 0xff, s88
+    v_mov_b32 v62, %[prev]
+    v_mov_b32 v61, %[pos]
+    global_store_byte v61, v62, %[outp]
+    s_add_u32 %[pos], %[pos], 1
+    """)
+    wpos_advance("1")
+    emit("v_readlane_b32 %[state], %[vlitnext], %[state]")  # stateUpdateLiteral as a 12-lane table
+    head_issue()
+
+
+def plain_literal():
+    """plain literal (:127-175) with its blocks in v50..v53 and base in v39; ends at pktl"""
+    walk(8, ["v50", "v51", "v52", "v53"])
+    literal_tail()
+    tree_update(8, base="v39")
+    literal_context(prev_v="v62")
+    emit("s_branch %s" % L("pktl"))
+
+
 def gen():
     # The gathers of packet n+1 are issued from the tail of packet n (software pipelining):
     # by the time the loop top has done its limit checks the probabilities have arrived.
-    emit("v_lshlrev_b32 v56, 1, %[vlane]\ns_mov_b32 s94, 0")
+    emit("v_lshlrev_b32 v56, 1, %%[vlane]\ns_mov_b32 s94, 0\nv_mov_b32 v38, %d" % ((P_LEN + 2) * 2))
     head_issue(first=True)
     literal_context()  # no copy is pending on entry: prevByte is valid
-    emit("s_mov_b32 s97, 1")
+    emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
+    # ------------------------------------------------------------- packet after a literal
+    # state < 7, no copy pending, literal blocks requested: the three tests of the general
+    # packet head are known
+    label("pktl")
+    emit("""
+    s_cmp_gt_u32 %%[arel], %%[arel_lim]
+    s_cbranch_scc1 %s
+    s_cmp_ge_u32 %%[pos], %%[pos_lim]
+    s_cbranch_scc1 %s
+    s_waitcnt lgkmcnt(0)
+    """ % (L("x0"), L("x0")))
+    hbit(H_IS_MATCH, L("match"))
+    plain_literal()
     # ------------------------------------------------------------- packet head
     label("pkt")
     emit("""
@@ -359,30 +406,8 @@ def gen():
     literal_context()
     emit("s_waitcnt lgkmcnt(0)")
     label("litready")
-    emit("s_cmp_ge_u32 %%[state], 7\ns_cbranch_scc1 %s\nv_mov_b32 v58, s92" % L("mlit"))
-    walk(8, ["v50", "v51", "v52", "v53"])
-    # tail of a plain literal: window.PutByte (:168), state (:171), then the next packet's head
-    # gather, this literal's model update, and the next packet's literal blocks (which may be
-    # the very table just updated, hence after the update's store)
-    emit("""
-    s_andn2_b32 %[prev], 0xff, s88
-    v_mov_b32 v60, %[prev]
-    v_mov_b32 v61, %[pos]
-    global_store_byte v61, v60, %[outp]
-    s_add_u32 %[pos], %[pos], 1
-    """)
-    wpos_advance("1")
-    emit("""
-    s_cmp_lt_u32 %[state], 10
-    s_cselect_b32 s80, 3, 6
-    s_sub_u32 s80, %[state], s80
-    s_cmp_lt_u32 %[state], 4
-    s_cselect_b32 %[state], 0, s80
-    """)
-    head_issue()
-    tree_update(8)
-    literal_context()
-    emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
+    emit("s_cmp_ge_u32 %%[state], 7\ns_cbranch_scc1 %s" % L("mlit"))
+    plain_literal()
     # ------------------------------------------------------------- matched literal (:59-114)
     # The matched half of the literal coder lives in HBM (xlz_format.h): ONE gather fetches the
     # eight probabilities the walk meets as long as the decoded bits follow matchByte (lane k =
@@ -391,8 +416,6 @@ def gen():
     # already in v50..v53.  s98 = levels decided in the matched table.
     label("mlit")
     emit("""
-    s_sub_u32 s83, s92, %d
-    s_lshl_b32 s83, s83, 1
     s_xor_b32 s89, %%[mb], 0x1ff
     v_min_u32 v55, 7, %%[vlane]
     v_sub_u32 v60, 8, v55
@@ -401,12 +424,12 @@ def gen():
     v_lshrrev_b32 v61, v61, %%[mb]
     v_and_b32 v61, 1, v61
     v_lshl_or_b32 v60, v61, 8, v60
-    v_lshl_add_u32 v57, v60, 1, s83
+    v_add_u32 v61, %d, v39
+    v_add_lshl_u32 v57, v60, v61, 1
     global_load_ushort v54, v57, %%[mptr]
     s_mov_b32 s88, 1
-    v_mov_b32 v58, s92
     s_waitcnt vmcnt(0)
-    """ % (P_LIT * 2))
+    """ % ((-P_LIT * 2) & 0xffffffff))
     for k in range(8):
         emit("v_readlane_b32 s86, v54, %d" % k)
         walk_core()
@@ -420,31 +443,20 @@ def gen():
         emit("s_mov_b32 s98, %d\ns_branch %s" % (k, L("pw%d" % k)))
     walk(8, ["v50", "v51", "v52", "v53"], entries="pw")
     label("mlfin")
+    literal_tail()
+    tree_update(8, base="v39", store=False)
+    # lanes < s98 -> matched table (HBM; the rest to its unused slot 0), lanes s98..7 -> plain table
     emit("""
-    s_andn2_b32 %[prev], 0xff, s88
-    v_mov_b32 v60, %[prev]
-    v_mov_b32 v61, %[pos]
-    global_store_byte v61, v60, %[outp]
-    s_add_u32 %[pos], %[pos], 1
-    """)
-    wpos_advance("1")
-    emit("""
-    s_cmp_lt_u32 %[state], 10
-    s_cselect_b32 s80, 3, 6
-    s_sub_u32 %[state], %[state], s80
-    """)
-    head_issue()
-    tree_update(8, store=False)  # lanes < s98 -> matched table (HBM), the rest -> plain table (LDS)
-    emit("""
-    s_bfm_b64 exec, s98, 0
+    v_cmp_gt_u32 vcc, s98, %[vlane]
+    v_cndmask_b32 v57, 0, v57, vcc
     global_store_short v57, v61, %[mptr]
-    s_sub_u32 s80, 8, s98
-    s_bfm_b64 exec, s80, s98
+    v_cndmask_b32 v60, v60, v38, vcc
+    v_cmp_gt_u32 vcc, 8, %[vlane]
+    v_cndmask_b32 v60, v38, v60, vcc
     ds_write_b16 v60, v61
-    s_mov_b64 exec, -1
     """)
-    literal_context()
-    emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
+    literal_context(prev_v="v62")
+    emit("s_branch %s" % L("pktl"))
     # ------------------------------------------------------------- match or rep
     label("match")
     hbit_one(H_IS_MATCH)
@@ -637,6 +649,7 @@ def gen():
     need_copy_done()
     emit("s_waitcnt lgkmcnt(0)\nds_write_b16 v47, v40\ns_waitcnt lgkmcnt(0)\ns_branch %s" % L("end"))
     emit_stubs()
+    emit_wstubs()
     emit_finish_blocks()
     label("end")
 
