@@ -523,7 +523,9 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_
 {
     uint32_t exitc;
     uint32_t vlpm; // lp_mask in a VGPR: the literal context is computed on the VALU
+    uint32_t vpm;  // pos_mask likewise (head gather addresses)
     asm volatile("v_mov_b32 %0, %1" : "=v"(vlpm) : "s"(d.lp_mask));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vpm) : "s"(d.pos_mask));
     asm volatile(
 #include "xlz_fastpath.inc"
         : [range] "+s"(d.range), [code] "+s"(d.code), [cur] "+s"(d.cur), [arel] "+s"(d.arel), [state] "+s"(d.state),
@@ -533,7 +535,7 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_
         : [arel_lim] "s"(arel_lim), [pos_lim] "s"(pos_lim), [dict] "s"(d.dict_size), [pos_mask] "s"(d.pos_mask),
           [lc] "s"(d.lc), [lc8] "s"(8u - d.lc), [wbase] "s"(d.wbase), [outp] "s"(out), [mptr] "s"(mprobs),
           [vin] "v"(d.vin), [vlane] "v"(lane), [vhc] "v"(hv.hc), [vhms] "v"(hv.hms), [vhm2] "v"(hv.hm2),
-          [vlitnext] "v"(hv.lit_next), [vlpm] "v"(vlpm)
+          [vlitnext] "v"(hv.lit_next), [vlpm] "v"(vlpm), [vpm] "v"(vpm)
         : "scc", "vcc", "memory", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
           "s93", "s94", "s95", "s96", "s97", "s98", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46",
           "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62",

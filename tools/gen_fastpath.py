@@ -272,20 +272,19 @@ def len_decode(tag, base, lane_c, lane_c2):
     """lenDecoder.Decode (len_decoder.go:34-60): raw length -> s89; the walked tree's update is
     left pending (s96 = its level count, v58 = its base, s88 / v54 = the walk)."""
     hbit(lane_c, L(tag + "c2"))
-    emit("s_lshl_b32 s92, s90, 4\ns_add_u32 s92, s92, %d\nv_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)"
+    emit("s_add_u32 s82, s92, %d\nv_mov_b32 v58, s82\ns_waitcnt lgkmcnt(0)"  # s92 = posState * 16 (len_prefetch)
          % ((base + LEN_LOW) * 2))
     walk(3, ["v41"])
     emit("s_andn2_b32 s89, 7, s88\ns_mov_b32 s96, 3\ns_branch %s" % L(tag + "end"))
     label(tag + "c2")
     hbit_one(lane_c)
     hbit(lane_c2, L(tag + "hi"))
-    emit("s_lshl_b32 s92, s90, 4\ns_add_u32 s92, s92, %d\nv_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)"
-         % ((base + LEN_MID) * 2))
+    emit("s_add_u32 s82, s92, %d\nv_mov_b32 v58, s82\ns_waitcnt lgkmcnt(0)" % ((base + LEN_MID) * 2))
     walk(3, ["v42"])
     emit("s_xor_b32 s89, s88, 7\ns_mov_b32 s96, 3\ns_branch %s" % L(tag + "end"))
     label(tag + "hi")
     hbit_one(lane_c2)
-    emit("s_movk_i32 s92, %d\nv_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)" % ((base + LEN_HIGH) * 2))
+    emit("v_mov_b32 v58, %d\ns_waitcnt lgkmcnt(0)" % ((base + LEN_HIGH) * 2))
     walk(8, ["v43", "v44", "v45", "v46"])
     emit("s_andn2_b32 s89, 0xff, s88\ns_add_u32 s89, s89, 16\ns_mov_b32 s96, 8")
     label(tag + "end")
@@ -331,16 +330,15 @@ def literal_context(prev_v=None):
 
 
 def head_issue(first=False):
-    """the finished packet's head probabilities go back to LDS; posState / state2 of the packet
-    about to start (-> s90, s91) and its head gather"""
+    """the finished packet's head probabilities go back to LDS; the head gather of the packet about
+    to start (addresses from its posState / state2, on the VALU)"""
     if not first:
         emit("ds_write_b16 v47, v40")
     emit("""
-    s_and_b32 s90, %[wpos], %[pos_mask]
-    s_lshl_b32 s91, %[state], 4
-    s_add_u32 s91, s91, s90
+    v_and_b32 v55, %[wpos], %[vpm]
+    v_lshl_add_u32 v55, %[state], 4, v55
     v_mad_u32_u24 v47, %[state], %[vhms], %[vhc]
-    v_mad_u32_u24 v47, s91, %[vhm2], v47
+    v_mad_u32_u24 v47, v55, %[vhm2], v47
     ds_read_u16 v40, v47
     """)
 
@@ -460,6 +458,7 @@ def gen():
     # ------------------------------------------------------------- match or rep
     label("match")
     hbit_one(H_IS_MATCH)
+    emit("s_and_b32 s90, %[wpos], %[pos_mask]")  # posState, for the length coders
     hbit(H_IS_REP, L("rep"))
     # simple match (:215-668)
     emit("s_mov_b32 %[rep3], %[rep2]\ns_mov_b32 %[rep2], %[rep1]\ns_mov_b32 %[rep1], %[rep0]")
@@ -547,8 +546,7 @@ def gen():
     s_andn2_b32 s84, s80, s84
     s_lshl_b32 s84, s84, 4
     s_add_u32 s93, s93, s84
-    s_movk_i32 s92, %d
-    v_mov_b32 v58, s92
+    v_mov_b32 v58, %d
     """ % (P_ALIGN * 2))
     walk(4, ["v35"])  # reverse tree over alignDecoderProbs (:579-625): M = 1 b0 b1 b2 b3
     tree_update(4)
