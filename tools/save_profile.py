@@ -7,9 +7,13 @@ os.makedirs(os.path.dirname(dest), exist_ok=True)
 shutil.copy(src + "/summary.md", dest + "_summary.md")
 shutil.copy(glob.glob(src + "/kt/*/*kernel_stats.csv")[0], dest + "_kernel_stats.csv")
 shutil.copy(src + "/kt.json", dest + "_benchline.json")
+with open(glob.glob(src + "/kt/*/*kernel_trace.csv")[0]) as f, open(dest + "_kernel_trace.csv", "w") as g:
+    for i, l in enumerate(f):
+        if i == 0 or "xlz_decode" in l:
+            g.write(l)
 rows = []
 vals = {}
-for sub in ("fetch", "write", "sq"):
+for sub in ("fetch", "write", "sq", "sq2"):
     for f in glob.glob(src + "/%s/*/*counter_collection.csv" % sub):
         for r in csv.DictReader(open(f)):
             if "xlz_decode" in r["Kernel_Name"]:

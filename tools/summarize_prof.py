@@ -21,6 +21,12 @@ print("\n## --kernel-trace --stats\n")
 print("| kernel | calls | total ns | avg ns | % |\n|---|---|---|---|---|")
 for r in kernel_rows("kt", "*kernel_stats.csv"):
     print("| %s | %s | %s | %.0f | %s |" % (r["Name"][:60], r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
+tr = kernel_rows("kt", "*kernel_trace.csv")
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in tr if "xlz_decode" in r["Kernel_Name"]]
+if d:
+    print("\nper launch of the decode kernel, in launch order (ms): %s -- the first is bench.py's untimed warm-up "
+          "(cold clocks / caches), the rest are the timed steps and agree with the HIP-event figure above; the "
+          "`--stats` average is over all of them." % ", ".join("%.2f" % x for x in d))
 print("\n## PMC (per launch of xlz_decode_kernel, summed over the device)\n")
 vals = collections.defaultdict(list)
 for sub in ("fetch", "write", "sq", "sq2"):
