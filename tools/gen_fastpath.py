@@ -27,15 +27,16 @@ How the 64 lanes are used (the wave is the register file of ONE decoder):
     slot 64b + j).  A tree level is then eight scalar instructions plus
     `v_readlane p, block, M`: the lane select IS the node index, so neither the decoded bit
     nor an LDS address is ever formed.  Blocks are requested well before they are walked.
-  * the probabilities met on a walk are parked in v54 (v_writelane) and updated together
-    in one vector operation (tree_update), lanes = levels.
+  * the probabilities met on a walk are found again in the block registers (ds_bpermute, the
+    slots of all levels follow from the final slot) and updated together in one vector
+    operation (tree_update), lanes = levels.
   * match copy: one byte per lane; its completion (store + prevByte/matchByte) is deferred
     behind the next packet's decode.
 
 Register conventions (fixed temporaries, declared as clobbers in xlz_kernel.hip):
-  s80,s81 core temps   s82,s83,s84,s85 temps   s86 P   s87 code - bound   s88 tree slot (1, then !bits)
+  s80 bound, s81 core temps   s82..s86 temps   s87 code - bound   s88 tree slot (1, then !bits)
   s89 LEN   s90 posState   s91 state2   s92 table base (bytes)   s93 dist
-  s94 copy pending   s95 its length   s96 levels of the walk awaiting its update
+  s94 copy pending   s95 its length
   s97 literal blocks prefetched   s98 posSlot / nbits
   v35 align block   v36 posSlot block   v37 posDecoders block   v40 head probabilities
   v41,v42 len low/mid blocks   v43..v46 len high blocks   v47 head addresses
@@ -74,30 +75,20 @@ def L(name):
     return ".L%s_%%=" % name
 
 
-def core():
-    """bound = (range >> 11) * p; the borrow of code - bound IS the decision (SCC).  Leaves
-    BIT in s87 and the updated probability p - ((p - k) >>a 5), k = bit ? 0 : 2017, in v63."""
-    emit("""
-    s_lshr_b32 s80, %[range], 11
-    s_mul_i32 s80, s80, s86
-    s_sub_u32 s81, %[range], s80
-    s_sub_u32 s87, %[code], s80
-    s_cselect_b32 %[range], s80, s81
-    s_cselect_b32 %[code], %[code], s87
-    s_cselect_b32 s81, 0x7e1, 0
-    s_cselect_b32 s87, 0, 1
-    s_sub_u32 s81, s86, s81
-    v_ashrrev_i32 v63, 5, s81
-    v_sub_u32 v63, s86, v63
-    """)
+def bound_of(src, lane):
+    """s80 = (range >> 11) * p for the probability in lane `lane` of VGPR `src`.  The product is
+    formed on the VALU for all 64 lanes at once and the lane select picks the BOUND: one scalar
+    instruction and one lane read, instead of a lane read plus two scalar instructions (the
+    scalar port is the bottleneck; a plain VALU op costs ~0.15 of a scalar slot)."""
+    # gfx940-family hazard: a v_readlane that reads a VGPR written by the VALU instruction right
+    # before it needs one wait state (the assembler does not insert it inside inline asm)
+    emit("s_lshr_b32 s80, %%[range], 11\nv_mul_u32_u24 v55, s80, %s\ns_nop 0\nv_readlane_b32 s80, v55, %s" % (src, lane))
 
 
-def walk_core():
-    """decision core of a tree level: range and code selected, SCC = (code < bound) kept for
-    the caller's s_addc that advances the tree index"""
+def decide():
+    """range and code selected from bound s80; SCC = (code < bound) = !bit is left for the caller
+    (s_addc that advances a tree index, or a branch)"""
     emit("""
-    s_lshr_b32 s80, %[range], 11
-    s_mul_i32 s80, s80, s86
     s_sub_u32 s81, %[range], s80
     s_sub_u32 s87, %[code], s80
     s_cselect_b32 %[range], s80, s81
@@ -105,12 +96,20 @@ def walk_core():
     """)
 
 
-def nchk():
-    """normalisation test; the stub is emitted out of line at the end of the block"""
+def nchk(prefix=None):
+    """normalisation test; the stub is emitted out of line at the end of the block.
+    prefix: a function that emits the first, range-only instructions of the NEXT decision
+    (s_lshr q / v_mul).  They are hoisted in front of the test, where they fill the wait state
+    their v_readlane needs; after a normalisation the stub returns in front of them."""
     uid[0] += 1
     k = "n%d" % uid[0]
-    emit("s_lshr_b32 s80, %%[range], 24\ns_cbranch_scc0 %s" % L(k))
-    label(k + "b")
+    if prefix:
+        label(k + "b")
+        prefix()
+        emit("s_lshr_b32 s81, %%[range], 24\ns_cbranch_scc0 %s" % L(k))
+    else:
+        emit("s_lshr_b32 s80, %%[range], 24\ns_cbranch_scc0 %s" % L(k))
+        label(k + "b")
     stubs.append(k)
 
 
@@ -172,15 +171,13 @@ def hbit(lane, one):
     """One decision on head probability `lane` (already in v40), both outcomes specialised: the
     borrow of code - bound is branched on directly.  Bit 0 falls through; bit 1 goes to label
     `one`, where the caller emits hbit_one(lane) first."""
+    bound_of("v40", lane)
     emit("""
-    v_readlane_b32 s86, v40, %d
-    s_lshr_b32 s80, %%[range], 11
-    s_mul_i32 s80, s80, s86
     s_sub_u32 s81, %%[range], s80
     s_sub_u32 s87, %%[code], s80
     s_cbranch_scc0 %s
     s_mov_b32 %%[range], s80
-    """ % (lane, one))
+    """ % one)
     head_update(lane, 0)
     nchk()
 
@@ -191,25 +188,105 @@ def hbit_one(lane):
     nchk()
 
 
-def fetch_level(k, blocks):
-    """probability of tree node s88 at level k (0-based) of an 8-level tree -> s86"""
+def level_prefix(k, blocks):
+    """range-only part of level k (0-based) of a tree walk: bounds of all slots of its block(s)"""
     if k <= 5:
-        emit("v_readlane_b32 s86, %s, s88" % blocks[0])
+        emit("s_lshr_b32 s80, %%[range], 11\nv_mul_u32_u24 v55, s80, %s" % blocks[0])
     elif k == 6:
-        emit("v_readlane_b32 s86, %s, s88" % blocks[1])
-    else:  # node 128..255: block 2 or 3 by bit 6 of M
-        emit("v_readlane_b32 s86, %s, s88\nv_readlane_b32 s84, %s, s88\ns_bitcmp1_b32 s88, 6\n"
-             "s_cselect_b32 s86, s84, s86" % (blocks[2], blocks[3]))
+        emit("s_lshr_b32 s80, %%[range], 11\nv_mul_u32_u24 v55, s80, %s" % blocks[1])
+    else:  # slot 128..255: block 2 or 3 by bit 6
+        emit("s_lshr_b32 s80, %%[range], 11\nv_mul_u32_u24 v55, s80, %s\nv_mul_u32_u24 v62, s80, %s"
+             % (blocks[2], blocks[3]))
+
+
+def level_pick(k):
+    """bound of slot s88 -> s80 (one instruction must separate this from level_prefix)"""
+    emit("v_readlane_b32 s80, v55, s88")
+    if k == 7:
+        emit("v_readlane_b32 s84, v62, s88\ns_bitcmp1_b32 s88, 6\ns_cselect_b32 s80, s84, s80")
 
 
 def walk(nbits, blocks, early_exit=None, entries=None):
     """Walk nbits levels of the bit tree whose 64-prob blocks are already in `blocks`
     (bit_tree_decoder.go:18-40).  s88 ends as 1 followed by the COMPLEMENTED decided bits (the tree
-    slot order of xlz_kernel.hip: tree_slot); the probability
-    of level k is parked in lane k of v54.  early_exit = (sgpr, label): leave after as many
+    slot order of xlz_kernel.hip: tree_slot).  Nothing is recorded: tree_update finds the
+    probabilities again in the block registers.  early_exit = (sgpr, label): leave after as many
     levels as the SGPR says (reverse tree over posDecoders, 1..5 levels).
     entries = label prefix: the walk is only ever entered at level k >= 1 through <prefix>k,
-    with s88 = the tree index reached so far."""
+    with s88 = the tree slot reached so far and level_prefix(k) done by the entering code."""
+    for k in range(nbits):
+        if entries:
+            if k == 0:
+                continue
+            label("%s%d" % (entries, k))
+        elif k == 0:
+            level_prefix(0, blocks)
+            emit("s_mov_b32 s88, 1")
+        level_pick(k)
+        decide()
+        emit("s_addc_u32 s88, s88, s88")  # J = 2J + SCC = 2J + !bit
+        if k + 1 < nbits:
+            nchk(prefix=lambda: level_prefix(k + 1, blocks))
+            if early_exit:
+                emit("s_cmp_eq_u32 %s, %d\ns_cbranch_scc1 %s" % (early_exit[0], k + 1, early_exit[1]))
+        else:
+            nchk()
+
+
+def tree_update(nb, blocks, base="v58"):
+    """Apply the model updates of a finished walk.  s88 = final slot (1, then the complemented
+    bits), `blocks` = the tree's block registers (lane j of block b = slot 64b + j), `base` = VGPR
+    with the byte address of the tree.  nb: int, or the name of an SGPR (single-block trees).
+    Every lane looks at its OWN slot: slot j at level l (v31 = l + 1) was visited iff
+    s88 >> (nb - l) == j, the decision taken there was !((s88 >> (nb - l - 1)) & 1), and the new
+    value is p - ((p - (bit ? 0 : 2017)) >>a 5) (decompress.go:30 / :177).  Pure VALU work on
+    registers that are already there -- nothing is recorded during the walk.  Only visited
+    slots are stored (a block register may overlap other tables and be stale there); the other
+    lanes store to the unused slot whose address is in v38.  Single-block trees."""
+    own = "v30"
+    emit("""
+    v_sub_u32 v55, %s, v31
+    v_lshrrev_b32 v61, v55, s88
+    v_lshrrev_b32 v60, 1, v61
+    v_cmp_eq_u32 vcc, v60, %s
+    v_and_b32 v61, 1, v61
+    v_mul_u32_u24 v61, 0x7e1, v61
+    v_sub_u32 v61, %s, v61
+    v_ashrrev_i32 v61, 5, v61
+    v_sub_u32 v61, %s, v61
+    v_add_u32 v60, %s, v56
+    v_cndmask_b32 v60, v38, v60, vcc
+    ds_write_b16 v60, v61
+    """ % (nb, own, blocks[0], blocks[0], base))
+    assert len(blocks) == 1
+
+
+# ---- 8-level trees (literal, high length): four blocks.  Here the per-slot update above would
+# be four vector passes and the VALU pipe becomes the bottleneck (measured: -15 % on literal-heavy
+# data), so these trees keep a record: the probability of level k is parked in lane k of v54
+# (v_writelane) and ONE vector operation, lanes = levels, updates them.
+
+def fetch_level(k, blocks):
+    """probability of tree slot s88 at level k (0-based) of an 8-level tree -> s86"""
+    if k <= 5:
+        emit("v_readlane_b32 s86, %s, s88" % blocks[0])
+    elif k == 6:
+        emit("v_readlane_b32 s86, %s, s88" % blocks[1])
+    else:  # slot 128..255: block 2 or 3 by bit 6
+        emit("v_readlane_b32 s86, %s, s88\nv_readlane_b32 s84, %s, s88\ns_bitcmp1_b32 s88, 6\n"
+             "s_cselect_b32 s86, s84, s86" % (blocks[2], blocks[3]))
+
+
+def level_rec():
+    """decision of a recorded level on the probability in s86"""
+    emit("s_lshr_b32 s80, %[range], 11\ns_mul_i32 s80, s80, s86")
+    decide()
+    emit("s_addc_u32 s88, s88, s88")
+
+
+def walk_rec(nbits, blocks, entries=None):
+    """walk() for the 8-level trees: also parks the probability of level k in lane k of v54.
+    entries = label prefix: entered at level k >= 1 through <prefix>k with s88 set."""
     if not entries:
         emit("s_mov_b32 s88, 1\nv_readlane_b32 s86, %s, 1" % blocks[0])
     for k in range(nbits):
@@ -219,25 +296,17 @@ def walk(nbits, blocks, early_exit=None, entries=None):
             label("%s%d" % (entries, k))
             fetch_level(k, blocks)
         emit("v_writelane_b32 v54, s86, %d" % k)
-        walk_core()
-        emit("s_addc_u32 s88, s88, s88")  # J = 2J + SCC = 2J + !bit (tree_slot order, xlz_kernel.hip)
+        level_rec()
         nchk()
-        if k + 1 < nbits:
-            if early_exit:
-                emit("s_cmp_eq_u32 %s, %d\ns_cbranch_scc1 %s" % (early_exit[0], k + 1, early_exit[1]))
-            if not entries:
-                fetch_level(k + 1, blocks)
+        if k + 1 < nbits and not entries:
+            fetch_level(k + 1, blocks)
 
 
-def tree_update(nb, base="v58", store=True):
-    """Apply the model updates of a finished walk in ONE vector operation.  s88 = final slot,
-    v54 lane k = probability seen at level k, `base` = byte address of the tree base.
-    nb: int, or the name of an SGPR holding the level count.
-    Lane k: slot = s88 >> (nb-k), !bit = (s88 >> (nb-k-1)) & 1  (s88 holds complemented bits),
-            new = p - ((p - (bit ? 0 : 2017)) >>a 5)   (decompress.go:30 / :177).
-    Lanes >= nb store to the unused slot whose address is in v38."""
+def tree_update_rec(nb, base, store=True):
+    """model updates of a walk_rec in ONE vector operation, lane k = level k: slot = s88 >> (nb-k),
+    !bit = (s88 >> (nb-k-1)) & 1, p = v54; lanes >= nb store to the unused slot (v38)."""
     emit("""
-    v_sub_u32 v55, %s, %%[vlane]
+    v_sub_u32 v55, %d, %%[vlane]
     v_lshrrev_b32 v60, v55, s88
     v_add_u32 v61, -1, v55
     v_lshrrev_b32 v61, v61, s88
@@ -248,9 +317,8 @@ def tree_update(nb, base="v58", store=True):
     v_ashrrev_i32 v61, 5, v61
     v_sub_u32 v61, v54, v61
     """ % (nb, base))
-    if not store:
-        return
-    emit("v_cmp_gt_u32 vcc, %s, %%[vlane]\nv_cndmask_b32 v60, v38, v60, vcc\nds_write_b16 v60, v61" % nb)
+    if store:
+        emit("v_cmp_gt_u32 vcc, %d, %%[vlane]\nv_cndmask_b32 v60, v38, v60, vcc\nds_write_b16 v60, v61" % nb)
 
 
 def len_prefetch(base):
@@ -268,25 +336,46 @@ def len_prefetch(base):
            (base + LEN_HIGH) * 2 + 256, (base + LEN_HIGH) * 2 + 384))
 
 
-def len_decode(tag, base, lane_c, lane_c2):
-    """lenDecoder.Decode (len_decoder.go:34-60): raw length -> s89; the walked tree's update is
-    left pending (s96 = its level count, v58 = its base, s88 / v54 = the walk)."""
+def posslot_request(static):
+    """posSlot block of lenState = min(len, 3) (decompress.go:433-441) requested into v36; s92 = its
+    tree base.  static: the length is >= 8, lenState is 3."""
+    if static:
+        emit("s_movk_i32 s92, %d" % ((P_POS_SLOT + 3 * 64) * 2))
+    else:
+        emit("s_min_u32 s83, s89, 3\ns_lshl_b32 s83, s83, 7\ns_add_u32 s92, s83, %d" % (P_POS_SLOT * 2))
+    emit("v_add_u32 v59, s92, v56\nds_read_u16 v36, v59")
+
+
+def len_decode(tag, base, lane_c, lane_c2, posslot):
+    """lenDecoder.Decode (len_decoder.go:34-60): raw length -> s89, the walked tree updated.
+    posslot: request the distance-slot block as soon as the length is known (simple match)."""
     hbit(lane_c, L(tag + "c2"))
     emit("s_add_u32 s82, s92, %d\nv_mov_b32 v58, s82\ns_waitcnt lgkmcnt(0)"  # s92 = posState * 16 (len_prefetch)
          % ((base + LEN_LOW) * 2))
     walk(3, ["v41"])
-    emit("s_andn2_b32 s89, 7, s88\ns_mov_b32 s96, 3\ns_branch %s" % L(tag + "end"))
+    emit("s_andn2_b32 s89, 7, s88")
+    if posslot:
+        posslot_request(False)
+    tree_update(3, ["v41"])
+    emit("s_branch %s" % L(tag + "end"))
     label(tag + "c2")
     hbit_one(lane_c)
     hbit(lane_c2, L(tag + "hi"))
     emit("s_add_u32 s82, s92, %d\nv_mov_b32 v58, s82\ns_waitcnt lgkmcnt(0)" % ((base + LEN_MID) * 2))
     walk(3, ["v42"])
-    emit("s_xor_b32 s89, s88, 7\ns_mov_b32 s96, 3\ns_branch %s" % L(tag + "end"))
+    emit("s_xor_b32 s89, s88, 7")
+    if posslot:
+        posslot_request(True)
+    tree_update(3, ["v42"])
+    emit("s_branch %s" % L(tag + "end"))
     label(tag + "hi")
     hbit_one(lane_c2)
     emit("v_mov_b32 v58, %d\ns_waitcnt lgkmcnt(0)" % ((base + LEN_HIGH) * 2))
-    walk(8, ["v43", "v44", "v45", "v46"])
-    emit("s_andn2_b32 s89, 0xff, s88\ns_add_u32 s89, s89, 16\ns_mov_b32 s96, 8")
+    walk_rec(8, ["v43", "v44", "v45", "v46"])
+    emit("s_andn2_b32 s89, 0xff, s88\ns_add_u32 s89, s89, 16")
+    if posslot:
+        posslot_request(True)
+    tree_update_rec(8, "v58")
     label(tag + "end")
 
 
@@ -343,15 +432,18 @@ def head_issue(first=False):
     """)
 
 
+LIT_BLOCKS = ["v50", "v51", "v52", "v53"]
+
+
 def literal_tail():
     """window.PutByte (:168), state (:171), then the next packet's head gather; the caller then
     applies the model update and requests the next literal blocks (which may be the very table
-    just updated, hence after the update's store).  v62 = the byte."""
+    just updated, hence after the update's store).  v32 = the byte."""
     emit("""
     s_andn2_b32 %[prev], 0xff, s88
-    v_mov_b32 v62, %[prev]
+    v_mov_b32 v32, %[prev]
     v_mov_b32 v61, %[pos]
-    global_store_byte v61, v62, %[outp]
+    global_store_byte v61, v32, %[outp]
     s_add_u32 %[pos], %[pos], 1
     """)
     wpos_advance("1")
@@ -361,10 +453,10 @@ def literal_tail():
 
 def plain_literal():
     """plain literal (:127-175) with its blocks in v50..v53 and base in v39; ends at pktl"""
-    walk(8, ["v50", "v51", "v52", "v53"])
+    walk_rec(8, LIT_BLOCKS)
     literal_tail()
-    tree_update(8, base="v39")
-    literal_context(prev_v="v62")
+    tree_update_rec(8, "v39")
+    literal_context(prev_v="v32")
     emit("s_branch %s" % L("pktl"))
 
 
@@ -372,6 +464,9 @@ def gen():
     # The gathers of packet n+1 are issued from the tail of packet n (software pipelining):
     # by the time the loop top has done its limit checks the probabilities have arrived.
     emit("v_lshlrev_b32 v56, 1, %%[vlane]\ns_mov_b32 s94, 0\nv_mov_b32 v38, %d" % ((P_LEN + 2) * 2))
+    # per-lane constants of tree_update: v31 = floor(log2(lane)) + 1, v30 = lane (lane 0: never a slot)
+    emit("v_ffbh_u32 v31, %[vlane]\nv_sub_u32 v31, 32, v31\nv_cmp_eq_u32 vcc, 0, %[vlane]\n"
+         "v_cndmask_b32 v30, %[vlane], -1, vcc")
     head_issue(first=True)
     literal_context()  # no copy is pending on entry: prevByte is valid
     emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
@@ -430,8 +525,7 @@ def gen():
     """ % ((-P_LIT * 2) & 0xffffffff))
     for k in range(8):
         emit("v_readlane_b32 s86, v54, %d" % k)
-        walk_core()
-        emit("s_addc_u32 s88, s88, s88")
+        level_rec()
         nchk()
         if k < 7:  # still on matchByte's path?  s88 == (0x1ff ^ mb) >> (7 - k)  (complemented bits)
             emit("s_lshr_b32 s80, s89, %d\ns_cmp_lg_u32 s80, s88\ns_cbranch_scc1 %s" % (7 - k, L("mx%d" % (k + 1))))
@@ -439,10 +533,10 @@ def gen():
     for k in range(1, 8):
         label("mx%d" % k)
         emit("s_mov_b32 s98, %d\ns_branch %s" % (k, L("pw%d" % k)))
-    walk(8, ["v50", "v51", "v52", "v53"], entries="pw")
+    walk_rec(8, LIT_BLOCKS, entries="pw")
     label("mlfin")
     literal_tail()
-    tree_update(8, base="v39", store=False)
+    tree_update_rec(8, "v39", store=False)
     # lanes < s98 -> matched table (HBM; the rest to its unused slot 0), lanes s98..7 -> plain table
     emit("""
     v_cmp_gt_u32 vcc, s98, %[vlane]
@@ -453,7 +547,7 @@ def gen():
     v_cndmask_b32 v60, v38, v60, vcc
     ds_write_b16 v60, v61
     """)
-    literal_context(prev_v="v62")
+    literal_context(prev_v="v32")
     emit("s_branch %s" % L("pktl"))
     # ------------------------------------------------------------- match or rep
     label("match")
@@ -464,18 +558,8 @@ def gen():
     emit("s_mov_b32 %[rep3], %[rep2]\ns_mov_b32 %[rep2], %[rep1]\ns_mov_b32 %[rep1], %[rep0]")
     len_prefetch(P_LEN)
     emit("ds_read_u16 v35, v56 offset:%d" % (P_ALIGN * 2))
-    len_decode("lm", P_LEN, H_LEN_C, H_LEN_C2)
-    emit("""
-    s_cmp_lt_u32 %%[state], 7
-    s_cselect_b32 %%[state], 7, 10
-    s_min_u32 s83, s89, 3
-    s_lshl_b32 s83, s83, 7
-    s_add_u32 s92, s83, %d
-    v_add_u32 v59, s92, v56
-    ds_read_u16 v36, v59
-    """ % (P_POS_SLOT * 2))
-    tree_update("s96")  # the length tree, while the posSlot block is on its way
-    emit("v_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)")
+    len_decode("lm", P_LEN, H_LEN_C, H_LEN_C2, posslot=True)  # leaves the posSlot block requested, s92 = its base
+    emit("s_cmp_lt_u32 %[state], 7\ns_cselect_b32 %[state], 7, 10\nv_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)")
     walk(6, ["v36"])
     emit("""
     s_andn2_b32 s98, 63, s88
@@ -483,7 +567,7 @@ def gen():
     s_cbranch_scc0 %s
     s_mov_b32 %%[rep0], s98
     """ % L("dist"))
-    tree_update(6)
+    tree_update(6, ["v36"])
     emit("s_branch %s" % L("distdone"))
     label("dist")
     emit("""
@@ -500,12 +584,12 @@ def gen():
     v_add_u32 v59, s92, v56
     ds_read_u16 v37, v59
     """ % (L("direct"), P_POS_DEC))
-    tree_update(6)  # posSlot tree, while the posDecoders block is on its way
+    tree_update(6, ["v36"])  # posSlot tree, while the posDecoders block is on its way
     # reverse bit tree over posDecoders (:495-546): s83 levels (1..5)
     emit("v_mov_b32 v58, s92\ns_mov_b32 s98, s83\ns_waitcnt lgkmcnt(0)")
     walk(5, ["v37"], early_exit=("s98", L("rtdone")))
     label("rtdone")
-    tree_update("s98")
+    tree_update("s98", ["v37"])
     emit("""
     s_not_b32 s80, s88
     s_brev_b32 s80, s80
@@ -515,7 +599,7 @@ def gen():
     s_branch %s
     """ % L("distdone"))
     label("direct")  # DecodeDirectBits (:549-577)
-    tree_update(6)  # posSlot tree
+    tree_update(6, ["v36"])  # posSlot tree
     # numDirectBits - 4 = s83 - 4 (2..26) halvings, unrolled; entered through a branch table so
     # that no loop counter is kept.  Exactly the reference's arithmetic: t = sign(code - range).
     # s84 collects the complemented bits (2 * acc + SCC).
@@ -549,7 +633,7 @@ def gen():
     v_mov_b32 v58, %d
     """ % (P_ALIGN * 2))
     walk(4, ["v35"])  # reverse tree over alignDecoderProbs (:579-625): M = 1 b0 b1 b2 b3
-    tree_update(4)
+    tree_update(4, ["v35"])
     emit("s_not_b32 s80, s88\ns_brev_b32 s80, s80\ns_lshr_b32 s80, s80, 28\ns_add_u32 %[rep0], s93, s80")
     label("distdone")
     emit("""
@@ -605,8 +689,7 @@ def gen():
     """)
     label("replen")
     len_prefetch(P_REP_LEN)
-    len_decode("lr", P_REP_LEN, H_REP_C, H_REP_C2)
-    tree_update("s96")
+    len_decode("lr", P_REP_LEN, H_REP_C, H_REP_C2, posslot=False)
     emit("s_cmp_lt_u32 %[state], 7\ns_cselect_b32 %[state], 8, 11\ns_add_u32 s89, s89, 2")
     # ------------------------------------------------------------- window.CopyMatch (window.go:55-87)
     label("copy")
