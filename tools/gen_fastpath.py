@@ -96,13 +96,16 @@ def decide():
     """)
 
 
-def nchk(prefix=None):
+def nchk(prefix=None, code_v=None):
     """normalisation test; the stub is emitted out of line at the end of the block.
     prefix: a function that emits the first, range-only instructions of the NEXT decision
     (s_lshr q / v_mul).  They are hoisted in front of the test, where they fill the wait state
-    their v_readlane needs; after a normalisation the stub returns in front of them."""
+    their v_readlane needs; after a normalisation the stub returns in front of them.
+    code_v: the code is (wave-uniform) in this VGPR instead of its SGPR (direct bits)."""
     uid[0] += 1
     k = "n%d" % uid[0]
+    if code_v:
+        vstubs[k] = code_v
     if prefix:
         label(k + "b")
         prefix()
@@ -113,14 +116,23 @@ def nchk(prefix=None):
     stubs.append(k)
 
 
+vstubs = {}
+
+
 def emit_stubs():
     for k in stubs:
         label(k)
+        if k in vstubs:
+            emit("s_lshl_b32 %%[range], %%[range], 8\ns_and_b32 s80, %%[cur], 0xff\nv_lshl_or_b32 %s, %s, 8, s80"
+                 % (vstubs[k], vstubs[k]))
+        else:
+            emit("""
+            s_lshl_b32 %[range], %[range], 8
+            s_lshl_b32 %[code], %[code], 8
+            s_and_b32 s80, %[cur], 0xff
+            s_or_b32 %[code], %[code], s80
+            """)
         emit("""
-        s_lshl_b32 %%[range], %%[range], 8
-        s_lshl_b32 %%[code], %%[code], 8
-        s_and_b32 s80, %%[cur], 0xff
-        s_or_b32 %%[code], %%[code], s80
         s_lshr_b32 %%[cur], %%[cur], 8
         s_add_u32 %%[arel], %%[arel], 1
         s_and_b32 s80, %%[arel], 3
@@ -602,29 +614,34 @@ def gen():
     tree_update(6, ["v36"])  # posSlot tree
     # numDirectBits - 4 = s83 - 4 (2..26) halvings, unrolled; entered through a branch table so
     # that no loop counter is kept.  Exactly the reference's arithmetic: t = sign(code - range).
-    # s84 collects the complemented bits (2 * acc + SCC).
+    # Only the range stays on the scalar side (its normalisation test needs SCC): the code (v34)
+    # and the collected, complemented bits (v33 = 2 * acc + (t < 0)) are wave-uniform VGPR values,
+    # four VALU instructions per bit instead of four scalar ones.
     emit("""
     s_getpc_b64 s[80:81]
-    s_sub_u32 s82, 35, s83
+    s_sub_u32 s82, 36, s83
     s_lshl2_add_u32 s80, s82, s80
     s_addc_u32 s81, s81, 0
-    s_mov_b32 s84, 0
+    v_mov_b32 v33, 0
+    v_mov_b32 v34, %[code]
     s_setpc_b64 s[80:81]
-    """)  # s_getpc returns the address of the s_sub; the table starts 5 instructions (all 4 bytes) later:
-    # entry e = 26 - (s83 - 4) is at +4 * (e + 5) = 4 * (35 - s83)
+    """)  # s_getpc returns the address of the s_sub; the table starts 6 instructions (all 4 bytes) later:
+    # entry e = 26 - (s83 - 4) is at +4 * (e + 6) = 4 * (36 - s83)
     for k in range(26, 0, -1):
         emit("s_branch %s" % L("db%d" % k))
     for k in range(26, 0, -1):
         label("db%d" % k)
         emit("""
         s_lshr_b32 %[range], %[range], 1
-        s_sub_u32 s81, %[code], %[range]
-        s_cmp_lt_i32 s81, 0
-        s_cselect_b32 %[code], %[code], s81
-        s_addc_u32 s84, s84, s84
+        v_subrev_u32 v55, %[range], v34
+        v_cmp_gt_i32 vcc, 0, v55
+        v_cndmask_b32 v34, v55, v34, vcc
+        v_addc_co_u32 v33, vcc, v33, v33, vcc
         """)
-        nchk()
+        nchk(code_v="v34")
     emit("""
+    v_readfirstlane_b32 %%[code], v34
+    v_readfirstlane_b32 s84, v33
     s_sub_u32 s83, s83, 4
     s_bfm_b32 s80, s83, 0
     s_andn2_b32 s84, s80, s84
@@ -636,18 +653,16 @@ def gen():
     tree_update(4, ["v35"])
     emit("s_not_b32 s80, s88\ns_brev_b32 s80, s80\ns_lshr_b32 s80, s80, 28\ns_add_u32 %[rep0], s93, s80")
     label("distdone")
+    # :633-653 in one test.  rep0 is valid iff rep0 < dictSize and (window full or rep0 <= window.pos);
+    # while the window is not full window.pos = pos - wbase < dictSize, so both say
+    # rep0 <= min(pos - wbase, dictSize - 1).  The end marker (rep0 = 0xFFFFFFFF) fails it too
+    # and is told apart out of line.
     emit("""
-    s_cmp_eq_u32 %%[rep0], -1
-    s_cbranch_scc1 %s
-    s_cmp_ge_u32 %%[rep0], %%[dict]
-    s_cbranch_scc1 %s
     s_sub_u32 s80, %%[pos], %%[wbase]
-    s_cmp_ge_u32 s80, %%[dict]
-    s_cbranch_scc1 %s
-    s_cmp_le_u32 %%[rep0], %%[wpos]
+    s_min_u32 s80, s80, %%[dictm1]
+    s_cmp_le_u32 %%[rep0], s80
     s_cbranch_scc0 %s
-    """ % (L("x2"), L("x1"), L("dok"), L("x1")))
-    label("dok")
+    """ % L("dbad"))
     emit("s_add_u32 s89, s89, 2\ns_branch %s" % L("copy"))
     # ------------------------------------------------------------- rep match (:685-1123)
     label("rep")
@@ -693,18 +708,17 @@ def gen():
     emit("s_cmp_lt_u32 %[state], 7\ns_cselect_b32 %[state], 8, 11\ns_add_u32 s89, s89, 2")
     # ------------------------------------------------------------- window.CopyMatch (window.go:55-87)
     label("copy")
+    # done here if len < 64, len < distance (no overlap) and the source lies inside the window's
+    # bytes; one test: the distance, or "too far" when the first two fail, against pos - wbase
     emit("""
     s_add_u32 s93, %%[rep0], 1
-    s_cmp_eq_u32 s93, 0
-    s_cselect_b32 s93, %%[dict], s93
-    s_cmp_ge_u32 s89, 64
-    s_cbranch_scc1 %s
-    s_cmp_le_u32 s93, s89
-    s_cbranch_scc1 %s
-    s_sub_u32 s80, %%[pos], %%[wbase]
-    s_cmp_lt_u32 s80, s93
-    s_cbranch_scc1 %s
-    """ % (L("x3"), L("x3"), L("x3")))
+    s_min_u32 s80, s93, 64
+    s_cmp_lt_u32 s89, s80
+    s_cselect_b32 s80, s93, -1
+    s_sub_u32 s81, %%[pos], %%[wbase]
+    s_cmp_le_u32 s80, s81
+    s_cbranch_scc0 %s
+    """ % L("x3"))
     need_copy_done()  # the new source may overlap the bytes the pending copy still has to store
     emit("""
     v_add_u32 v48, %[pos], %[vlane]
@@ -718,6 +732,8 @@ def gen():
     head_issue()  # next packet's head gather; its literal blocks wait for the copy (prevByte)
     emit("s_mov_b32 s97, 0\ns_branch %s" % L("pkt"))
     # ------------------------------------------------------------- exits
+    label("dbad")
+    emit("s_cmp_eq_u32 %%[rep0], -1\ns_cbranch_scc1 %s\ns_branch %s" % (L("x2"), L("x1")))
     label("x3")
     emit("s_mov_b32 %%[lenout], s89\ns_mov_b32 %%[exitc], 3\ns_branch %s" % L("fin"))
     label("x2")
