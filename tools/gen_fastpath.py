@@ -75,14 +75,13 @@ def L(name):
     return ".L%s_%%=" % name
 
 
-def bound_of(src, lane):
-    """s80 = (range >> 11) * p for the probability in lane `lane` of VGPR `src`.  The product is
-    formed on the VALU for all 64 lanes at once and the lane select picks the BOUND: one scalar
-    instruction and one lane read, instead of a lane read plus two scalar instructions (the
-    scalar port is the bottleneck; a plain VALU op costs ~0.15 of a scalar slot)."""
-    # gfx940-family hazard: a v_readlane that reads a VGPR written by the VALU instruction right
-    # before it needs one wait state (the assembler does not insert it inside inline asm)
-    emit("s_lshr_b32 s80, %%[range], 11\nv_mul_u32_u24 v55, s80, %s\ns_nop 0\nv_readlane_b32 s80, v55, %s" % (src, lane))
+def bounds(src, dst="v55"):
+    """dst = (range >> 11) * p for all 64 probabilities of VGPR `src` -- entirely on the VALU (the
+    scalar port is the bottleneck).  The lane select of a later v_readlane then picks the BOUND.
+    gfx940-family hazard: that v_readlane must not be the very next instruction (one wait state
+    between a VALU write of a VGPR and a v_readlane of it; the assembler does not insert it
+    inside inline asm) -- callers put independent work in between."""
+    emit("v_lshrrev_b32 %s, 11, %%[range]\nv_mul_u32_u24 %s, %s, %s" % (dst, dst, dst, src))
 
 
 def decide():
@@ -179,36 +178,42 @@ def head_update(lane, bit):
     emit("v_sub_u32 v63, v40, v63\nv_cmp_eq_u32 vcc, %d, %%[vlane]\nv_cndmask_b32 v40, v40, v63, vcc" % lane)
 
 
-def hbit(lane, one):
+def hbit(lane, one, prefixed=False, filler=None, next_head=None):
     """One decision on head probability `lane` (already in v40), both outcomes specialised: the
     borrow of code - bound is branched on directly.  Bit 0 falls through; bit 1 goes to label
-    `one`, where the caller emits hbit_one(lane) first."""
-    bound_of("v40", lane)
+    `one`, where the caller emits hbit_one(lane) first.
+    prefixed: bounds("v40") was already emitted (hoisted in front of the previous normalisation
+    test); filler: instructions to put between bounds() and the lane read; next_head: the bit-0
+    path continues with another head decision, whose bounds() is hoisted likewise."""
+    if not prefixed:
+        bounds("v40")
+        emit(filler if filler else "s_nop 0")
     emit("""
+    v_readlane_b32 s80, v55, %d
     s_sub_u32 s81, %%[range], s80
     s_sub_u32 s87, %%[code], s80
     s_cbranch_scc0 %s
     s_mov_b32 %%[range], s80
-    """ % one)
+    """ % (lane, one))
     head_update(lane, 0)
-    nchk()
+    nchk(prefix=(lambda: bounds("v40")) if next_head else None)
 
 
-def hbit_one(lane):
+def hbit_one(lane, next_head=False):
     emit("s_mov_b32 %[code], s87\ns_mov_b32 %[range], s81")
     head_update(lane, 1)
-    nchk()
+    nchk(prefix=(lambda: bounds("v40")) if next_head else None)
 
 
 def level_prefix(k, blocks):
     """range-only part of level k (0-based) of a tree walk: bounds of all slots of its block(s)"""
     if k <= 5:
-        emit("s_lshr_b32 s80, %%[range], 11\nv_mul_u32_u24 v55, s80, %s" % blocks[0])
+        bounds(blocks[0])
     elif k == 6:
-        emit("s_lshr_b32 s80, %%[range], 11\nv_mul_u32_u24 v55, s80, %s" % blocks[1])
+        bounds(blocks[1])
     else:  # slot 128..255: block 2 or 3 by bit 6
-        emit("s_lshr_b32 s80, %%[range], 11\nv_mul_u32_u24 v55, s80, %s\nv_mul_u32_u24 v62, s80, %s"
-             % (blocks[2], blocks[3]))
+        bounds(blocks[2])
+        bounds(blocks[3], dst="v62")
 
 
 def level_pick(k):
@@ -361,7 +366,7 @@ def posslot_request(static):
 def len_decode(tag, base, lane_c, lane_c2, posslot):
     """lenDecoder.Decode (len_decoder.go:34-60): raw length -> s89, the walked tree updated.
     posslot: request the distance-slot block as soon as the length is known (simple match)."""
-    hbit(lane_c, L(tag + "c2"))
+    hbit(lane_c, L(tag + "c2"), prefixed=True)  # bounds("v40") came before len_prefetch
     emit("s_add_u32 s82, s92, %d\nv_mov_b32 v58, s82\ns_waitcnt lgkmcnt(0)"  # s92 = posState * 16 (len_prefetch)
          % ((base + LEN_LOW) * 2))
     walk(3, ["v41"])
@@ -371,8 +376,8 @@ def len_decode(tag, base, lane_c, lane_c2, posslot):
     tree_update(3, ["v41"])
     emit("s_branch %s" % L(tag + "end"))
     label(tag + "c2")
-    hbit_one(lane_c)
-    hbit(lane_c2, L(tag + "hi"))
+    hbit_one(lane_c, next_head=True)
+    hbit(lane_c2, L(tag + "hi"), prefixed=True)
     emit("s_add_u32 s82, s92, %d\nv_mov_b32 v58, s82\ns_waitcnt lgkmcnt(0)" % ((base + LEN_MID) * 2))
     walk(3, ["v42"])
     emit("s_xor_b32 s89, s88, 7")
@@ -486,25 +491,27 @@ def gen():
     # state < 7, no copy pending, literal blocks requested: the three tests of the general
     # packet head are known
     label("pktl")
+    emit("s_waitcnt lgkmcnt(0)")
+    bounds("v40")
     emit("""
     s_cmp_gt_u32 %%[arel], %%[arel_lim]
     s_cbranch_scc1 %s
     s_cmp_ge_u32 %%[pos], %%[pos_lim]
     s_cbranch_scc1 %s
-    s_waitcnt lgkmcnt(0)
     """ % (L("x0"), L("x0")))
-    hbit(H_IS_MATCH, L("match"))
+    hbit(H_IS_MATCH, L("match"), prefixed=True)
     plain_literal()
     # ------------------------------------------------------------- packet head
     label("pkt")
+    emit("s_waitcnt lgkmcnt(0)")
+    bounds("v40")
     emit("""
     s_cmp_gt_u32 %%[arel], %%[arel_lim]
     s_cbranch_scc1 %s
     s_cmp_ge_u32 %%[pos], %%[pos_lim]
     s_cbranch_scc1 %s
-    s_waitcnt lgkmcnt(0)
     """ % (L("x0"), L("x0")))
-    hbit(H_IS_MATCH, L("match"))
+    hbit(H_IS_MATCH, L("match"), prefixed=True)
     # ------------------------------------------------------------- literal (decompress.go:44-175)
     need_copy_done()
     emit("s_cmp_lg_u32 s97, 0\ns_cbranch_scc1 %s" % L("litready"))
@@ -563,10 +570,11 @@ def gen():
     emit("s_branch %s" % L("pktl"))
     # ------------------------------------------------------------- match or rep
     label("match")
-    hbit_one(H_IS_MATCH)
+    hbit_one(H_IS_MATCH, next_head=True)
     emit("s_and_b32 s90, %[wpos], %[pos_mask]")  # posState, for the length coders
-    hbit(H_IS_REP, L("rep"))
+    hbit(H_IS_REP, L("rep"), prefixed=True)
     # simple match (:215-668)
+    bounds("v40")  # for the length coder's first decision
     emit("s_mov_b32 %[rep3], %[rep2]\ns_mov_b32 %[rep2], %[rep1]\ns_mov_b32 %[rep1], %[rep0]")
     len_prefetch(P_LEN)
     emit("ds_read_u16 v35, v56 offset:%d" % (P_ALIGN * 2))
@@ -666,10 +674,10 @@ def gen():
     emit("s_add_u32 s89, s89, 2\ns_branch %s" % L("copy"))
     # ------------------------------------------------------------- rep match (:685-1123)
     label("rep")
-    hbit_one(H_IS_REP)
+    hbit_one(H_IS_REP, next_head=True)
     emit("s_cmp_eq_u32 %%[pos], %%[wbase]\ns_cbranch_scc1 %s" % L("x1"))
-    hbit(H_G0, L("g1"))
-    hbit(H_REP0_LONG, L("r0long"))
+    hbit(H_G0, L("g1"), prefixed=True, next_head=True)
+    hbit(H_REP0_LONG, L("r0long"), prefixed=True)
     emit("""
     s_cmp_lt_u32 %%[state], 7
     s_cselect_b32 %%[state], 9, 11
@@ -680,12 +688,12 @@ def gen():
     hbit_one(H_REP0_LONG)
     emit("s_branch %s" % L("replen"))
     label("g1")
-    hbit_one(H_G0)
-    hbit(H_G1, L("g2"))
+    hbit_one(H_G0, next_head=True)
+    hbit(H_G1, L("g2"), prefixed=True)
     emit("s_mov_b32 s80, %%[rep1]\ns_mov_b32 %%[rep1], %%[rep0]\ns_mov_b32 %%[rep0], s80\ns_branch %s" % L("replen"))
     label("g2")
-    hbit_one(H_G1)
-    hbit(H_G2, L("g3"))
+    hbit_one(H_G1, next_head=True)
+    hbit(H_G2, L("g3"), prefixed=True)
     emit("""
     s_mov_b32 s80, %%[rep2]
     s_mov_b32 %%[rep2], %%[rep1]
@@ -703,6 +711,7 @@ def gen():
     s_mov_b32 %[rep0], s80
     """)
     label("replen")
+    bounds("v40")
     len_prefetch(P_REP_LEN)
     len_decode("lr", P_REP_LEN, H_REP_C, H_REP_C2, posslot=False)
     emit("s_cmp_lt_u32 %[state], 7\ns_cselect_b32 %[state], 8, 11\ns_add_u32 s89, s89, 2")
