@@ -539,13 +539,17 @@ def gen():
     v_add_u32 v61, %d, v39
     v_add_lshl_u32 v57, v60, v61, 1
     global_load_ushort v54, v57, %%[mptr]
-    s_mov_b32 s88, 1
     s_waitcnt vmcnt(0)
     """ % ((-P_LIT * 2) & 0xffffffff))
+    # matched levels: the eight candidate probabilities are lanes 0..7 of v54, so the bound of
+    # level k is lane k of the VALU product (no record needed: v54 itself is the record)
+    bounds("v54")
+    emit("s_mov_b32 s88, 1")
     for k in range(8):
-        emit("v_readlane_b32 s86, v54, %d" % k)
-        level_rec()
-        nchk()
+        emit("v_readlane_b32 s80, v55, %d" % k)
+        decide()
+        emit("s_addc_u32 s88, s88, s88")
+        nchk(prefix=(lambda: bounds("v54")) if k < 7 else None)
         if k < 7:  # still on matchByte's path?  s88 == (0x1ff ^ mb) >> (7 - k)  (complemented bits)
             emit("s_lshr_b32 s80, s89, %d\ns_cmp_lg_u32 s80, s88\ns_cbranch_scc1 %s" % (7 - k, L("mx%d" % (k + 1))))
     emit("s_mov_b32 s98, 8\ns_branch %s" % L("mlfin"))
