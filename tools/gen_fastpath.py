@@ -45,6 +45,9 @@ Register conventions (fixed temporaries, declared as clobbers in xlz_kernel.hip)
   v60..v63 temps
 """
 import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 # probability-table layout: must match xlz_format.h (checked by static_asserts in the .hip)
 P_IS_MATCH, P_IS_REP, P_IS_REP_G0, P_IS_REP_G1, P_IS_REP_G2, P_IS_REP0_LONG = 0, 192, 204, 216, 228, 240
@@ -85,53 +88,51 @@ def bounds(src, dst="v55"):
 
 
 def decide():
-    """range and code selected from bound s80; SCC = (code < bound) = !bit is left for the caller
-    (s_addc that advances a tree index, or a branch)"""
+    """One decision against bound s80.  The CODE lives in v29 (wave-uniform) for the whole loop:
+    one subtract with borrow-out gives code - bound and VCC = (code < bound), an unsigned min
+    selects the new code; the scalar side only keeps what steers control: the range and
+    SCC = (code < bound) = !bit, which the caller uses next (s_addc that advances a tree slot)."""
     emit("""
     s_sub_u32 s81, %[range], s80
-    s_sub_u32 s87, %[code], s80
+    v_subrev_co_u32 v28, vcc, s80, v29
+    s_cmp_lg_u32 vcc_lo, 0
+    v_min_u32 v29, v29, v28
     s_cselect_b32 %[range], s80, s81
-    s_cselect_b32 %[code], %[code], s87
     """)
 
 
-def nchk(prefix=None, code_v=None):
+def nchk(prefix=None, pick=None, mid=None):
     """normalisation test; the stub is emitted out of line at the end of the block.
-    prefix: a function that emits the first, range-only instructions of the NEXT decision
-    (s_lshr q / v_mul).  They are hoisted in front of the test, where they fill the wait state
-    their v_readlane needs; after a normalisation the stub returns in front of them.
-    code_v: the code is (wave-uniform) in this VGPR instead of its SGPR (direct bits)."""
+    prefix / pick: functions that emit the first instructions of the NEXT decision -- the
+    range-only VALU product (bounds) and the lane read of its bound.  They are hoisted in front of
+    the branch: the product, the test's s_lshr, the lane read, the branch -- which gives every
+    gfx950 wait state (tools/hazards.py) for free.  After a normalisation the stub returns in
+    front of them."""
     uid[0] += 1
     k = "n%d" % uid[0]
-    if code_v:
-        vstubs[k] = code_v
     if prefix:
         label(k + "b")
         prefix()
-        emit("s_lshr_b32 s81, %%[range], 24\ns_cbranch_scc0 %s" % L(k))
+        emit("s_lshr_b32 s81, %[range], 24")
+        if pick:
+            pick()
+        emit("s_cbranch_scc0 %s" % L(k))
     else:
-        emit("s_lshr_b32 s80, %%[range], 24\ns_cbranch_scc0 %s" % L(k))
+        emit("s_lshr_b32 s80, %[range], 24")
+        if mid:  # VALU instructions of the caller between test and branch (SCC is kept)
+            emit(mid)
+        emit("s_cbranch_scc0 %s" % L(k))
         label(k + "b")
     stubs.append(k)
-
-
-vstubs = {}
 
 
 def emit_stubs():
     for k in stubs:
         label(k)
-        if k in vstubs:
-            emit("s_lshl_b32 %%[range], %%[range], 8\ns_and_b32 s80, %%[cur], 0xff\nv_lshl_or_b32 %s, %s, 8, s80"
-                 % (vstubs[k], vstubs[k]))
-        else:
-            emit("""
-            s_lshl_b32 %[range], %[range], 8
-            s_lshl_b32 %[code], %[code], 8
-            s_and_b32 s80, %[cur], 0xff
-            s_or_b32 %[code], %[code], s80
-            """)
         emit("""
+        s_lshl_b32 %%[range], %%[range], 8
+        s_and_b32 s80, %%[cur], 0xff
+        v_lshl_or_b32 v29, v29, 8, s80
         s_lshr_b32 %%[cur], %%[cur], 8
         s_add_u32 %%[arel], %%[arel], 1
         s_and_b32 s80, %%[arel], 3
@@ -171,38 +172,48 @@ def head_update(lane, bit):
     """new value of head probability `lane` (decompress.go:30 / :177), VALU only: the lanes of v40
     all compute it from their own value, lane `lane` keeps it.  v40 goes back to LDS in one
     store when the packet is over (head_issue / exit)."""
+    emit("v_cmp_eq_u32 vcc, %d, %%[vlane]" % lane)
     if bit == 0:
         emit("v_add_u32 v63, 0xfffff81f, v40\nv_ashrrev_i32 v63, 5, v63")
     else:
         emit("v_ashrrev_i32 v63, 5, v40")
-    emit("v_sub_u32 v63, v40, v63\nv_cmp_eq_u32 vcc, %d, %%[vlane]\nv_cndmask_b32 v40, v40, v63, vcc" % lane)
+    emit("v_sub_u32 v63, v40, v63\nv_cndmask_b32 v40, v40, v63, vcc")
 
 
-def hbit(lane, one, prefixed=False, filler=None, next_head=None):
-    """One decision on head probability `lane` (already in v40), both outcomes specialised: the
-    borrow of code - bound is branched on directly.  Bit 0 falls through; bit 1 goes to label
-    `one`, where the caller emits hbit_one(lane) first.
-    prefixed: bounds("v40") was already emitted (hoisted in front of the previous normalisation
-    test); filler: instructions to put between bounds() and the lane read; next_head: the bit-0
-    path continues with another head decision, whose bounds() is hoisted likewise."""
-    if not prefixed:
+def head_pick(lane):
+    return lambda: emit("v_readlane_b32 s80, v55, %d" % lane)
+
+
+def hbit(lane, one, stage=0, next_head=None):
+    """One decision on head probability `lane` (already in v40), both outcomes specialised: VCC of
+    the compare is branched on directly.  Bit 0 falls through; bit 1 goes to label `one`, where
+    the caller emits hbit_one(lane) first.
+    stage: what the code in front already did for this decision -- 0 nothing, 1 bounds("v40"),
+    2 also the lane read of the bound (both hoisted in front of the previous normalisation test).
+    next_head: lane of the head decision the bit-0 path continues with (hoisted likewise)."""
+    if stage < 1:
         bounds("v40")
-        emit(filler if filler else "s_nop 0")
+    if stage < 2:
+        emit("v_readlane_b32 s80, v55, %d" % lane)
     emit("""
-    v_readlane_b32 s80, v55, %d
-    s_sub_u32 s81, %%[range], s80
-    s_sub_u32 s87, %%[code], s80
-    s_cbranch_scc0 %s
+    v_cmp_gt_u32 vcc, s80, v29
+    s_cbranch_vccz %s
     s_mov_b32 %%[range], s80
-    """ % (lane, one))
+    """ % one)
     head_update(lane, 0)
-    nchk(prefix=(lambda: bounds("v40")) if next_head else None)
+    if next_head is not None:
+        nchk(prefix=lambda: bounds("v40"), pick=head_pick(next_head))
+    else:
+        nchk()
 
 
-def hbit_one(lane, next_head=False):
-    emit("s_mov_b32 %[code], s87\ns_mov_b32 %[range], s81")
+def hbit_one(lane, next_head=None):
+    emit("v_subrev_u32 v29, s80, v29\ns_sub_u32 %[range], %[range], s80")
     head_update(lane, 1)
-    nchk(prefix=(lambda: bounds("v40")) if next_head else None)
+    if next_head is not None:
+        nchk(prefix=lambda: bounds("v40"), pick=head_pick(next_head))
+    else:
+        nchk()
 
 
 def level_prefix(k, blocks):
@@ -223,27 +234,23 @@ def level_pick(k):
         emit("v_readlane_b32 s84, v62, s88\ns_bitcmp1_b32 s88, 6\ns_cselect_b32 s80, s84, s80")
 
 
-def walk(nbits, blocks, early_exit=None, entries=None):
-    """Walk nbits levels of the bit tree whose 64-prob blocks are already in `blocks`
+def walk(nbits, blocks, early_exit=None, filler="s_nop 0"):
+    """Walk nbits <= 6 levels of a bit tree whose 64-prob block is already in blocks[0]
     (bit_tree_decoder.go:18-40).  s88 ends as 1 followed by the COMPLEMENTED decided bits (the tree
     slot order of xlz_kernel.hip: tree_slot).  Nothing is recorded: tree_update finds the
-    probabilities again in the block registers.  early_exit = (sgpr, label): leave after as many
+    probabilities again in the block register.  early_exit = (sgpr, label): leave after as many
     levels as the SGPR says (reverse tree over posDecoders, 1..5 levels).
-    entries = label prefix: the walk is only ever entered at level k >= 1 through <prefix>k,
-    with s88 = the tree slot reached so far and level_prefix(k) done by the entering code."""
+    filler: independent instruction(s) of the caller, placed in the wait state between the first
+    VALU product and its lane read."""
+    assert nbits <= 6
+    level_prefix(0, blocks)
+    emit(filler)
+    emit("v_readlane_b32 s80, v55, 1\ns_mov_b32 s88, 1")
     for k in range(nbits):
-        if entries:
-            if k == 0:
-                continue
-            label("%s%d" % (entries, k))
-        elif k == 0:
-            level_prefix(0, blocks)
-            emit("s_mov_b32 s88, 1")
-        level_pick(k)
         decide()
         emit("s_addc_u32 s88, s88, s88")  # J = 2J + SCC = 2J + !bit
         if k + 1 < nbits:
-            nchk(prefix=lambda: level_prefix(k + 1, blocks))
+            nchk(prefix=lambda: level_prefix(k + 1, blocks), pick=lambda: level_pick(k + 1))
             if early_exit:
                 emit("s_cmp_eq_u32 %s, %d\ns_cbranch_scc1 %s" % (early_exit[0], k + 1, early_exit[1]))
         else:
@@ -294,9 +301,11 @@ def fetch_level(k, blocks):
              "s_cselect_b32 s86, s84, s86" % (blocks[2], blocks[3]))
 
 
-def level_rec():
-    """decision of a recorded level on the probability in s86"""
+def level_rec(k=None):
+    """decision of a recorded level on the probability in s86 (parked in lane k of v54)"""
     emit("s_lshr_b32 s80, %[range], 11\ns_mul_i32 s80, s80, s86")
+    if k is not None:
+        emit("v_writelane_b32 v54, s86, %d" % k)
     decide()
     emit("s_addc_u32 s88, s88, s88")
 
@@ -312,8 +321,7 @@ def walk_rec(nbits, blocks, entries=None):
                 continue
             label("%s%d" % (entries, k))
             fetch_level(k, blocks)
-        emit("v_writelane_b32 v54, s86, %d" % k)
-        level_rec()
+        level_rec(k)
         nchk()
         if k + 1 < nbits and not entries:
             fetch_level(k + 1, blocks)
@@ -322,6 +330,8 @@ def walk_rec(nbits, blocks, entries=None):
 def tree_update_rec(nb, base, store=True):
     """model updates of a walk_rec in ONE vector operation, lane k = level k: slot = s88 >> (nb-k),
     !bit = (s88 >> (nb-k-1)) & 1, p = v54; lanes >= nb store to the unused slot (v38)."""
+    if store:
+        emit("v_cmp_gt_u32 vcc, %d, %%[vlane]" % nb)
     emit("""
     v_sub_u32 v55, %d, %%[vlane]
     v_lshrrev_b32 v60, v55, s88
@@ -335,11 +345,14 @@ def tree_update_rec(nb, base, store=True):
     v_sub_u32 v61, v54, v61
     """ % (nb, base))
     if store:
-        emit("v_cmp_gt_u32 vcc, %d, %%[vlane]\nv_cndmask_b32 v60, v38, v60, vcc\nds_write_b16 v60, v61" % nb)
+        emit("v_cndmask_b32 v60, v38, v60, vcc\nds_write_b16 v60, v61")
 
 
-def len_prefetch(base):
-    """request the three length trees of this posState (blocks v41..v46)"""
+def len_prefetch(base, lane_c):
+    """request the three length trees of this posState (blocks v41..v46); bounds("v40") was just
+    emitted: the bound of the coder's first decision (head lane lane_c) is read here, in the wait
+    states"""
+    emit("v_readlane_b32 s80, v55, %d" % lane_c)
     emit("""
     s_lshl_b32 s92, s90, 4
     v_add_u32 v59, s92, v56
@@ -366,20 +379,19 @@ def posslot_request(static):
 def len_decode(tag, base, lane_c, lane_c2, posslot):
     """lenDecoder.Decode (len_decoder.go:34-60): raw length -> s89, the walked tree updated.
     posslot: request the distance-slot block as soon as the length is known (simple match)."""
-    hbit(lane_c, L(tag + "c2"), prefixed=True)  # bounds("v40") came before len_prefetch
-    emit("s_add_u32 s82, s92, %d\nv_mov_b32 v58, s82\ns_waitcnt lgkmcnt(0)"  # s92 = posState * 16 (len_prefetch)
-         % ((base + LEN_LOW) * 2))
-    walk(3, ["v41"])
+    hbit(lane_c, L(tag + "c2"), stage=2)  # bounds("v40") and the lane read: len_prefetch
+    emit("s_waitcnt lgkmcnt(0)")
+    walk(3, ["v41"], filler="s_add_u32 s82, s92, %d\nv_mov_b32 v58, s82" % ((base + LEN_LOW) * 2))  # s92 = posState * 16
     emit("s_andn2_b32 s89, 7, s88")
     if posslot:
         posslot_request(False)
     tree_update(3, ["v41"])
     emit("s_branch %s" % L(tag + "end"))
     label(tag + "c2")
-    hbit_one(lane_c, next_head=True)
-    hbit(lane_c2, L(tag + "hi"), prefixed=True)
-    emit("s_add_u32 s82, s92, %d\nv_mov_b32 v58, s82\ns_waitcnt lgkmcnt(0)" % ((base + LEN_MID) * 2))
-    walk(3, ["v42"])
+    hbit_one(lane_c, next_head=lane_c2)
+    hbit(lane_c2, L(tag + "hi"), stage=2)
+    emit("s_waitcnt lgkmcnt(0)")
+    walk(3, ["v42"], filler="s_add_u32 s82, s92, %d\nv_mov_b32 v58, s82" % ((base + LEN_MID) * 2))
     emit("s_xor_b32 s89, s88, 7")
     if posslot:
         posslot_request(True)
@@ -480,9 +492,9 @@ def plain_literal():
 def gen():
     # The gathers of packet n+1 are issued from the tail of packet n (software pipelining):
     # by the time the loop top has done its limit checks the probabilities have arrived.
-    emit("v_lshlrev_b32 v56, 1, %%[vlane]\ns_mov_b32 s94, 0\nv_mov_b32 v38, %d" % ((P_LEN + 2) * 2))
+    emit("v_lshlrev_b32 v56, 1, %%[vlane]\ns_mov_b32 s94, 0\nv_mov_b32 v38, %d\nv_mov_b32 v29, %%[code]" % ((P_LEN + 2) * 2))
     # per-lane constants of tree_update: v31 = floor(log2(lane)) + 1, v30 = lane (lane 0: never a slot)
-    emit("v_ffbh_u32 v31, %[vlane]\nv_sub_u32 v31, 32, v31\nv_cmp_eq_u32 vcc, 0, %[vlane]\n"
+    emit("v_cmp_eq_u32 vcc, 0, %[vlane]\nv_ffbh_u32 v31, %[vlane]\nv_sub_u32 v31, 32, v31\n"
          "v_cndmask_b32 v30, %[vlane], -1, vcc")
     head_issue(first=True)
     literal_context()  # no copy is pending on entry: prevByte is valid
@@ -496,10 +508,11 @@ def gen():
     emit("""
     s_cmp_gt_u32 %%[arel], %%[arel_lim]
     s_cbranch_scc1 %s
+    v_readlane_b32 s80, v55, %d
     s_cmp_ge_u32 %%[pos], %%[pos_lim]
     s_cbranch_scc1 %s
-    """ % (L("x0"), L("x0")))
-    hbit(H_IS_MATCH, L("match"), prefixed=True)
+    """ % (L("x0"), H_IS_MATCH, L("x0")))
+    hbit(H_IS_MATCH, L("match"), stage=2)
     plain_literal()
     # ------------------------------------------------------------- packet head
     label("pkt")
@@ -508,10 +521,11 @@ def gen():
     emit("""
     s_cmp_gt_u32 %%[arel], %%[arel_lim]
     s_cbranch_scc1 %s
+    v_readlane_b32 s80, v55, %d
     s_cmp_ge_u32 %%[pos], %%[pos_lim]
     s_cbranch_scc1 %s
-    """ % (L("x0"), L("x0")))
-    hbit(H_IS_MATCH, L("match"), prefixed=True)
+    """ % (L("x0"), H_IS_MATCH, L("x0")))
+    hbit(H_IS_MATCH, L("match"), stage=2)
     # ------------------------------------------------------------- literal (decompress.go:44-175)
     need_copy_done()
     emit("s_cmp_lg_u32 s97, 0\ns_cbranch_scc1 %s" % L("litready"))
@@ -528,8 +542,8 @@ def gen():
     # already in v50..v53.  s98 = levels decided in the matched table.
     label("mlit")
     emit("""
-    s_xor_b32 s89, %%[mb], 0x1ff
     v_min_u32 v55, 7, %%[vlane]
+    s_xor_b32 s89, %%[mb], 0x1ff
     v_sub_u32 v60, 8, v55
     v_lshrrev_b32 v60, v60, s89
     v_sub_u32 v61, 7, v55
@@ -544,14 +558,16 @@ def gen():
     # matched levels: the eight candidate probabilities are lanes 0..7 of v54, so the bound of
     # level k is lane k of the VALU product (no record needed: v54 itself is the record)
     bounds("v54")
-    emit("s_mov_b32 s88, 1")
+    emit("s_mov_b32 s88, 1\nv_readlane_b32 s80, v55, 0\ns_nop 0")
     for k in range(8):
-        emit("v_readlane_b32 s80, v55, %d" % k)
         decide()
         emit("s_addc_u32 s88, s88, s88")
-        nchk(prefix=(lambda: bounds("v54")) if k < 7 else None)
+        if k < 7:
+            nchk(prefix=lambda: bounds("v54"), pick=head_pick(k + 1))
+        else:
+            nchk()
         if k < 7:  # still on matchByte's path?  s88 == (0x1ff ^ mb) >> (7 - k)  (complemented bits)
-            emit("s_lshr_b32 s80, s89, %d\ns_cmp_lg_u32 s80, s88\ns_cbranch_scc1 %s" % (7 - k, L("mx%d" % (k + 1))))
+            emit("s_lshr_b32 s82, s89, %d\ns_cmp_lg_u32 s82, s88\ns_cbranch_scc1 %s" % (7 - k, L("mx%d" % (k + 1))))  # s80 holds the next bound
     emit("s_mov_b32 s98, 8\ns_branch %s" % L("mlfin"))
     for k in range(1, 8):
         label("mx%d" % k)
@@ -559,32 +575,31 @@ def gen():
     walk_rec(8, LIT_BLOCKS, entries="pw")
     label("mlfin")
     literal_tail()
-    tree_update_rec(8, "v39", store=False)
     # lanes < s98 -> matched table (HBM; the rest to its unused slot 0), lanes s98..7 -> plain table
+    emit("v_cmp_gt_u32 vcc, s98, %[vlane]\nv_cmp_gt_u32 s[82:83], 8, %[vlane]")
+    tree_update_rec(8, "v39", store=False)
     emit("""
-    v_cmp_gt_u32 vcc, s98, %[vlane]
     v_cndmask_b32 v57, 0, v57, vcc
     global_store_short v57, v61, %[mptr]
     v_cndmask_b32 v60, v60, v38, vcc
-    v_cmp_gt_u32 vcc, 8, %[vlane]
-    v_cndmask_b32 v60, v38, v60, vcc
+    v_cndmask_b32 v60, v38, v60, s[82:83]
     ds_write_b16 v60, v61
     """)
     literal_context(prev_v="v32")
     emit("s_branch %s" % L("pktl"))
     # ------------------------------------------------------------- match or rep
     label("match")
-    hbit_one(H_IS_MATCH, next_head=True)
+    hbit_one(H_IS_MATCH, next_head=H_IS_REP)
     emit("s_and_b32 s90, %[wpos], %[pos_mask]")  # posState, for the length coders
-    hbit(H_IS_REP, L("rep"), prefixed=True)
+    hbit(H_IS_REP, L("rep"), stage=2)
     # simple match (:215-668)
     bounds("v40")  # for the length coder's first decision
     emit("s_mov_b32 %[rep3], %[rep2]\ns_mov_b32 %[rep2], %[rep1]\ns_mov_b32 %[rep1], %[rep0]")
-    len_prefetch(P_LEN)
+    len_prefetch(P_LEN, H_LEN_C)
     emit("ds_read_u16 v35, v56 offset:%d" % (P_ALIGN * 2))
     len_decode("lm", P_LEN, H_LEN_C, H_LEN_C2, posslot=True)  # leaves the posSlot block requested, s92 = its base
-    emit("s_cmp_lt_u32 %[state], 7\ns_cselect_b32 %[state], 7, 10\nv_mov_b32 v58, s92\ns_waitcnt lgkmcnt(0)")
-    walk(6, ["v36"])
+    emit("s_waitcnt lgkmcnt(0)")
+    walk(6, ["v36"], filler="s_cmp_lt_u32 %[state], 7\ns_cselect_b32 %[state], 7, 10\nv_mov_b32 v58, s92")
     emit("""
     s_andn2_b32 s98, 63, s88
     s_cmp_lt_u32 s98, 4
@@ -610,8 +625,8 @@ def gen():
     """ % (L("direct"), P_POS_DEC))
     tree_update(6, ["v36"])  # posSlot tree, while the posDecoders block is on its way
     # reverse bit tree over posDecoders (:495-546): s83 levels (1..5)
-    emit("v_mov_b32 v58, s92\ns_mov_b32 s98, s83\ns_waitcnt lgkmcnt(0)")
-    walk(5, ["v37"], early_exit=("s98", L("rtdone")))
+    emit("s_waitcnt lgkmcnt(0)")
+    walk(5, ["v37"], early_exit=("s98", L("rtdone")), filler="v_mov_b32 v58, s92\ns_mov_b32 s98, s83")
     label("rtdone")
     tree_update("s98", ["v37"])
     emit("""
@@ -626,42 +641,39 @@ def gen():
     tree_update(6, ["v36"])  # posSlot tree
     # numDirectBits - 4 = s83 - 4 (2..26) halvings, unrolled; entered through a branch table so
     # that no loop counter is kept.  Exactly the reference's arithmetic: t = sign(code - range).
-    # Only the range stays on the scalar side (its normalisation test needs SCC): the code (v34)
+    # Only the range stays on the scalar side (its normalisation test needs SCC): the code (v29)
     # and the collected, complemented bits (v33 = 2 * acc + (t < 0)) are wave-uniform VGPR values,
     # four VALU instructions per bit instead of four scalar ones.
     emit("""
     s_getpc_b64 s[80:81]
-    s_sub_u32 s82, 36, s83
+    s_sub_u32 s82, 35, s83
     s_lshl2_add_u32 s80, s82, s80
     s_addc_u32 s81, s81, 0
     v_mov_b32 v33, 0
-    v_mov_b32 v34, %[code]
     s_setpc_b64 s[80:81]
-    """)  # s_getpc returns the address of the s_sub; the table starts 6 instructions (all 4 bytes) later:
-    # entry e = 26 - (s83 - 4) is at +4 * (e + 6) = 4 * (36 - s83)
+    """)  # s_getpc returns the address of the s_sub; the table starts 5 instructions (all 4 bytes) later:
+    # entry e = 26 - (s83 - 4) is at +4 * (e + 5) = 4 * (35 - s83)
     for k in range(26, 0, -1):
         emit("s_branch %s" % L("db%d" % k))
     for k in range(26, 0, -1):
         label("db%d" % k)
         emit("""
         s_lshr_b32 %[range], %[range], 1
-        v_subrev_u32 v55, %[range], v34
+        v_subrev_u32 v55, %[range], v29
         v_cmp_gt_i32 vcc, 0, v55
-        v_cndmask_b32 v34, v55, v34, vcc
-        v_addc_co_u32 v33, vcc, v33, v33, vcc
         """)
-        nchk(code_v="v34")
+        # the normalisation test sits in the VCC wait states; the stub (which shifts v29) is
+        # entered after the bit is done
+        nchk(mid="s_nop 0\nv_cndmask_b32 v29, v55, v29, vcc\nv_addc_co_u32 v33, vcc, v33, v33, vcc")
     emit("""
-    v_readfirstlane_b32 %%[code], v34
     v_readfirstlane_b32 s84, v33
     s_sub_u32 s83, s83, 4
     s_bfm_b32 s80, s83, 0
     s_andn2_b32 s84, s80, s84
     s_lshl_b32 s84, s84, 4
-    s_add_u32 s93, s93, s84
-    v_mov_b32 v58, %d
-    """ % (P_ALIGN * 2))
-    walk(4, ["v35"])  # reverse tree over alignDecoderProbs (:579-625): M = 1 b0 b1 b2 b3
+    """)
+    # reverse tree over alignDecoderProbs (:579-625): M = 1 b0 b1 b2 b3
+    walk(4, ["v35"], filler="s_add_u32 s93, s93, s84\nv_mov_b32 v58, %d" % (P_ALIGN * 2))
     tree_update(4, ["v35"])
     emit("s_not_b32 s80, s88\ns_brev_b32 s80, s80\ns_lshr_b32 s80, s80, 28\ns_add_u32 %[rep0], s93, s80")
     label("distdone")
@@ -678,10 +690,10 @@ def gen():
     emit("s_add_u32 s89, s89, 2\ns_branch %s" % L("copy"))
     # ------------------------------------------------------------- rep match (:685-1123)
     label("rep")
-    hbit_one(H_IS_REP, next_head=True)
+    hbit_one(H_IS_REP, next_head=H_G0)
     emit("s_cmp_eq_u32 %%[pos], %%[wbase]\ns_cbranch_scc1 %s" % L("x1"))
-    hbit(H_G0, L("g1"), prefixed=True, next_head=True)
-    hbit(H_REP0_LONG, L("r0long"), prefixed=True)
+    hbit(H_G0, L("g1"), stage=2, next_head=H_REP0_LONG)
+    hbit(H_REP0_LONG, L("r0long"), stage=2)
     emit("""
     s_cmp_lt_u32 %%[state], 7
     s_cselect_b32 %%[state], 9, 11
@@ -692,12 +704,12 @@ def gen():
     hbit_one(H_REP0_LONG)
     emit("s_branch %s" % L("replen"))
     label("g1")
-    hbit_one(H_G0, next_head=True)
-    hbit(H_G1, L("g2"), prefixed=True)
+    hbit_one(H_G0, next_head=H_G1)
+    hbit(H_G1, L("g2"), stage=2)
     emit("s_mov_b32 s80, %%[rep1]\ns_mov_b32 %%[rep1], %%[rep0]\ns_mov_b32 %%[rep0], s80\ns_branch %s" % L("replen"))
     label("g2")
-    hbit_one(H_G1, next_head=True)
-    hbit(H_G2, L("g3"), prefixed=True)
+    hbit_one(H_G1, next_head=H_G2)
+    hbit(H_G2, L("g3"), stage=2)
     emit("""
     s_mov_b32 s80, %%[rep2]
     s_mov_b32 %%[rep2], %%[rep1]
@@ -716,7 +728,7 @@ def gen():
     """)
     label("replen")
     bounds("v40")
-    len_prefetch(P_REP_LEN)
+    len_prefetch(P_REP_LEN, H_REP_C)
     len_decode("lr", P_REP_LEN, H_REP_C, H_REP_C2, posslot=False)
     emit("s_cmp_lt_u32 %[state], 7\ns_cselect_b32 %[state], 8, 11\ns_add_u32 s89, s89, 2")
     # ------------------------------------------------------------- window.CopyMatch (window.go:55-87)
@@ -756,6 +768,7 @@ def gen():
     label("x0")
     emit("s_mov_b32 %[exitc], 0")
     label("fin")
+    emit("v_readfirstlane_b32 %[code], v29")
     need_copy_done()
     emit("s_waitcnt lgkmcnt(0)\nds_write_b16 v47, v40\ns_waitcnt lgkmcnt(0)\ns_branch %s" % L("end"))
     emit_stubs()
@@ -765,6 +778,10 @@ def gen():
 
 
 gen()
+import hazards  # noqa: E402  (tools/hazards.py: the gfx950 wait states the assembler does not insert in inline asm)
+lines, n_nops = hazards.fix(lines, verbose=bool(os.environ.get("XLZ_GEN_VERBOSE")))
+assert not hazards.analyse(lines)
+print("hazards: %d s_nop inserted" % n_nops)
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lzma_amd", "csrc", "xlz_fastpath.inc")
 with open(out, "w") as f:
     f.write("// GENERATED by tools/gen_fastpath.py -- do not edit.  %d instructions, %d normalisation stubs.\n"
