@@ -1,0 +1,46 @@
+"""The fast loop is generated code: the committed .inc must be what the generator produces, and
+it must respect the gfx950 wait states the assembler does not insert inside inline asm
+(tools/hazards.py) -- a missing one once made every stream decode wrong."""
+import importlib.util
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    spec = importlib.util.spec_from_file_location("gen_fastpath_under_test", os.path.join(ROOT, "tools", "gen_fastpath.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_committed_inc_is_generated_and_hazard_free():
+    g = _load()
+    text, final, n_nops = g.render()
+    with open(os.path.join(ROOT, "lzma_amd", "csrc", "xlz_fastpath.inc")) as f:
+        assert f.read() == text, "run python3 tools/gen_fastpath.py"
+    import hazards
+    assert hazards.analyse(final) == {}
+    assert n_nops < 20  # instruction order, not s_nop, is what satisfies the wait states
+
+
+def test_hazard_checker_sees_the_known_cases():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import hazards
+    # R1: VALU write of a VGPR, v_readlane of it right after
+    assert hazards.analyse(["v_mul_u32_u24 v55, v55, v40", "v_readlane_b32 s80, v55, 3"])
+    assert not hazards.analyse(["v_mul_u32_u24 v55, v55, v40", "s_lshr_b32 s81, s80, 24", "v_readlane_b32 s80, v55, 3"])
+    # R2: SGPR written by v_readlane, read by a VALU instruction one slot later
+    assert hazards.analyse(["v_readlane_b32 s80, v55, 3", "s_sub_u32 s81, s82, s80", "v_subrev_co_u32 v28, vcc, s80, v29"])
+    assert not hazards.analyse(["v_readlane_b32 s80, v55, 3", "s_sub_u32 s81, s82, s80", "s_nop 0",
+                                "v_subrev_co_u32 v28, vcc, s80, v29"])
+    # R3: VCC written by v_cmp, read by v_cndmask
+    assert hazards.analyse(["v_cmp_eq_u32 vcc, 0, v1", "v_cndmask_b32 v2, v3, v4, vcc"])
+    assert not hazards.analyse(["v_cmp_eq_u32 vcc, 0, v1", "s_nop 1", "v_cndmask_b32 v2, v3, v4, vcc"])
+    # across a branch: the consumer is the first instruction at the target
+    bad = ["v_readlane_b32 s80, v55, 3", "s_cbranch_scc0 .Lx", "s_nop 3", ".Lx:", "v_add_u32 v1, s80, v1"]
+    assert hazards.analyse(bad)
+    fixed, n = hazards.fix(bad)
+    assert n == 1 and not hazards.analyse(fixed)

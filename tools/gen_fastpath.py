@@ -777,17 +777,28 @@ def gen():
     label("end")
 
 
-gen()
 import hazards  # noqa: E402  (tools/hazards.py: the gfx950 wait states the assembler does not insert in inline asm)
-lines, n_nops = hazards.fix(lines, verbose=bool(os.environ.get("XLZ_GEN_VERBOSE")))
-assert not hazards.analyse(lines)
-print("hazards: %d s_nop inserted" % n_nops)
-out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lzma_amd", "csrc", "xlz_fastpath.inc")
-with open(out, "w") as f:
-    f.write("// GENERATED by tools/gen_fastpath.py -- do not edit.  %d instructions, %d normalisation stubs.\n"
-            % (sum(1 for l in lines if not l.endswith(":")), len(stubs)))
-    f.write("// Included inside lzma_fast_loop() in xlz_kernel.hip as the body of one asm volatile statement.\n")
-    for l in lines:
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lzma_amd", "csrc", "xlz_fastpath.inc")
+
+
+def render():
+    """-> (text of xlz_fastpath.inc, final instruction lines, number of s_nop the hazard pass added)"""
+    gen()
+    final, n_nops = hazards.fix(lines, verbose=bool(os.environ.get("XLZ_GEN_VERBOSE")))
+    assert not hazards.analyse(final)
+    text = ["// GENERATED by tools/gen_fastpath.py -- do not edit.  %d instructions, %d normalisation stubs.\n"
+            % (sum(1 for l in final if not l.endswith(":")), len(stubs)),
+            "// Included inside lzma_fast_loop() in xlz_kernel.hip as the body of one asm volatile statement.\n"]
+    for l in final:
         sep = "\\n" if l.endswith(":") else "\\n\\t"
-        f.write('    "%s%s"\n' % (l, sep))
-print(out, len(lines), "lines,", len(stubs), "stubs")
+        text.append('    "%s%s"\n' % (l, sep))
+    return "".join(text), final, n_nops
+
+
+if __name__ == "__main__":
+    text, final, n_nops = render()
+    with open(OUT, "w") as f:
+        f.write(text)
+    print("hazards: %d s_nop inserted" % n_nops)
+    print(OUT, len(final), "lines,", len(stubs), "stubs")
