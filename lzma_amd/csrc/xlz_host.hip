@@ -54,6 +54,22 @@ struct xlz_reader;
 struct Batcher;
 static void batcher_shutdown(Batcher *bt); // defined next to the readers
 
+// Host side of the boundary (host buffers in, host buffers out): pinned staging that lives as
+// long as the context, so that neither page pinning nor pageable copies sit on the path.
+//  * input: one grow-only pinned image, packed by several host threads, one async H2D copy;
+//  * output: a ring of pinned buffers; D2H copies of arena chunks run on their own stream while
+//    host threads scatter the chunks that have arrived into the callers' buffers.
+struct HostPipe {
+    static constexpr int kRing = 4;
+    static constexpr size_t kRingBytes = 64u << 20;
+    std::mutex mu; // one staged call at a time per context
+    uint8_t *pin_in = nullptr;
+    size_t pin_in_cap = 0;
+    uint8_t *ring[kRing] = {};
+    hipEvent_t ring_ev[kRing] = {};
+    hipStream_t copy_stream = nullptr;
+};
+
 struct xlz_ctx {
     Batcher *batcher = nullptr; // coalesces pull-style readers into batches (xlz_ctx_enable_batching)
     int device = 0;
@@ -62,6 +78,7 @@ struct xlz_ctx {
     uint32_t *queue = nullptr; // work-queue head, re-zeroed on the stream before each launch
     hipEvent_t ev[8] = {};
     std::mutex mu;
+    HostPipe pipe;
 };
 
 // per-stream bookkeeping of a batch
@@ -173,6 +190,37 @@ extern "C" uint64_t xlz_decode_unpack_size(const uint8_t h[8])
 }
 
 // ---------------------------------------------------------------- context ----
+namespace {
+
+// host threads for a staging job of `bytes` bytes: one per 32 MiB, at most 8 (or XLZ_HOST_THREADS)
+unsigned host_threads(size_t bytes)
+{
+    unsigned cap = 8;
+    if (const char *e = getenv("XLZ_HOST_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) cap = (unsigned)v;
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && hw < cap) cap = hw;
+    const unsigned want = (unsigned)(bytes / (32u << 20)) + 1;
+    return want < cap ? want : cap;
+}
+
+template <class F> void run_threads(unsigned n, F &&f)
+{
+    if (n <= 1) {
+        f(0u);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve(n - 1);
+    for (unsigned t = 1; t < n; t++) th.emplace_back([&f, t] { f(t); });
+    f(0u);
+    for (auto &x : th) x.join();
+}
+
+} // namespace
+
 extern "C" int xlz_ctx_create(int device, xlz_ctx **out)
 {
     if (!out) return XLZ_ERR_BAD_ARG;
@@ -201,6 +249,12 @@ extern "C" void xlz_ctx_destroy(xlz_ctx *c)
     if (c->batcher) batcher_shutdown(c->batcher);
     (void)hipSetDevice(c->device);
     if (c->queue) (void)hipFree(c->queue);
+    if (c->pipe.pin_in) (void)hipHostFree(c->pipe.pin_in);
+    for (int i = 0; i < HostPipe::kRing; i++) {
+        if (c->pipe.ring[i]) (void)hipHostFree(c->pipe.ring[i]);
+        if (c->pipe.ring_ev[i]) (void)hipEventDestroy(c->pipe.ring_ev[i]);
+    }
+    if (c->pipe.copy_stream) (void)hipStreamDestroy(c->pipe.copy_stream);
     for (hipEvent_t e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -517,17 +571,35 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
             return fail(XLZ_ERR_DEVICE);
     }
     {
-        // pack the payloads into one staging image, then a single H2D copy
-        uint8_t *stage = nullptr;
-        if (hipHostMalloc(&stage, b->in_bytes, hipHostMallocDefault) != hipSuccess) return fail(XLZ_ERR_DEVICE);
-        memset(stage, 0, b->in_bytes);
-        for (size_t k = 0; k < nu; k++) {
-            const Unit &u = b->units[k];
-            memcpy(stage + u.in_off, streams[u.stream].in + unit_src_off[k], u.in_len);
+        // pack the payloads into the context's pinned image (several host threads), one H2D copy
+        HostPipe &hp = ctx->pipe;
+        std::lock_guard<std::mutex> pl(hp.mu);
+        if (hp.pin_in_cap < b->in_bytes) {
+            if (hp.pin_in) (void)hipHostFree(hp.pin_in);
+            hp.pin_in = nullptr;
+            hp.pin_in_cap = 0;
+            const size_t want = b->in_bytes + b->in_bytes / 4 + (1u << 20);
+            if (hipHostMalloc(&hp.pin_in, want, hipHostMallocDefault) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+            hp.pin_in_cap = want;
         }
-        hipError_t e = hipMemcpy(b->d_in, stage, b->in_bytes, hipMemcpyHostToDevice);
-        (void)hipHostFree(stage);
-        if (e != hipSuccess) return fail(XLZ_ERR_DEVICE);
+        uint8_t *stage = hp.pin_in;
+        const unsigned nth = host_threads(b->in_bytes);
+        auto pack = [&](unsigned t) {
+            // units are laid out in arena order: thread t owns a contiguous run of them and the
+            // padding bytes that follow each (zeroed: the decoder's input window may run into them)
+            const size_t k0 = nu * t / nth, k1 = nu * (t + 1) / nth;
+            for (size_t k = k0; k < k1; k++) {
+                const Unit &u = b->units[k];
+                memcpy(stage + u.in_off, streams[u.stream].in + unit_src_off[k], u.in_len);
+                const uint64_t end = u.in_off + u.in_len;
+                const uint64_t next = k + 1 < nu ? b->units[k + 1].in_off : b->in_bytes;
+                if (next > end) memset(stage + end, 0, (size_t)(next - end));
+            }
+        };
+        if (nu && b->units[0].in_off) memset(stage, 0, (size_t)b->units[0].in_off);
+        if (!nu) memset(stage, 0, b->in_bytes);
+        run_threads(nth, pack);
+        if (hipMemcpy(b->d_in, stage, b->in_bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(XLZ_ERR_DEVICE);
     }
     if (nu) {
         if (hipMemcpy(b->d_units, b->units.data(), nu * sizeof(Unit), hipMemcpyHostToDevice) != hipSuccess ||
@@ -787,6 +859,133 @@ extern "C" int xlz_batch_download(xlz_batch *b, size_t i, uint8_t *dst, size_t l
 
 extern "C" void xlz_batch_destroy(xlz_batch *b) { batch_free(b); }
 
+namespace {
+
+// All decoded streams of a batch to the callers' buffers: the output arena is cut into chunks of
+// at most HostPipe::kRingBytes (whole stream regions where they fit, pieces of a region where one
+// does not), each chunk is copied D2H into a slot of the pinned ring on the copy stream, and host
+// threads scatter the chunks that have arrived while the next ones are in flight.
+int download_all(xlz_batch *b, const xlz_stream_desc *streams, const xlz_result *results)
+{
+    xlz_ctx *ctx = b->ctx;
+    HostPipe &hp = ctx->pipe;
+    struct Piece {
+        uint64_t dev_off;
+        uint8_t *dst;
+        size_t len;
+    };
+    struct Chunk {
+        uint64_t dev_off = 0;
+        size_t len = 0;
+        std::vector<Piece> pieces;
+    };
+    std::vector<Chunk> chunks;
+    for (size_t i = 0; i < b->n; i++) {
+        const StreamPlan &pl = b->plans[i];
+        size_t len = (size_t)results[i].out_len;
+        if (pl.host_status != 1 || len == 0) continue;
+        if (len > pl.out_cap) len = (size_t)pl.out_cap;
+        uint64_t off = pl.out_off;
+        uint8_t *dst = streams[i].out;
+        while (len) {
+            if (chunks.empty() || off + 1 > chunks.back().dev_off + HostPipe::kRingBytes || off < chunks.back().dev_off) {
+                chunks.emplace_back();
+                chunks.back().dev_off = off;
+            }
+            Chunk &c = chunks.back();
+            const size_t room = (size_t)(c.dev_off + HostPipe::kRingBytes - off);
+            const size_t take = len < room ? len : room;
+            c.pieces.push_back({off, dst, take});
+            c.len = (size_t)(off + take - c.dev_off);
+            off += take;
+            dst += take;
+            len -= take;
+        }
+    }
+    if (chunks.empty()) return XLZ_OK;
+
+    std::lock_guard<std::mutex> pl(hp.mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!hp.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&hp.copy_stream, hipStreamNonBlocking));
+    for (int r = 0; r < HostPipe::kRing; r++) {
+        if (!hp.ring[r]) HIP_TRY(hipHostMalloc(&hp.ring[r], HostPipe::kRingBytes, hipHostMallocDefault));
+        if (!hp.ring_ev[r]) HIP_TRY(hipEventCreateWithFlags(&hp.ring_ev[r], hipEventDisableTiming));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // the decode has finished (results were read)
+
+    // scatter workers: chunk k is claimed by one worker, which waits for its copy event
+    const unsigned nworkers = std::min<unsigned>(host_threads(b->out_bytes), HostPipe::kRing);
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t issued = 0, next_claim = 0, n_done = 0; // chunks whose D2H was issued / claimed / scattered
+    std::vector<char> done(chunks.size(), 0);
+    bool failed = false;
+    auto worker = [&] {
+        (void)hipSetDevice(ctx->device);
+        for (;;) {
+            size_t k;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return next_claim < issued || next_claim >= chunks.size() || failed; });
+                if (failed || next_claim >= chunks.size()) return;
+                k = next_claim++;
+            }
+            const int slot = (int)(k % HostPipe::kRing);
+            const bool ok = hipEventSynchronize(hp.ring_ev[slot]) == hipSuccess;
+            if (ok)
+                for (const Piece &pc : chunks[k].pieces)
+                    memcpy(pc.dst, hp.ring[slot] + (pc.dev_off - chunks[k].dev_off), pc.len);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                done[k] = 1;
+                n_done++;
+                if (!ok) failed = true;
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nworkers; t++) th.emplace_back(worker);
+    int st = XLZ_OK;
+    for (size_t k = 0; k < chunks.size(); k++) {
+        const int slot = (int)(k % HostPipe::kRing);
+        if (k >= (size_t)HostPipe::kRing) { // the slot's previous chunk must have been scattered
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return done[k - HostPipe::kRing] || failed; });
+            if (failed) break;
+        }
+        if (hipMemcpyAsync(hp.ring[slot], b->d_out + chunks[k].dev_off, chunks[k].len, hipMemcpyDeviceToHost,
+                           hp.copy_stream) != hipSuccess ||
+            hipEventRecord(hp.ring_ev[slot], hp.copy_stream) != hipSuccess) {
+            std::lock_guard<std::mutex> lk(mu);
+            failed = true;
+            break;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            issued = k + 1;
+        }
+        cv.notify_all();
+    }
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (failed) {
+            st = XLZ_ERR_DEVICE;
+        } else {
+            cv.wait(lk, [&] { return n_done == chunks.size() || failed; });
+            if (failed) st = XLZ_ERR_DEVICE;
+        }
+        next_claim = std::max(next_claim, chunks.size()); // release idle workers
+        if (st != XLZ_OK) failed = true;
+    }
+    cv.notify_all();
+    for (auto &x : th) x.join();
+    (void)hipStreamSynchronize(hp.copy_stream);
+    return st;
+}
+
+} // namespace
+
 extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_result *results)
 {
     if (!ctx || (!streams && n) || (!results && n)) return XLZ_ERR_BAD_ARG;
@@ -797,10 +996,7 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     if (st != XLZ_OK) return st;
     st = xlz_batch_run(b);
     if (st == XLZ_OK) st = xlz_batch_results(b, results);
-    if (st == XLZ_OK) {
-        for (size_t i = 0; i < n && st == XLZ_OK; i++)
-            if (results[i].out_len) st = xlz_batch_download(b, i, streams[i].out, (size_t)results[i].out_len);
-    }
+    if (st == XLZ_OK) st = download_all(b, streams, results);
     xlz_batch_destroy(b);
     return st;
 }

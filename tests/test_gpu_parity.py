@@ -417,3 +417,45 @@ def test_concurrent_readers_are_coalesced_into_batches(xlz_so):
     batches, streams = c2.batching_stats()
     assert streams >= 48 and batches <= 24, (batches, streams)
     c2.close()
+
+
+def test_host_pipeline_big_and_ragged_streams(ctx):
+    """xlz_decode_batch's staged host path (pinned ring, chunked D2H, scatter threads): a stream
+    larger than one ring slot (64 MiB), many small ones around it, a truncated and an empty one --
+    every byte against the plaintext / the oracle, twice (the pinned pools are reused)."""
+    import threading
+    big = corpus.plain("Z", 901, 80 * 1024 * 1024 + 12345)
+    items = [(corpus.compress_alone(big, dict_size=1 << 20), big)]
+    for k in range(40):
+        p = corpus.plain("TRMZ"[k % 4], 910 + k, 1000 + 37777 * k)
+        items.append((corpus.compress_alone(p), p))
+    trunc = items[5][0][: len(items[5][0]) // 2]
+    streams = [Stream(c, FMT_LZMA_ALONE, out_cap=len(p)) for c, p in items]
+    streams.insert(3, Stream(trunc, FMT_LZMA_ALONE, out_cap=len(items[5][1])))
+    streams.insert(7, Stream(b"", FMT_LZMA_ALONE, out_cap=10))
+    want = [(p, 0) for _, p in items]
+    wt = oracle.lzma1_alone(trunc, len(items[5][1]))
+    want.insert(3, (wt[0], wt[1]))
+    we = oracle.lzma1_alone(b"", 10)
+    want.insert(7, (we[0], we[1]))
+    for _ in range(2):
+        got = lzma_amd.decode_batch(ctx, streams)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g[1] == w[1], i
+            assert hashlib.sha256(g[0]).digest() == hashlib.sha256(w[0]).digest(), i
+
+    # two host threads share the context (one staged call at a time inside)
+    errs = []
+
+    def run():
+        try:
+            r = lzma_amd.decode_batch(ctx, streams[1:12])
+            for (g, w) in zip(r, want[1:12]):
+                assert g[1] == w[1] and g[0] == w[0]
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=run) for _ in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
