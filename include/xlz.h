@@ -161,6 +161,33 @@ int xlz_reader_close(xlz_reader *r); /* readCloser.Close (readcloser.go:16-28); 
                                         XLZ_ERR_CLOSED; the handle stays valid until _free       */
 void xlz_reader_free(xlz_reader *r);
 
+/* ---- .xz container front-end ----------------------------
+ * Outside the reference (which has no container code): an .xz file is a list of independent
+ * blocks, each ONE raw LZMA2 stream with its own dictionary -- what NewReader2(in, dictSize)
+ * takes (reader2.go:26-41) -- so a file is one batch.  Only filter chains made of a single
+ * LZMA2 filter are accepted (BCJ / delta: XLZ_ERR_UNSUPPORTED).                              */
+typedef struct xlz_xz_block {
+    uint64_t comp_off;   /* raw LZMA2 payload inside the file                                   */
+    uint64_t comp_len;
+    uint64_t uncomp_off; /* where the block's bytes go in the decoded file                      */
+    uint64_t uncomp_len;
+    uint64_t check_off;  /* the block's integrity check inside the file                         */
+    uint32_t dict_size;
+    uint32_t check_type; /* 0 none, 1 CRC32, 4 CRC64, 10 SHA-256                                */
+} xlz_xz_block;
+
+/* Block index of a whole .xz file (concatenated streams and stream padding included), host
+ * only.  blocks may be NULL with max_blocks 0 to obtain the counts.  XLZ_ERR_OUT_CAP: more
+ * blocks than max_blocks (*n_blocks is the full count).                                      */
+int xlz_xz_index(const uint8_t *file, size_t len, xlz_xz_block *blocks, size_t max_blocks,
+                 size_t *n_blocks, uint64_t *total_uncompressed);
+/* Decode a whole .xz file into out as ONE GPU batch.  verify != 0: check every block's CRC32 /
+ * CRC64 on the host; *unverified (optional) = number of blocks whose check type is not
+ * implemented (SHA-256).  A failed check or a block that does not match the index:
+ * XLZ_ERR_RESULT.                                                                             */
+int xlz_xz_decode(xlz_ctx *ctx, const uint8_t *file, size_t len, uint8_t *out, size_t out_cap,
+                  uint64_t *out_len, int verify, size_t *unverified);
+
 #ifdef __cplusplus
 }
 #endif

@@ -335,3 +335,37 @@ def NewLZMADecompressorForSevenZip(ctx, props, unpack_size, readers):
 def NewLZMA2DecompressorForSevenZip(ctx, props, unpack_size, readers):
     """reader2.go:49-75: props = one dict-size byte; exactly one reader."""
     return _sevenzip(N.lib().xlz_new_lzma2_decompressor_for_sevenzip, ctx, props, unpack_size, readers)
+
+
+# ---- .xz container front-end (include/xlz.h: xlz_xz_index / xlz_xz_decode) -------------------
+def xz_index(data):
+    """Block index of an .xz file: list of dicts (comp_off, comp_len, uncomp_off, uncomp_len,
+    dict_size, check_type) and the total decoded size.  Host only."""
+    buf = ctypes.create_string_buffer(data, len(data)) if len(data) else ctypes.create_string_buffer(1)
+    n = ctypes.c_size_t()
+    total = ctypes.c_uint64()
+    st = N.lib().xlz_xz_index(ctypes.cast(buf, ctypes.c_void_p), len(data), None, 0, ctypes.byref(n), ctypes.byref(total))
+    if st != OK:
+        raise LzmaError(st, "xlz_xz_index")
+    blocks = (N.XzBlock * max(n.value, 1))()
+    st = N.lib().xlz_xz_index(ctypes.cast(buf, ctypes.c_void_p), len(data), blocks, n.value, ctypes.byref(n),
+                              ctypes.byref(total))
+    if st != OK:
+        raise LzmaError(st, "xlz_xz_index")
+    fields = [f for f, _ in N.XzBlock._fields_]
+    return [{f: getattr(blocks[i], f) for f in fields} for i in range(n.value)], total.value
+
+
+def xz_decode(ctx, data, verify=True):
+    """Decode a whole .xz file (all streams, all blocks) as one GPU batch -> bytes.
+    verify: check every block's CRC32 / CRC64."""
+    _, total = xz_index(data)
+    buf = ctypes.create_string_buffer(data, len(data))
+    out = ctypes.create_string_buffer(max(total, 1))
+    out_len = ctypes.c_uint64()
+    unverified = ctypes.c_size_t()
+    st = N.lib().xlz_xz_decode(ctx._h, ctypes.cast(buf, ctypes.c_void_p), len(data), ctypes.cast(out, ctypes.c_void_p),
+                               total, ctypes.byref(out_len), 1 if verify else 0, ctypes.byref(unverified))
+    if st != OK:
+        raise LzmaError(st, "xlz_xz_decode")
+    return out.raw[: out_len.value]

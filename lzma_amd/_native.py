@@ -41,7 +41,7 @@ EXPORTS = [
     "xlz_batch_results", "xlz_batch_download", "xlz_batch_device_output", "xlz_batch_last_kernel_ms",
     "xlz_batch_stats", "xlz_batch_destroy", "xlz_new_reader1", "xlz_new_reader2",
     "xlz_new_lzma_decompressor_for_sevenzip", "xlz_new_lzma2_decompressor_for_sevenzip",
-    "xlz_reader_read", "xlz_reader_close", "xlz_reader_free",
+    "xlz_reader_read", "xlz_reader_close", "xlz_reader_free", "xlz_xz_index", "xlz_xz_decode",
 ]
 
 
@@ -65,6 +65,18 @@ class Result(ctypes.Structure):
         ("in_consumed", ctypes.c_uint64),
         ("status", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
+    ]
+
+
+class XzBlock(ctypes.Structure):
+    _fields_ = [
+        ("comp_off", ctypes.c_uint64),
+        ("comp_len", ctypes.c_uint64),
+        ("uncomp_off", ctypes.c_uint64),
+        ("uncomp_len", ctypes.c_uint64),
+        ("check_off", ctypes.c_uint64),
+        ("dict_size", ctypes.c_uint32),
+        ("check_type", ctypes.c_uint32),
     ]
 
 
@@ -125,6 +137,8 @@ def lib():
     L.xlz_reader_close.argtypes = [vp]
     L.xlz_reader_free.argtypes = [vp]
     L.xlz_reader_free.restype = None
+    L.xlz_xz_index.argtypes = [vp, sz, ctypes.POINTER(XzBlock), sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint64)]
+    L.xlz_xz_decode.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(ctypes.c_uint64), i32, ctypes.POINTER(sz)]
     _lib = L
     return L
 

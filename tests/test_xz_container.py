@@ -1,0 +1,99 @@
+"""The .xz front-end (include/xlz.h: xlz_xz_index / xlz_xz_decode).
+
+The reference has no container code, so the checker here is liblzma (Python's lzma module, the
+format's own implementation): every block the index reports must be a raw LZMA2 stream that
+liblzma decodes to the right slice of the plaintext, and on the GPU the whole file must decode
+to what liblzma gives.
+"""
+import lzma
+import shutil
+import subprocess
+
+import pytest
+
+import corpus
+import lzma_amd
+from lzma_amd import LzmaError
+
+
+def _three_streams():
+    p = corpus.plain("T", 3, 600_000) + corpus.plain("R", 4, 100_000) + corpus.plain("Z", 5, 300_000)
+    a = lzma.compress(p[:250_000], format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC64)
+    b = lzma.compress(p[250_000:650_000], format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC32, preset=1)
+    c = lzma.compress(p[650_000:], format=lzma.FORMAT_XZ, check=lzma.CHECK_SHA256,
+                      filters=[{"id": lzma.FILTER_LZMA2, "preset": 6, "dict_size": 1 << 16, "lc": 2, "lp": 1, "pb": 1}])
+    return a + b + b"\0" * 8 + c + b"\0" * 4, p
+
+
+def _multi_block(block_size=131072):
+    if not shutil.which("xz"):
+        pytest.skip("xz command not available")
+    p = corpus.plain("M", 8, 1_000_000)
+    f = subprocess.run(["xz", "-c", "-T2", "--block-size=%d" % block_size], input=p, capture_output=True, check=True).stdout
+    return f, p
+
+
+def _check_blocks_with_liblzma(f, p):
+    blocks, total = lzma_amd.xz_index(f)
+    assert total == len(p)
+    for b in blocks:
+        raw = f[b["comp_off"]: b["comp_off"] + b["comp_len"]]
+        filt = [{"id": lzma.FILTER_LZMA2, "dict_size": b["dict_size"]}]
+        got = lzma.decompress(raw, format=lzma.FORMAT_RAW, filters=filt)
+        assert got == p[b["uncomp_off"]: b["uncomp_off"] + b["uncomp_len"]]
+    return blocks
+
+
+def test_index_of_concatenated_streams_with_padding():
+    f, p = _three_streams()
+    if shutil.which("xz"):  # (Python's lzma.decompress stops at stream padding; the xz tool does not)
+        assert subprocess.run(["xz", "-dc"], input=f, capture_output=True, check=True).stdout == p
+    blocks = _check_blocks_with_liblzma(f, p)
+    assert [b["check_type"] for b in blocks] == [4, 1, 10]
+    assert blocks[2]["dict_size"] == 1 << 16
+
+
+def test_index_of_a_multi_block_file():
+    f, p = _multi_block()
+    blocks = _check_blocks_with_liblzma(f, p)
+    assert len(blocks) == 8 and all(b["uncomp_len"] <= 131072 for b in blocks)
+
+
+def test_malformed_and_unsupported_files_are_refused():
+    f, _ = _three_streams()
+    for bad in (f[:-1], f[: len(f) // 2], f[1:], b"", b"\0" * 64):
+        with pytest.raises(LzmaError):
+            lzma_amd.xz_index(bad)
+    flip = bytearray(f)
+    flip[-20] ^= 1  # inside the last stream's index / footer
+    with pytest.raises(LzmaError):
+        lzma_amd.xz_index(bytes(flip))
+    bcj = lzma.compress(b"\x90" * 5000, format=lzma.FORMAT_XZ,
+                        filters=[{"id": lzma.FILTER_X86}, {"id": lzma.FILTER_LZMA2, "preset": 1}])
+    with pytest.raises(LzmaError) as e:
+        lzma_amd.xz_index(bcj)
+    assert e.value.status == lzma_amd.ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+def test_whole_files_decode_as_one_batch(ctx):
+    for f, p in (_three_streams(), _multi_block(), _multi_block(65536)):
+        assert lzma_amd.xz_decode(ctx, f) == p
+    # an empty file body: a stream with no blocks
+    e = lzma.compress(b"", format=lzma.FORMAT_XZ)
+    assert lzma_amd.xz_decode(ctx, e) == b""
+
+
+@pytest.mark.gpu
+def test_block_check_is_verified(ctx):
+    f, p = _multi_block()
+    blocks, _ = lzma_amd.xz_index(f)
+    bad = bytearray(f)
+    bad[blocks[3]["check_off"]] ^= 0x40  # the stored CRC64 of block 3
+    with pytest.raises(LzmaError):
+        lzma_amd.xz_decode(ctx, bytes(bad))
+    assert lzma_amd.xz_decode(ctx, bytes(bad), verify=False) == p
+    bad = bytearray(f)
+    bad[blocks[2]["comp_off"] + 40] ^= 0x10  # payload damage: wrong bytes or a decode error, never silent
+    with pytest.raises(LzmaError):
+        lzma_amd.xz_decode(ctx, bytes(bad))
