@@ -36,10 +36,10 @@ double run(int per_cu, int iters, uint32_t *d)
 {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<MODE>, dim3(256 * per_cu), dim3(64), 8192, 0, d, 10, 1u);
+    hipLaunchKernelGGL(k<MODE>, dim3(256 * per_cu), dim3(64), 4096, 0, d, 10, 1u);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(256 * per_cu), dim3(64), 8192, 0, d, iters, 1u);
+    hipLaunchKernelGGL(k<MODE>, dim3(256 * per_cu), dim3(64), 4096, 0, d, iters, 1u);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -51,8 +51,8 @@ int main()
     const int iters = 20000;
     const char *names[] = {"8 SALU", "8 SALU + cmp + br-nt", "9 SALU", "8 SALU + wrlane + rdlane", "8 SALU + 2 VALU", "8 SALU + 6 VALU", "tree level (9S+br+2lane)", "tree level VALU bound", "8 SALU + s_nop 0", "8 SALU + s_nop 1"};
     int salu[] = {8, 9, 9, 8, 8, 8, 9, 8, 8, 8};
-    for (int mode : {0, 2, 8, 9}) {
-        for (int pc : {16}) {
+    for (int mode : {0, 6}) {
+        for (int pc : {12, 16, 17, 18, 20, 24, 28, 32}) {
             double ms = 0;
             switch (mode) {
             case 0: ms = run<0>(pc, iters, d); break; case 1: ms = run<1>(pc, iters, d); break;
