@@ -41,7 +41,8 @@ enum {
                                     the 5 range-coder init bytes (reader1.go:78-98,153-156)     */
     XLZ_ERR_RC_INIT = -4,        /* first range-coder byte != 0 (range_decoder.go:32-34)         */
     XLZ_ERR_UNEXPECTED_EOF = -5, /* io.ErrUnexpectedEOF from LZMA2 framing (reader2.go:104-127)  */
-    XLZ_ERR_OUT_CAP = -6,        /* new: out_cap smaller than the decoded size; out_len==out_cap */
+    XLZ_ERR_OUT_CAP = -6,        /* new: out_cap smaller than the decoded size; out_len==out_cap,
+                                    in_consumed unspecified (the reference has no output limit)  */
     XLZ_ERR_BAD_ARG = -7,        /* new: NULL pointer / unknown format                           */
     XLZ_ERR_DEVICE = -8,         /* new: HIP runtime failure or no gfx950 device                 */
     XLZ_ERR_UNSUPPORTED = -9,    /* new: stream outside what the GPU path implements (DESIGN.md

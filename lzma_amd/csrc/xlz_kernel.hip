@@ -724,7 +724,8 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
             d.pos += n;
             d.wpos += n; // window.ReadFrom (window.go:146-153); the dictionary may be smaller than n
             while (d.wpos >= d.dict_size) d.wpos -= d.dict_size;
-            in_window(d, in_pos(d) + n, lane);
+            // out of room: the byte that did not fit has been read (as in the oracle's byte loop)
+            in_window(d, in_pos(d) + n + (overflow ? 1u : 0u), lane);
             if (overflow) return ST_ERR_OUT_CAP;
             reload_context(d, out, lane);
             continue;

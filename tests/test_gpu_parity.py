@@ -459,3 +459,18 @@ def test_host_pipeline_big_and_ragged_streams(ctx):
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errs, errs
+
+
+def test_differential_fuzz_against_the_oracle(ctx):
+    """tools/fuzz_gpu.py for a few seconds: random families, sizes around the fast path's margins,
+    lc/lp/pb, odd dictionary sizes, caps, truncations, byte flips, damaged LZMA2 framing -- bytes,
+    status and consumed input against the oracle.  (A five-minute run of the same tool, 53 760
+    streams, is recorded in DESIGN.md.)"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(root, "tools", "fuzz_gpu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, n_bad = mod.fuzz(ctx, budget=8.0, seed=20251004, per_round=96, verbose=False)
+    assert n >= 96 and n_bad > 0
