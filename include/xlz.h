@@ -162,6 +162,12 @@ int xlz_reader_close(xlz_reader *r); /* readCloser.Close (readcloser.go:16-28); 
                                         XLZ_ERR_CLOSED; the handle stays valid until _free       */
 void xlz_reader_free(xlz_reader *r);
 
+/* Multi-GPU form of xlz_decode_batch: one context per GPU; the batch is
+ * split by stream (balanced by out_cap), every context decodes its shard on its own host
+ * thread, results come back in input order.  No device-to-device traffic.                   */
+int xlz_decode_batch_multi(xlz_ctx *const *ctxs, size_t n_ctx, const xlz_stream_desc *streams,
+                           size_t n, xlz_result *results);
+
 /* ---- .xz container front-end ----------------------------
  * Outside the reference (which has no container code): an .xz file is a list of independent
  * blocks, each ONE raw LZMA2 stream with its own dictionary -- what NewReader2(in, dictSize)

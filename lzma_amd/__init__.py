@@ -140,6 +140,23 @@ def decode_batch(ctx, streams):
     return [(outs[i].raw[: res[i].out_len], res[i].status, res[i].in_consumed) for i in range(n)]
 
 
+def decode_batch_on(ctxs, streams):
+    """decode_batch over several contexts (one per GPU) through xlz_decode_batch_multi: sharded by
+    stream inside the library, one host thread per context, results in input order."""
+    streams = list(streams)
+    n = len(streams)
+    if n == 0:
+        return []
+    descs, keep, outs = _make_descs(streams)
+    res = (N.Result * n)()
+    hs = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    st = N.lib().xlz_decode_batch_multi(hs, len(ctxs), descs, n, res)
+    if st != OK:
+        raise LzmaError(st, "xlz_decode_batch_multi")
+    del keep
+    return [(outs[i].raw[: res[i].out_len], res[i].status, res[i].in_consumed) for i in range(n)]
+
+
 class Batch:
     """Device-resident batch: upload once, run many times (xlz_batch)."""
 

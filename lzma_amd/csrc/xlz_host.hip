@@ -1001,6 +1001,50 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     return st;
 }
 
+// Multi-GPU form of xlz_decode_batch: the streams are independent, so the
+// batch is split by stream -- longest-processing-time greedy on the output capacity -- and every
+// context (one per GPU) decodes its shard on its own host thread.  No device-to-device traffic.
+extern "C" int xlz_decode_batch_multi(xlz_ctx *const *ctxs, size_t n_ctx, const xlz_stream_desc *streams, size_t n,
+                                      xlz_result *results)
+{
+    if (!ctxs || n_ctx == 0 || (!streams && n) || (!results && n)) return XLZ_ERR_BAD_ARG;
+    for (size_t c = 0; c < n_ctx; c++)
+        if (!ctxs[c]) return XLZ_ERR_BAD_ARG;
+    if (n_ctx == 1 || n <= 1) return xlz_decode_batch(ctxs[0], streams, n, results);
+    std::vector<size_t> order(n);
+    std::iota(order.begin(), order.end(), (size_t)0);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](size_t a, size_t b) { return streams[a].out_cap > streams[b].out_cap; });
+    std::vector<std::vector<size_t>> shard(n_ctx);
+    std::vector<uint64_t> load(n_ctx, 0);
+    for (size_t i : order) {
+        size_t k = 0;
+        for (size_t c = 1; c < n_ctx; c++)
+            if (load[c] < load[k]) k = c;
+        shard[k].push_back(i);
+        load[k] += (uint64_t)streams[i].out_cap + 1;
+    }
+    std::vector<int> st(n_ctx, XLZ_OK);
+    auto work = [&](size_t c) {
+        std::vector<size_t> &idx = shard[c];
+        if (idx.empty()) return;
+        std::sort(idx.begin(), idx.end());
+        std::vector<xlz_stream_desc> d(idx.size());
+        std::vector<xlz_result> r(idx.size());
+        for (size_t k = 0; k < idx.size(); k++) d[k] = streams[idx[k]];
+        st[c] = xlz_decode_batch(ctxs[c], d.data(), d.size(), r.data());
+        if (st[c] == XLZ_OK)
+            for (size_t k = 0; k < idx.size(); k++) results[idx[k]] = r[k];
+    };
+    std::vector<std::thread> th;
+    for (size_t c = 1; c < n_ctx; c++) th.emplace_back(work, c);
+    work(0);
+    for (auto &x : th) x.join();
+    for (size_t c = 0; c < n_ctx; c++)
+        if (st[c] != XLZ_OK) return st[c];
+    return XLZ_OK;
+}
+
 // ---------------------------------------------------------------- readers ----
 // Pull-style mirror of Reader1 / Reader2 / readCloser (reader1.go:223-254,
 // reader2.go:216-250, readcloser.go:9-41) on top of the batch engine.

@@ -323,6 +323,19 @@ def test_multi_device_driver_on_gpu(ctx):
     streams = [Stream(corpus.compress_alone(p), out_cap=len(p)) for p in ps]
     res = multigpu.decode_batch_multi(streams, [0, 0])   # two host threads, two contexts, one GPU
     assert [r[0] for r in res] == ps and all(r[1] == 0 for r in res)
+    # the same inside the library: xlz_decode_batch_multi over three contexts (all on this GPU),
+    # ragged sizes and one bad stream; results must come back in input order
+    ps2 = [corpus.plain("TRMZ"[i % 4], 950 + i, 1000 + 9000 * (i % 7)) for i in range(23)]
+    streams2 = [Stream(corpus.compress_alone(p), out_cap=len(p)) for p in ps2]
+    streams2[5] = Stream(streams2[5].data[:40], out_cap=len(ps2[5]))
+    ctxs = [ctx, lzma_amd.Context(0), lzma_amd.Context(0)]
+    res2 = lzma_amd.decode_batch_on(ctxs, streams2)
+    for i, (r, p) in enumerate(zip(res2, ps2)):
+        if i == 5:
+            assert r == oracle.lzma1_alone(streams2[5].data, len(p))
+        else:
+            assert r[0] == p and r[1] == 0, i
+    assert lzma_amd.decode_batch_on([ctx], streams2[:3]) == lzma_amd.decode_batch(ctx, streams2[:3])
 
 
 # ------------------------------------------------ models too large for LDS (lc+lp > 6) ----
