@@ -348,22 +348,21 @@ def tree_update_rec(nb, base, store=True):
         emit("v_cndmask_b32 v60, v38, v60, vcc\nds_write_b16 v60, v61")
 
 
-def len_prefetch(base, lane_c):
-    """request the three length trees of this posState (blocks v41..v46); bounds("v40") was just
-    emitted: the bound of the coder's first decision (head lane lane_c) is read here, in the wait
-    states"""
-    emit("v_readlane_b32 s80, v55, %d" % lane_c)
+def len_request(base):
+    """request the low and mid length trees of this posState (blocks v41, v42; s92 = posState * 16).
+    The high tree (four blocks) is rare and is requested where it is needed."""
     emit("""
     s_lshl_b32 s92, s90, 4
     v_add_u32 v59, s92, v56
     ds_read_u16 v41, v59 offset:%d
     ds_read_u16 v42, v59 offset:%d
-    ds_read_u16 v43, v56 offset:%d
-    ds_read_u16 v44, v56 offset:%d
-    ds_read_u16 v45, v56 offset:%d
-    ds_read_u16 v46, v56 offset:%d
-    """ % ((base + LEN_LOW) * 2, (base + LEN_MID) * 2, (base + LEN_HIGH) * 2, (base + LEN_HIGH) * 2 + 128,
-           (base + LEN_HIGH) * 2 + 256, (base + LEN_HIGH) * 2 + 384))
+    """ % ((base + LEN_LOW) * 2, (base + LEN_MID) * 2))
+
+
+def len_pick(lane_c):
+    """bounds("v40") was emitted at least one instruction ago: read the bound of the length
+    coder's first decision (head lane lane_c)"""
+    emit("v_readlane_b32 s80, v55, %d" % lane_c)
 
 
 def posslot_request(static):
@@ -399,7 +398,15 @@ def len_decode(tag, base, lane_c, lane_c2, posslot):
     emit("s_branch %s" % L(tag + "end"))
     label(tag + "hi")
     hbit_one(lane_c2)
-    emit("v_mov_b32 v58, %d\ns_waitcnt lgkmcnt(0)" % ((base + LEN_HIGH) * 2))
+    emit("""
+    ds_read_u16 v43, v56 offset:%d
+    ds_read_u16 v44, v56 offset:%d
+    ds_read_u16 v45, v56 offset:%d
+    ds_read_u16 v46, v56 offset:%d
+    v_mov_b32 v58, %d
+    s_waitcnt lgkmcnt(0)
+    """ % ((base + LEN_HIGH) * 2, (base + LEN_HIGH) * 2 + 128, (base + LEN_HIGH) * 2 + 256, (base + LEN_HIGH) * 2 + 384,
+           (base + LEN_HIGH) * 2))
     walk_rec(8, ["v43", "v44", "v45", "v46"])
     emit("s_andn2_b32 s89, 0xff, s88\ns_add_u32 s89, s89, 16")
     if posslot:
@@ -591,11 +598,12 @@ def gen():
     label("match")
     hbit_one(H_IS_MATCH, next_head=H_IS_REP)
     emit("s_and_b32 s90, %[wpos], %[pos_mask]")  # posState, for the length coders
+    len_request(P_LEN)  # speculative (a rep match asks for its own trees): one LDS round trip earlier
     hbit(H_IS_REP, L("rep"), stage=2)
     # simple match (:215-668)
     bounds("v40")  # for the length coder's first decision
     emit("s_mov_b32 %[rep3], %[rep2]\ns_mov_b32 %[rep2], %[rep1]\ns_mov_b32 %[rep1], %[rep0]")
-    len_prefetch(P_LEN, H_LEN_C)
+    len_pick(H_LEN_C)
     emit("ds_read_u16 v35, v56 offset:%d" % (P_ALIGN * 2))
     len_decode("lm", P_LEN, H_LEN_C, H_LEN_C2, posslot=True)  # leaves the posSlot block requested, s92 = its base
     emit("s_waitcnt lgkmcnt(0)")
@@ -728,7 +736,8 @@ def gen():
     """)
     label("replen")
     bounds("v40")
-    len_prefetch(P_REP_LEN, H_REP_C)
+    len_request(P_REP_LEN)
+    len_pick(H_REP_C)
     len_decode("lr", P_REP_LEN, H_REP_C, H_REP_C2, posslot=False)
     emit("s_cmp_lt_u32 %[state], 7\ns_cselect_b32 %[state], 8, 11\ns_add_u32 s89, s89, 2")
     # ------------------------------------------------------------- window.CopyMatch (window.go:55-87)
