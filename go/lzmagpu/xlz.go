@@ -233,3 +233,31 @@ func DecodeBatch(streams [][]byte, outs [][]byte) ([]int, []error, error) {
 	}
 	return lens, errs, nil
 }
+
+// DecodeXZ decodes a whole .xz file (all streams, all blocks) as ONE GPU batch: every block is a
+// raw LZMA2 stream of its own -- what NewReader2(in, dictSize) takes -- so the file's block index
+// is the batch (xlz_xz_index / xlz_xz_decode, include/xlz.h).  Not part of the reference, which has
+// no container code; verify checks each block's CRC32 / CRC64.
+func DecodeXZ(file []byte, verify bool) ([]byte, error) {
+	c, err := context()
+	if err != nil {
+		return nil, err
+	}
+	fp, fl := cbuf(file)
+	var nBlocks C.size_t
+	var total C.uint64_t
+	if st := C.xlz_xz_index(fp, fl, nil, 0, &nBlocks, &total); st != C.XLZ_OK {
+		return nil, statusToError(st, true)
+	}
+	out := make([]byte, int(total)+1)
+	op, _ := cbuf(out)
+	var outLen C.uint64_t
+	v := C.int(0)
+	if verify {
+		v = 1
+	}
+	if st := C.xlz_xz_decode(c, fp, fl, op, C.size_t(total), &outLen, v, nil); st != C.XLZ_OK {
+		return nil, statusToError(st, false)
+	}
+	return out[:int(outLen)], nil
+}
