@@ -143,29 +143,38 @@ def emit_stubs():
         """ % (L(k + "b"), L(k + "b")))
 
 
-def need_copy_done():
+def need_copy_done(inline=False):
     """The previous match copy's load is left in flight while the next packet decodes; whoever
     needs its bytes (prevByte / matchByte for a literal, the next copy, any exit) comes here
     first.  s94 = copy pending, v48 = its destination offsets, v49 = loaded bytes, s95 = len."""
     uid[0] += 1
     k = "f%d" % uid[0]
+    if inline:  # a copy is nearly always pending here: no branch out and back
+        emit("s_cmp_eq_u32 s94, 0\ns_cbranch_scc1 %s" % L(k + "b"))
+        finish_body()
+        label(k + "b")
+        return
     emit("s_cmp_eq_u32 s94, 0\ns_cbranch_scc0 %s" % L(k))
     label(k + "b")
     finish_sites.append(k)
 
 
+def finish_body():
+    emit("""
+    s_waitcnt vmcnt(0)
+    global_store_byte v48, v49, %[outp]
+    s_sub_u32 s80, s95, 1
+    v_readlane_b32 %[prev], v49, s80
+    v_readlane_b32 %[mb], v49, s95
+    s_mov_b32 s94, 0
+    """)
+
+
 def emit_finish_blocks():
     for k in finish_sites:
         label(k)
-        emit("""
-        s_waitcnt vmcnt(0)
-        global_store_byte v48, v49, %%[outp]
-        s_sub_u32 s80, s95, 1
-        v_readlane_b32 %%[prev], v49, s80
-        v_readlane_b32 %%[mb], v49, s95
-        s_mov_b32 s94, 0
-        s_branch %s
-        """ % L(k + "b"))
+        finish_body()
+        emit("s_branch %s" % L(k + "b"))
 
 
 def head_update(lane, bit):
@@ -385,7 +394,11 @@ def len_decode(tag, base, lane_c, lane_c2, posslot):
     if posslot:
         posslot_request(False)
     tree_update(3, ["v41"])
-    emit("s_branch %s" % L(tag + "end"))
+    label(tag + "end")  # the common (low) path runs straight on; mid and high trees are out of line
+    deferred.append(lambda: len_decode_rest(tag, base, lane_c, lane_c2, posslot))
+
+
+def len_decode_rest(tag, base, lane_c, lane_c2, posslot):
     label(tag + "c2")
     hbit_one(lane_c, next_head=lane_c2)
     hbit(lane_c2, L(tag + "hi"), stage=2)
@@ -412,10 +425,11 @@ def len_decode(tag, base, lane_c, lane_c2, posslot):
     if posslot:
         posslot_request(True)
     tree_update_rec(8, "v58")
-    label(tag + "end")
+    emit("s_branch %s" % L(tag + "end"))
 
 
 wstubs = []
+deferred = []
 
 
 def wpos_advance(amount):
@@ -496,16 +510,8 @@ def plain_literal():
     emit("s_branch %s" % L("pktl"))
 
 
-def gen():
-    # The gathers of packet n+1 are issued from the tail of packet n (software pipelining):
-    # by the time the loop top has done its limit checks the probabilities have arrived.
-    emit("v_lshlrev_b32 v56, 1, %%[vlane]\ns_mov_b32 s94, 0\nv_mov_b32 v38, %d\nv_mov_b32 v29, %%[code]" % ((P_LEN + 2) * 2))
-    # per-lane constants of tree_update: v31 = floor(log2(lane)) + 1, v30 = lane (lane 0: never a slot)
-    emit("v_cmp_eq_u32 vcc, 0, %[vlane]\nv_ffbh_u32 v31, %[vlane]\nv_sub_u32 v31, 32, v31\n"
-         "v_cndmask_b32 v30, %[vlane], -1, vcc")
-    head_issue(first=True)
-    literal_context()  # no copy is pending on entry: prevByte is valid
-    emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
+def sec_packet_after_literal():
+    """packet head when the previous packet was a literal, and the plain literal"""
     # ------------------------------------------------------------- packet after a literal
     # state < 7, no copy pending, literal blocks requested: the three tests of the general
     # packet head are known
@@ -521,6 +527,10 @@ def gen():
     """ % (L("x0"), H_IS_MATCH, L("x0")))
     hbit(H_IS_MATCH, L("match"), stage=2)
     plain_literal()
+
+
+def sec_packet_general():
+    """general packet head, literal after a match (plain or matched)"""
     # ------------------------------------------------------------- packet head
     label("pkt")
     emit("s_waitcnt lgkmcnt(0)")
@@ -594,6 +604,10 @@ def gen():
     """)
     literal_context(prev_v="v32")
     emit("s_branch %s" % L("pktl"))
+
+
+def sec_match():
+    """simple match up to the validity test of the new distance; falls into sec_copy"""
     # ------------------------------------------------------------- match or rep
     label("match")
     hbit_one(H_IS_MATCH, next_head=H_IS_REP)
@@ -695,7 +709,11 @@ def gen():
     s_cmp_le_u32 %%[rep0], s80
     s_cbranch_scc0 %s
     """ % L("dbad"))
-    emit("s_add_u32 s89, s89, 2\ns_branch %s" % L("copy"))
+    emit("s_add_u32 s89, s89, 2")  # falls into the copy (the rep paths branch to it)
+
+
+def sec_rep():
+    """rep matches; out of line, ends with a branch to the copy"""
     # ------------------------------------------------------------- rep match (:685-1123)
     label("rep")
     hbit_one(H_IS_REP, next_head=H_G0)
@@ -739,7 +757,11 @@ def gen():
     len_request(P_REP_LEN)
     len_pick(H_REP_C)
     len_decode("lr", P_REP_LEN, H_REP_C, H_REP_C2, posslot=False)
-    emit("s_cmp_lt_u32 %[state], 7\ns_cselect_b32 %[state], 8, 11\ns_add_u32 s89, s89, 2")
+    emit("s_cmp_lt_u32 %%[state], 7\ns_cselect_b32 %%[state], 8, 11\ns_add_u32 s89, s89, 2\ns_branch %s" % L("copy"))
+
+
+def sec_copy():
+    """window.CopyMatch of short non-overlapping matches; falls into the general packet head"""
     # ------------------------------------------------------------- window.CopyMatch (window.go:55-87)
     label("copy")
     # done here if len < 64, len < distance (no overlap) and the source lies inside the window's
@@ -753,7 +775,7 @@ def gen():
     s_cmp_le_u32 s80, s81
     s_cbranch_scc0 %s
     """ % L("x3"))
-    need_copy_done()  # the new source may overlap the bytes the pending copy still has to store
+    need_copy_done(inline=True)  # the new source may overlap the bytes the pending copy still has to store
     emit("""
     v_add_u32 v48, %[pos], %[vlane]
     v_subrev_u32 v61, s93, v48
@@ -764,7 +786,11 @@ def gen():
     """)
     wpos_advance("s89")
     head_issue()  # next packet's head gather; its literal blocks wait for the copy (prevByte)
-    emit("s_mov_b32 s97, 0\ns_branch %s" % L("pkt"))
+    emit("s_mov_b32 s97, 0")  # falls into the general packet head
+
+
+def sec_exits():
+    """exit codes, completion of pending work, out-of-line stubs"""
     # ------------------------------------------------------------- exits
     label("dbad")
     emit("s_cmp_eq_u32 %%[rep0], -1\ns_cbranch_scc1 %s\ns_branch %s" % (L("x2"), L("x1")))
@@ -785,6 +811,31 @@ def gen():
     emit_finish_blocks()
     label("end")
 
+
+
+
+
+def gen():
+    # The gathers of packet n+1 are issued from the tail of packet n (software pipelining):
+    # by the time the loop top has done its limit checks the probabilities have arrived.
+    emit("v_lshlrev_b32 v56, 1, %%[vlane]\ns_mov_b32 s94, 0\nv_mov_b32 v38, %d\nv_mov_b32 v29, %%[code]" % ((P_LEN + 2) * 2))
+    # per-lane constants of tree_update: v31 = floor(log2(lane)) + 1, v30 = lane (lane 0: never a slot)
+    emit("v_cmp_eq_u32 vcc, 0, %[vlane]\nv_ffbh_u32 v31, %[vlane]\nv_sub_u32 v31, 32, v31\n"
+         "v_cndmask_b32 v30, %[vlane], -1, vcc")
+    head_issue(first=True)
+    literal_context()  # no copy is pending on entry: prevByte is valid
+    emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
+    # Layout: the match path runs straight through -- match, distance, copy, next packet's head --
+    # and everything rarer is out of line (length coder's mid / high trees: deferred blocks; rep
+    # matches).  A taken branch costs about as much as a scalar instruction plus a fetch bubble.
+    sec_packet_after_literal()
+    sec_match()
+    sec_copy()
+    sec_packet_general()
+    sec_rep()
+    for f in deferred:
+        f()
+    sec_exits()
 
 import hazards  # noqa: E402  (tools/hazards.py: the gfx950 wait states the assembler does not insert in inline asm)
 
