@@ -631,12 +631,11 @@ def sec_match():
     tree_update(6, ["v36"])
     emit("s_branch %s" % L("distdone"))
     label("dist")
+    # numDirectBits = (slot >> 1) - 1 and the distance's base (2 | slot & 1) << numDirectBits
+    # (:491-492) from two 64-entry tables held in v24 / v25, lane = slot
     emit("""
-    s_lshr_b32 s83, s98, 1
-    s_sub_u32 s83, s83, 1
-    s_and_b32 s84, s98, 1
-    s_or_b32 s84, s84, 2
-    s_lshl_b32 s93, s84, s83
+    v_readlane_b32 s83, v24, s98
+    v_readlane_b32 s93, v25, s98
     s_cmp_lt_u32 s98, 14
     s_cbranch_scc0 %s
     s_sub_u32 s84, s93, s98
@@ -664,7 +663,7 @@ def sec_match():
     # numDirectBits - 4 = s83 - 4 (2..26) halvings, unrolled; entered through a branch table so
     # that no loop counter is kept.  Exactly the reference's arithmetic: t = sign(code - range).
     # Only the range stays on the scalar side (its normalisation test needs SCC): the code (v29)
-    # and the collected, complemented bits (v33 = 2 * acc + (t < 0)) are wave-uniform VGPR values,
+    # and the collected bits (v33 = 2 * acc + (t >= 0)) are wave-uniform VGPR values,
     # four VALU instructions per bit instead of four scalar ones.
     emit("""
     s_getpc_b64 s[80:81]
@@ -682,22 +681,16 @@ def sec_match():
         emit("""
         s_lshr_b32 %[range], %[range], 1
         v_subrev_u32 v55, %[range], v29
-        v_cmp_gt_i32 vcc, 0, v55
+        v_cmp_le_i32 vcc, 0, v55
         """)
         # the normalisation test sits in the VCC wait states; the stub (which shifts v29) is
         # entered after the bit is done
-        nchk(mid="s_nop 0\nv_cndmask_b32 v29, v55, v29, vcc\nv_addc_co_u32 v33, vcc, v33, v33, vcc")
-    emit("""
-    v_readfirstlane_b32 s84, v33
-    s_sub_u32 s83, s83, 4
-    s_bfm_b32 s80, s83, 0
-    s_andn2_b32 s84, s80, s84
-    s_lshl_b32 s84, s84, 4
-    """)
+        nchk(mid="s_nop 0\nv_cndmask_b32 v29, v29, v55, vcc\nv_addc_co_u32 v33, vcc, v33, v33, vcc")
+    emit("v_readfirstlane_b32 s84, v33\ns_lshl_b32 s84, s84, 4")
     # reverse tree over alignDecoderProbs (:579-625): M = 1 b0 b1 b2 b3
     walk(4, ["v35"], filler="s_add_u32 s93, s93, s84\nv_mov_b32 v58, %d" % (P_ALIGN * 2))
     tree_update(4, ["v35"])
-    emit("s_not_b32 s80, s88\ns_brev_b32 s80, s80\ns_lshr_b32 s80, s80, 28\ns_add_u32 %[rep0], s93, s80")
+    emit("v_readlane_b32 s80, v23, s88\ns_add_u32 %[rep0], s93, s80")  # v23: slot -> the four bits, reversed
     label("distdone")
     # :633-653 in one test.  rep0 is valid iff rep0 < dictSize and (window full or rep0 <= window.pos);
     # while the window is not full window.pos = pos - wbase < dictSize, so both say
@@ -822,6 +815,20 @@ def gen():
     # per-lane constants of tree_update: v31 = floor(log2(lane)) + 1, v30 = lane (lane 0: never a slot)
     emit("v_cmp_eq_u32 vcc, 0, %[vlane]\nv_ffbh_u32 v31, %[vlane]\nv_sub_u32 v31, 32, v31\n"
          "v_cndmask_b32 v30, %[vlane], -1, vcc")
+    # distance tables, lane = posSlot: v24 = (slot >> 1) - 1, v25 = (2 | slot & 1) << v24;
+    # v23, lane = final slot of the align tree (1, then the complemented bits b0..b3): the value
+    # b0 | b1 << 1 | b2 << 2 | b3 << 3 (reverse tree, bit_tree_decoder.go:42-70)
+    emit("""
+    v_lshrrev_b32 v24, 1, %[vlane]
+    v_add_u32 v24, -1, v24
+    v_and_b32 v25, 1, %[vlane]
+    v_or_b32 v25, 2, v25
+    v_lshlrev_b32 v25, v24, v25
+    v_not_b32 v23, %[vlane]
+    v_and_b32 v23, 15, v23
+    v_bfrev_b32 v23, v23
+    v_lshrrev_b32 v23, 28, v23
+    """)
     head_issue(first=True)
     literal_context()  # no copy is pending on entry: prevByte is valid
     emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
