@@ -358,11 +358,11 @@ def tree_update_rec(nb, base, store=True):
 
 
 def len_request(base):
-    """request the low and mid length trees of this posState (blocks v41, v42; s92 = posState * 16).
-    The high tree (four blocks) is rare and is requested where it is needed."""
+    """request the low and mid length trees of this posState (blocks v41, v42; v22 = posState, on
+    the VALU).  The high tree (four blocks) is rare and is requested where it is needed."""
     emit("""
-    s_lshl_b32 s92, s90, 4
-    v_add_u32 v59, s92, v56
+    v_and_b32 v22, %%[wpos], %%[vpm]
+    v_lshl_add_u32 v59, v22, 4, v56
     ds_read_u16 v41, v59 offset:%d
     ds_read_u16 v42, v59 offset:%d
     """ % ((base + LEN_LOW) * 2, (base + LEN_MID) * 2))
@@ -380,7 +380,7 @@ def posslot_request(static):
     if static:
         emit("s_movk_i32 s92, %d" % ((P_POS_SLOT + 3 * 64) * 2))
     else:
-        emit("s_min_u32 s83, s89, 3\ns_lshl_b32 s83, s83, 7\ns_add_u32 s92, s83, %d" % (P_POS_SLOT * 2))
+        emit("v_readlane_b32 s92, v21, s89")  # table: lane = length 0..7 -> base of posSlot[min(len, 3)]
     emit("v_add_u32 v59, s92, v56\nds_read_u16 v36, v59")
 
 
@@ -389,7 +389,7 @@ def len_decode(tag, base, lane_c, lane_c2, posslot):
     posslot: request the distance-slot block as soon as the length is known (simple match)."""
     hbit(lane_c, L(tag + "c2"), stage=2)  # bounds("v40") and the lane read: len_prefetch
     emit("s_waitcnt lgkmcnt(0)")
-    walk(3, ["v41"], filler="s_add_u32 s82, s92, %d\nv_mov_b32 v58, s82" % ((base + LEN_LOW) * 2))  # s92 = posState * 16
+    walk(3, ["v41"], filler="v_lshlrev_b32 v58, 4, v22\nv_add_u32 v58, %d, v58" % ((base + LEN_LOW) * 2))
     emit("s_andn2_b32 s89, 7, s88")
     if posslot:
         posslot_request(False)
@@ -403,7 +403,7 @@ def len_decode_rest(tag, base, lane_c, lane_c2, posslot):
     hbit_one(lane_c, next_head=lane_c2)
     hbit(lane_c2, L(tag + "hi"), stage=2)
     emit("s_waitcnt lgkmcnt(0)")
-    walk(3, ["v42"], filler="s_add_u32 s82, s92, %d\nv_mov_b32 v58, s82" % ((base + LEN_MID) * 2))
+    walk(3, ["v42"], filler="v_lshlrev_b32 v58, 4, v22\nv_add_u32 v58, %d, v58" % ((base + LEN_MID) * 2))
     emit("s_xor_b32 s89, s88, 7")
     if posslot:
         posslot_request(True)
@@ -611,7 +611,6 @@ def sec_match():
     # ------------------------------------------------------------- match or rep
     label("match")
     hbit_one(H_IS_MATCH, next_head=H_IS_REP)
-    emit("s_and_b32 s90, %[wpos], %[pos_mask]")  # posState, for the length coders
     len_request(P_LEN)  # speculative (a rep match asks for its own trees): one LDS round trip earlier
     hbit(H_IS_REP, L("rep"), stage=2)
     # simple match (:215-668)
@@ -621,7 +620,7 @@ def sec_match():
     emit("ds_read_u16 v35, v56 offset:%d" % (P_ALIGN * 2))
     len_decode("lm", P_LEN, H_LEN_C, H_LEN_C2, posslot=True)  # leaves the posSlot block requested, s92 = its base
     emit("s_waitcnt lgkmcnt(0)")
-    walk(6, ["v36"], filler="s_cmp_lt_u32 %[state], 7\ns_cselect_b32 %[state], 7, 10\nv_mov_b32 v58, s92")
+    walk(6, ["v36"], filler="v_readlane_b32 %[state], v20, %[state]\nv_mov_b32 v58, s92")  # stateUpdateMatch as a table
     emit("""
     s_andn2_b32 s98, 63, s88
     s_cmp_lt_u32 s98, 4
@@ -829,6 +828,17 @@ def gen():
     v_bfrev_b32 v23, v23
     v_lshrrev_b32 v23, 28, v23
     """)
+    # v21, lane = raw length 0..7: byte address of posSlot[min(len, 3)]; v20, lane = state:
+    # stateUpdateMatch (state.go:165-171)
+    emit("""
+    v_min_u32 v21, 3, %%[vlane]
+    v_lshlrev_b32 v21, 7, v21
+    v_add_u32 v21, %d, v21
+    v_cmp_gt_u32 vcc, 7, %%[vlane]
+    v_mov_b32 v20, 10
+    s_nop 1
+    v_cndmask_b32 v20, v20, 7, vcc
+    """ % (P_POS_SLOT * 2))
     head_issue(first=True)
     literal_context()  # no copy is pending on entry: prevByte is valid
     emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
