@@ -337,24 +337,21 @@ def walk_rec(nbits, blocks, entries=None):
 
 
 def tree_update_rec(nb, base, store=True):
-    """model updates of a walk_rec in ONE vector operation, lane k = level k: slot = s88 >> (nb-k),
-    !bit = (s88 >> (nb-k-1)) & 1, p = v54; lanes >= nb store to the unused slot (v38)."""
-    if store:
-        emit("v_cmp_gt_u32 vcc, %d, %%[vlane]" % nb)
+    """model updates of a walk_rec in ONE vector operation, lane k = level k: slot = s88 >> (8-k),
+    !bit = (s88 >> (7-k)) & 1, p = v54; lanes >= 8 store to the unused slot (v38).  The per-lane
+    shift counts 8-k and 7-k are v19 / v18, the lanes-below-8 mask is s[76:77] (loop constants)."""
+    assert nb == 8
     emit("""
-    v_sub_u32 v55, %d, %%[vlane]
-    v_lshrrev_b32 v60, v55, s88
-    v_add_u32 v61, -1, v55
-    v_lshrrev_b32 v61, v61, s88
-    v_and_b32 v61, 1, v61
+    v_lshrrev_b32 v60, v19, s88
+    v_bfe_u32 v61, s88, v18, 1
     v_lshl_add_u32 v60, v60, 1, %s
     v_mul_u32_u24 v61, 0x7e1, v61
     v_sub_u32 v61, v54, v61
     v_ashrrev_i32 v61, 5, v61
     v_sub_u32 v61, v54, v61
-    """ % (nb, base))
+    """ % base)
     if store:
-        emit("v_cndmask_b32 v60, v38, v60, vcc\nds_write_b16 v60, v61")
+        emit("v_cndmask_b32 v60, v38, v60, s[76:77]\nds_write_b16 v60, v61")
 
 
 def len_request(base):
@@ -593,13 +590,13 @@ def sec_packet_general():
     label("mlfin")
     literal_tail()
     # lanes < s98 -> matched table (HBM; the rest to its unused slot 0), lanes s98..7 -> plain table
-    emit("v_cmp_gt_u32 vcc, s98, %[vlane]\nv_cmp_gt_u32 s[82:83], 8, %[vlane]")
+    emit("v_cmp_gt_u32 vcc, s98, %[vlane]")
     tree_update_rec(8, "v39", store=False)
     emit("""
     v_cndmask_b32 v57, 0, v57, vcc
     global_store_short v57, v61, %[mptr]
     v_cndmask_b32 v60, v60, v38, vcc
-    v_cndmask_b32 v60, v38, v60, s[82:83]
+    v_cndmask_b32 v60, v38, v60, s[76:77]
     ds_write_b16 v60, v61
     """)
     literal_context(prev_v="v32")
@@ -828,6 +825,8 @@ def gen():
     v_bfrev_b32 v23, v23
     v_lshrrev_b32 v23, 28, v23
     """)
+    # constants of tree_update_rec
+    emit("v_sub_u32 v19, 8, %[vlane]\nv_sub_u32 v18, 7, %[vlane]\nv_cmp_gt_u32 s[76:77], 8, %[vlane]")
     # v21, lane = raw length 0..7: byte address of posSlot[min(len, 3)]; v20, lane = state:
     # stateUpdateMatch (state.go:165-171)
     emit("""
