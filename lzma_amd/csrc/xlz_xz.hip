@@ -110,6 +110,7 @@ bool xz_dict_size(uint8_t b, uint32_t &d)
 
 struct Stream {
     size_t start = 0, end = 0; // [start, end) of the stream inside the file, padding excluded
+    size_t index_start = 0;    // blocks live in [start + 12, index_start)
     unsigned check = 0;
     std::vector<std::pair<uint64_t, uint64_t>> records; // (unpadded size, uncompressed size)
 };
@@ -125,7 +126,8 @@ int parse_stream_backwards(const uint8_t *f, size_t end, Stream &s)
     s.check = ft[9] & 0x0F;
     const uint64_t index_size = ((uint64_t)le32(ft + 4) + 1) * 4;
     if (index_size + 24 > end) return XLZ_ERR_RESULT;
-    const size_t ix = end - 12 - (size_t)index_size;
+    const size_t ix = end - 12 - (size_t)index_size; // where the index starts
+    s.index_start = ix;
     const uint8_t *ip = f + ix;
     if (crc32(ip, (size_t)index_size - 4) != le32(ip + index_size - 4)) return XLZ_ERR_RESULT;
     if (ip[0] != 0x00) return XLZ_ERR_RESULT;
@@ -138,9 +140,14 @@ int parse_stream_backwards(const uint8_t *f, size_t end, Stream &s)
     for (uint64_t r = 0; r < nrec; r++) {
         uint64_t unpadded, uncomp;
         if (!vli(ip, (size_t)index_size - 4, pos, unpadded) || !vli(ip, (size_t)index_size - 4, pos, uncomp)) return XLZ_ERR_RESULT;
-        if (unpadded < 5 || unpadded > (1ull << 62)) return XLZ_ERR_RESULT;
+        // every block lies between the 12-byte stream header and the index: a record that does not
+        // fit what is left there is rejected before it is added (no 64-bit wrap of the sum)
+        if (unpadded < 5 || ix < 12 || unpadded > (uint64_t)ix - 12 - blocks_total) return XLZ_ERR_RESULT;
+        const uint64_t padded = (unpadded + 3) & ~3ull;
+        if (padded > (uint64_t)ix - 12 - blocks_total) return XLZ_ERR_RESULT;
+        if (uncomp > (1ull << 62)) return XLZ_ERR_RESULT;
         s.records.emplace_back(unpadded, uncomp);
-        blocks_total += (unpadded + 3) & ~3ull;
+        blocks_total += padded;
     }
     while (pos < index_size - 4)
         if (ip[pos++] != 0) return XLZ_ERR_RESULT; // index padding
@@ -219,7 +226,9 @@ extern "C" int xlz_xz_index(const uint8_t *file, size_t len, xlz_xz_block *block
             size_t hdr;
             uint32_t dict = 0;
             uint64_t csz, usz;
-            const int st = parse_block_header(file + pos, s.end - pos, hdr, dict, csz, usz);
+            const uint64_t padded = (rec.first + 3) & ~3ull;
+            if (pos > s.index_start || padded > s.index_start - pos) return XLZ_ERR_RESULT; // block inside the stream
+            const int st = parse_block_header(file + pos, s.index_start - pos, hdr, dict, csz, usz);
             if (st != XLZ_OK) return st;
             const unsigned chk = check_size(s.check);
             if (rec.first < hdr + chk) return XLZ_ERR_RESULT;
@@ -237,8 +246,9 @@ extern "C" int xlz_xz_index(const uint8_t *file, size_t len, xlz_xz_block *block
                 b.check_off = pos + hdr + ((comp + 3) & ~3ull);
             }
             nb++;
+            if (rec.second > ~0ull - uoff) return XLZ_ERR_RESULT;
             uoff += rec.second;
-            pos += (size_t)((rec.first + 3) & ~3ull);
+            pos += (size_t)padded;
         }
     }
     *n_blocks = nb;

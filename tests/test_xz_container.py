@@ -75,6 +75,54 @@ def test_malformed_and_unsupported_files_are_refused():
     assert e.value.status == lzma_amd.ERR_UNSUPPORTED
 
 
+def _vli(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def test_index_whose_record_sizes_wrap_64_bits_is_refused():
+    """four records of 2^62 wrap the sum of the padded sizes to 0 mod 2^64, so a
+    crafted index can pass the header-position check and send the block walk out of bounds."""
+    import struct
+    import zlib
+    good = lzma.compress(corpus.plain("T", 9, 5000), format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC32)
+    blocks, _ = lzma_amd.xz_index(good)
+    assert len(blocks) == 1
+    # the real block's record, read back from the good file's index
+    isz = (struct.unpack("<I", good[-8:-4])[0] + 1) * 4
+    ix = len(good) - 12 - isz
+    unpadded = ix - 12  # one block, already 4-aligned by its padding or not: recompute from the index
+    # parse the real (unpadded, uncompressed) pair
+    pos = ix + 2
+    vals = []
+    for _ in range(2):
+        v, sh = 0, 0
+        while True:
+            b = good[pos]
+            pos += 1
+            v |= (b & 0x7F) << sh
+            sh += 7
+            if not b & 0x80:
+                break
+        vals.append(v)
+    for order in ("huge-first", "huge-last"):
+        recs = [(1 << 62, 1)] * 4
+        recs = recs + [tuple(vals)] if order == "huge-first" else [tuple(vals)] + recs
+        body = b"\x00" + _vli(len(recs)) + b"".join(_vli(a) + _vli(b) for a, b in recs)
+        body += b"\0" * (-len(body) % 4)
+        index = body + struct.pack("<I", zlib.crc32(body))
+        backward = struct.pack("<I", len(index) // 4 - 1)
+        flags = good[-4:-2]
+        footer = struct.pack("<I", zlib.crc32(backward + flags)) + backward + flags + b"YZ"
+        crafted = good[:ix] + index + footer
+        with pytest.raises(LzmaError):
+            lzma_amd.xz_index(crafted)
+
+
 @pytest.mark.gpu
 def test_whole_files_decode_as_one_batch(ctx):
     for f, p in (_three_streams(), _multi_block(), _multi_block(65536)):
