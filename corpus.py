@@ -17,6 +17,8 @@ from concurrent.futures import ProcessPoolExecutor
 import numpy as np
 
 _VOCAB = None
+_VOCAB_FLAT = None
+_PIECE = 1 << 20
 
 
 def _vocab():
@@ -28,14 +30,37 @@ def _vocab():
     return _VOCAB
 
 
+def _vocab_flat():
+    """(all words, each followed by a space, as one uint8 array; length of word+space; start)"""
+    global _VOCAB_FLAT
+    if _VOCAB_FLAT is None:
+        v = _vocab()
+        flat = np.frombuffer(b"".join(w + b" " for w in v), dtype=np.uint8)
+        lens = np.array([len(w) + 1 for w in v], dtype=np.int32)
+        starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+        _VOCAB_FLAT = (flat, lens, starts)
+    return _VOCAB_FLAT
+
+
 def plain_text(seed, n):
-    """Words drawn uniformly from a fixed 2000-word vocabulary, space separated."""
-    v = _vocab()
+    """Words drawn uniformly from a fixed 2000-word vocabulary, space separated
+    (b" ".join(words)[:n], built with numpy index arithmetic instead of a Python join).
+    Above 1 MiB the text is made of independent 1 MiB pieces (small working arrays stay in
+    cache and in the allocator's arenas: several times faster than one big pass)."""
+    if n > _PIECE:
+        return b"".join(plain_text([seed, k], min(_PIECE, n - k * _PIECE)) for k in range((n + _PIECE - 1) // _PIECE))
+    flat, lens, starts = _vocab_flat()
     rng = np.random.default_rng(seed)
-    idx = rng.integers(0, len(v), size=n // 4 + 16)
-    out = b" ".join([v[i] for i in idx])
-    assert len(out) >= n
-    return out[:n]
+    idx = rng.integers(0, len(lens), size=n // 4 + 16)
+    ln = lens[idx]
+    ends = np.cumsum(ln, dtype=np.int64)
+    k = min(int(np.searchsorted(ends, n + 1, side="left")) + 1, len(idx))
+    ln = ln[:k]
+    total = int(ends[k - 1])
+    assert total - 1 >= n
+    src = np.repeat((starts[idx[:k]] - (ends[:k] - ln)).astype(np.int32), ln)
+    src += np.arange(total, dtype=np.int32)
+    return flat[src][:n].tobytes()
 
 
 def plain_random(seed, n):
@@ -64,7 +89,22 @@ def plain_repeats(seed, n):
     return buf.tobytes()
 
 
-FAMILIES = {"T": plain_text, "R": plain_random, "M": plain_mixed, "Z": plain_repeats}
+def plain_far(seed, n, far_lo=6 << 20, far_hi=(8 << 20) - 1024, every=65536, blob=256):
+    """Text with long-range repeats: every `every` bytes a random `blob`-byte key, copied again
+    far_lo..far_hi bytes later -- matches whose distance approaches an 8 MiB dictionary (the
+    window-wrap variant of BASELINE config 5)."""
+    buf = np.frombuffer(plain_text(seed, n), dtype=np.uint8).copy()
+    rng = np.random.default_rng(seed ^ 0x5EED)
+    for q in range(0, n - blob, every):
+        key = rng.integers(0, 256, size=blob, dtype=np.uint8)
+        buf[q:q + blob] = key
+        d = int(rng.integers(far_lo, far_hi))
+        if q + d + blob <= n and (q + d) % every >= blob:  # do not land on another key
+            buf[q + d:q + d + blob] = key
+    return buf.tobytes()
+
+
+FAMILIES = {"T": plain_text, "R": plain_random, "M": plain_mixed, "Z": plain_repeats, "F": plain_far}
 
 
 def plain(family, seed, n):
@@ -75,8 +115,14 @@ def props_byte(lc, lp, pb):
     return (pb * 5 + lp) * 9 + lc
 
 
+def _enc(preset):
+    """preset: a liblzma preset number, or a dict of explicit encoder options (mode, mf, nice_len,
+    depth) for corpora that must be generated quickly."""
+    return dict(preset) if isinstance(preset, dict) else {"preset": preset}
+
+
 def lzma1_filters(dict_size=65536, lc=3, lp=0, pb=2, preset=6):
-    return [{"id": lzma.FILTER_LZMA1, "preset": preset, "dict_size": dict_size, "lc": lc, "lp": lp, "pb": pb}]
+    return [dict(id=lzma.FILTER_LZMA1, dict_size=dict_size, lc=lc, lp=lp, pb=pb, **_enc(preset))]
 
 
 def compress_alone(data, dict_size=65536, lc=3, lp=0, pb=2, preset=6, known_size=False):
@@ -96,7 +142,7 @@ def compress_raw_lzma1(data, dict_size=65536, lc=3, lp=0, pb=2, preset=6):
 
 
 def compress_raw_lzma2(data, dict_size=65536, lc=3, lp=0, pb=2, preset=6):
-    f = [{"id": lzma.FILTER_LZMA2, "preset": preset, "dict_size": dict_size, "lc": lc, "lp": lp, "pb": pb}]
+    f = [dict(id=lzma.FILTER_LZMA2, dict_size=dict_size, lc=lc, lp=lp, pb=pb, **_enc(preset))]
     return lzma.compress(data, format=lzma.FORMAT_RAW, filters=f)
 
 

@@ -1,0 +1,76 @@
+"""GPU: the BASELINE shapes that no oracle-sized test reaches: a 65 536-entry
+work queue, an output arena beyond 4 GiB (64-bit arena offsets), and one stream whose 8 MiB window
+wraps with distances up to the dictionary size (window.go:31-87, decompress.go:22,56,651-653)."""
+import hashlib
+
+import pytest
+
+import corpus
+import lzma_amd
+import oracle
+from lzma_amd import FMT_LZMA_ALONE, Stream
+
+pytestmark = pytest.mark.gpu
+
+
+def test_65536_streams_through_one_batch(ctx):
+    """cfg3's stream count (8 KiB each so that the corpus builds in seconds): SHA-256 of every
+    stream, per-stream results, and the batch's byte accounting."""
+    n, size = 65536, 8192
+    comp, digests = corpus.make_alone_batch("M", n, size, base_seed=90_000, preset={"mode": 1, "mf": 3, "nice_len": 32,
+                                                                                    "depth": 2})
+    b = lzma_amd.Batch(ctx, [Stream(c, FMT_LZMA_ALONE, out_cap=size) for c in comp])
+    b.run()
+    res = b.results()
+    assert len(res) == n and all(r[1] == 0 and r[0] == size for r in res)
+    assert all(r[2] == len(c) for r, c in zip(res, comp))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as ex:
+        got = list(ex.map(lambda i: hashlib.sha256(b.download(i, size)).digest(), range(n)))
+    assert got == digests
+    cin, cout, units = b.stats()
+    assert cout == n * size and units == n and cin == sum(len(c) - 13 for c in comp)
+    b.close()
+
+
+def test_output_arena_beyond_4_gib(ctx):
+    """4352 streams x 1 MiB: stream regions start past offset 2^32 in the output arena (and the
+    input arena offsets are 64-bit too); 64 distinct plaintexts, every region checked."""
+    nd, n, size = 64, 4352, 1 << 20
+    ps = [corpus.plain("TMZR"[i % 4], 91_000 + i, size) for i in range(nd)]
+    cs = [corpus.compress_alone(p, preset=0) for p in ps]
+    hs = [hashlib.sha256(p).digest() for p in ps]
+    b = lzma_amd.Batch(ctx, [Stream(cs[(i * 7) % nd], FMT_LZMA_ALONE, out_cap=size) for i in range(n)])
+    ptr0, _ = b.device_output(0)
+    ptr_last, _ = b.device_output(n - 1)
+    assert ptr_last - ptr0 > (1 << 32)
+    b.run()
+    res = b.results()
+    assert all(r[1] == 0 and r[0] == size for r in res)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as ex:
+        ok = list(ex.map(lambda i: hashlib.sha256(b.download(i, size)).digest() == hs[(i * 7) % nd], range(n)))
+    assert all(ok)
+    b.close()
+
+
+def test_one_stream_wraps_an_8_mib_window(ctx):
+    """20 MiB, props 0x38 (lc2 lp1 pb1, BASELINE config 5), 8 MiB dictionary, repeats 6-8 MiB back:
+    window.pos wraps twice and the copies reach almost a whole dictionary back; byte for byte and
+    on status / consumed input against the oracle.  A second stream with a dictionary size that is
+    not a multiple of 16 (the wrapped position feeds posState and the literal context)."""
+    p = corpus.plain("F", 92_000, 20 << 20)
+    c = corpus.compress_alone(p, dict_size=8 << 20, lc=2, lp=1, pb=1, preset=0)
+    assert c[0] == 0x38
+    p2 = corpus.plain_far(92_001, 3 << 20, far_lo=900_000, far_hi=1_000_000)
+    c2 = bytearray(corpus.compress_alone(p2, dict_size=1 << 20, lc=2, lp=1, pb=1, preset=0))
+    c2[1:5] = (1_048_583).to_bytes(4, "little")  # window.size not a multiple of 16 (and >= the encoder's 1 MiB)
+    got = lzma_amd.decode_batch(ctx, [Stream(c, FMT_LZMA_ALONE, out_cap=len(p)), Stream(bytes(c2), FMT_LZMA_ALONE,
+                                                                                         out_cap=len(p2))])
+    want = [oracle.lzma1_alone(c, len(p)), oracle.lzma1_alone(bytes(c2), len(p2))]
+    assert got[0][1] == want[0][1] == 0 and got[0][2] == want[0][2]
+    assert got[0][0] == want[0][0] == p
+    # window.size % 16 != 0: after the first wrap the reference's posState (wrapped window.pos,
+    # decompress.go:22) leaves the encoder's, the decode derails -- identically in the oracle
+    assert len(want[1][0]) > 1_048_583 and want[1][0][:1_048_583] == p2[:1_048_583]
+    assert got[1] == want[1]

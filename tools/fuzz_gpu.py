@@ -37,9 +37,11 @@ def fuzz(ctx, budget, seed, per_round=160, verbose=True):
       for _ in range(per_round):
           fam = "TRMZ"[int(rng.integers(0, 4))]
           n = int(rng.choice([1, 2, 17, 300, 335, 336, 337, 1000, 5000, 40000, 70000, 131072, 200000, 300001]))
+          if rng.random() < 0.02:
+              n = int(rng.choice([1 << 20, 3 << 20]))  # rare: streams far longer than the small dictionaries
           n = max(1, n + int(rng.integers(-3, 4)))
           lc = int(rng.integers(0, 5)); lp = int(rng.integers(0, 5 - lc)); pb = int(rng.integers(0, 5))
-          dict_size = int(rng.choice([4096, 4097, 5000, 8192, 65536, 65537, 100003, 1 << 20]))
+          dict_size = int(rng.choice([4096, 4097, 5000, 8192, 65536, 65537, 100003, 1 << 20, 8 << 20]))
           p = corpus.plain(fam, int(rng.integers(1, 1 << 30)), n)
           if rng.random() < 0.75:
               c = corpus.compress_alone(p, dict_size=dict_size, lc=lc, lp=lp, pb=pb, known_size=bool(rng.random() < 0.3))
@@ -54,7 +56,7 @@ def fuzz(ctx, budget, seed, per_round=160, verbose=True):
               nseg = int(rng.integers(1, 5))
               cut = sorted(set(int(x) for x in rng.integers(0, n + 1, nseg - 1)))
               parts = [p[a:b] for a, b in zip([0] + cut, cut + [n]) if b > a] or [p]
-              d2 = int(rng.choice([4096, 65536, 1 << 20]))
+              d2 = int(rng.choice([4096, 65536, 1 << 20, 8 << 20]))
               c = corpus.lzma2_concat(parts, dict_size=d2, lc=lc, lp=lp, pb=pb)
               if rng.random() < 0.4:
                   c = bytearray(c)

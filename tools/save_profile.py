@@ -1,7 +1,14 @@
-"""Copy the judged parts of a tools/profile_bench.sh run from gpurun_out/ into profiles/.
-usage: python tools/save_profile.py <tag> <dest-prefix>   e.g.  r01b profiles/r01/bench_default_v3"""
+"""Copy the judged parts of a tools/profile_bench.sh run from gpurun_out/ into profiles/ and
+register it in profiles/current.json (what bench.py reports as roofline.traffic / roofline.issue
+while the kernel sources are the ones the profile was taken on).
+usage: python tools/save_profile.py <tag> <dest-prefix> [config]   e.g.  r02a profiles/r02/cfg2-T_v9 cfg2-T"""
 import csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # kernel_rev()
+
 tag, dest = sys.argv[1], sys.argv[2]
+cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg2-T"
 src = "gpurun_out/prof_" + tag
 os.makedirs(os.path.dirname(dest), exist_ok=True)
 shutil.copy(src + "/summary.md", dest + "_summary.md")
@@ -24,16 +31,36 @@ w = csv.writer(open(dest + "_pmc.csv", "w"))
 w.writerow(["pass", "dispatch", "grid", "wg", "vgpr", "sgpr", "counter", "value"])
 w.writerows(rows)
 line = json.loads(open(src + "/kt.json").read().strip().splitlines()[-1])
-fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]) * 1024
-write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"]) * 1024
-traffic = {
-    "workload": line["config"]["workload"],
-    "fetch_bytes_per_launch_raw": fetch, "write_bytes_per_launch": write,
-    "traffic_bytes_per_launch": fetch + write,
+mean = lambda k: sum(vals[k]) / len(vals[k])
+fetch = mean("FETCH_SIZE") * 1024
+write = mean("WRITE_SIZE") * 1024
+kernel_ms = line["roofline"]["kernel_ms"]
+grid = int(rows[0][2]) // 64  # single-wave workgroups = wave slots of the launch
+CUS, CLK = 256, 2.4e9
+cu_cycles = kernel_ms / 1e3 * CLK * CUS
+entry = {
+    "workload": line["config"]["workload"], "kernel_rev": bench.kernel_rev(), "source": dest + "_pmc.csv",
+    "fetch_bytes_per_launch_raw": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KiB units x 1024), mean over the launches "
             "of xlz_decode_kernel; FETCH_SIZE taken raw: this kernel's reads are one-byte-per-lane gathers and 4-byte-per-"
             "lane window loads, not the 16-byte-per-lane streaming reads the gfx950 x2 correction is calibrated for",
-    "source": dest + "_pmc.csv",
+    "issue": {
+        "salu_per_cu_cycle": round(mean("SQ_INSTS_SALU") / cu_cycles, 4),
+        "valu_per_cu_cycle": round(mean("SQ_INSTS_VALU") / cu_cycles, 4),
+        "branch_per_cu_cycle": round(mean("SQ_INSTS_BRANCH") / cu_cycles, 4),
+        "lds_per_cu_cycle": round(mean("SQ_INSTS_LDS") / cu_cycles, 4),
+        "instructions_per_decoded_byte": round((mean("SQ_INSTS_SALU") + mean("SQ_INSTS_VALU") + mean("SQ_INSTS_BRANCH") +
+                                               mean("SQ_INSTS_LDS") + mean("SQ_INSTS_VMEM")) /
+                                              (line["config"]["streams_per_gpu"] * line["config"]["bytes_per_stream"]), 2),
+        # SQ_WAVE_CYCLES counts in quad-cycles per wave: x4 / (slots x kernel cycles) = average slot occupancy
+        "slot_occupancy": round(mean("SQ_WAVE_CYCLES") * 4 / (grid * kernel_ms / 1e3 * CLK), 4),
+        "budget": "one scalar-port instruction and one wave64 VALU instruction per CU cycle (tools/ubench/thr2.hip); "
+                  "clock %.1f GHz, %d CUs, kernel_ms %.3f" % (CLK / 1e9, CUS, kernel_ms),
+        "source": dest + "_pmc.csv",
+    },
 }
-json.dump(traffic, open(os.path.join(os.path.dirname(dest), "..", "traffic_default.json"), "w"), indent=1)
-print(json.dumps(traffic, indent=1))
+cur_path = os.path.join(ROOT, "profiles", "current.json")
+cur = json.load(open(cur_path)) if os.path.exists(cur_path) else {}
+cur[cfg] = entry
+json.dump(cur, open(cur_path, "w"), indent=1)
+print(json.dumps(entry, indent=1))
