@@ -41,8 +41,9 @@ enum {
                                     the 5 range-coder init bytes (reader1.go:78-98,153-156)     */
     XLZ_ERR_RC_INIT = -4,        /* first range-coder byte != 0 (range_decoder.go:32-34)         */
     XLZ_ERR_UNEXPECTED_EOF = -5, /* io.ErrUnexpectedEOF from LZMA2 framing (reader2.go:104-127)  */
-    XLZ_ERR_OUT_CAP = -6,        /* new: out_cap smaller than the decoded size; out_len==out_cap,
-                                    in_consumed unspecified (the reference has no output limit)  */
+    XLZ_ERR_OUT_CAP = -6,        /* new: out_cap smaller than the decoded size (the reference has no
+                                    output limit); out_len==out_cap, in_consumed = the input read
+                                    when the packet / stored chunk that did not fit was complete   */
     XLZ_ERR_BAD_ARG = -7,        /* new: NULL pointer / unknown format                           */
     XLZ_ERR_DEVICE = -8,         /* new: HIP runtime failure or no gfx950 device                 */
     XLZ_ERR_UNSUPPORTED = -9,    /* new: stream outside what the GPU path implements (DESIGN.md
@@ -104,9 +105,10 @@ int xlz_ctx_event_elapsed_ms(xlz_ctx *ctx, int slot_a, int slot_b, float *ms);
 
 /* Coalescing of pull-style readers.  The reference's readers are
  * independent single-goroutine objects; many goroutines each doing io.Copy(dst, NewReader1(src))
- * would each occupy one wave of the GPU.  After this call, every reader created on `ctx` hands
- * its stream to a background thread that waits up to `window_us` for more readers (at most
- * `max_streams`) and decodes them as ONE batch; xlz_reader_read blocks until its stream is done. */
+ * would each occupy one wave of the GPU with a launch of its own.  After this call, every refill
+ * of a reader of `ctx` is handed to a background thread that waits up to `window_us` for refills
+ * of other readers (at most `max_streams`) and runs them as ONE launch; xlz_reader_read blocks
+ * until its refill is done.                                                                      */
 int xlz_ctx_enable_batching(xlz_ctx *ctx, uint32_t window_us, uint32_t max_streams);
 int xlz_ctx_batching_stats(xlz_ctx *ctx, uint64_t *batches, uint64_t *streams);
 
@@ -131,13 +133,29 @@ int xlz_batch_device_output(xlz_batch *batch, size_t i, void **dptr, size_t *cap
 int xlz_batch_last_kernel_ms(xlz_batch *batch, float *ms);
 /* algorithmic bytes (compressed in + decoded out) the last run moved, and units  */
 int xlz_batch_stats(xlz_batch *batch, uint64_t *in_bytes, uint64_t *out_bytes, uint64_t *units);
+/* When each unit of the last run started and ended on its wave, in ticks of the device's 100 MHz
+ * clock since the first unit started, and its compressed size (the work-queue key).  Arrays of
+ * `cap` entries (any may be NULL); *n_units = units of the batch.  For slot-occupancy / tail
+ * analysis of the persistent grid (bench.py: roofline.issue.slot_occupancy).                */
+int xlz_batch_unit_trace(xlz_batch *batch, uint32_t *t_start, uint32_t *t_end, uint32_t *in_len,
+                         size_t cap, size_t *n_units);
 void xlz_batch_destroy(xlz_batch *batch);
 
 /* ---- pull-style readers mirroring the reference's Go surface --------------- */
-/* The GPU needs the whole compressed stream, so constructors take it as a buffer
- * (a Go shim slurps its io.Reader first).  Constructor-time errors are the ones
- * the reference's constructors return; decode errors surface from xlz_reader_read
- * once all bytes produced before the error have been delivered.                  */
+/* Constructors take the compressed stream as a buffer (a Go shim slurps its io.Reader
+ * first) and copy it.  Constructor-time errors are the ones the reference's
+ * constructors return; decode errors surface from xlz_reader_read once all bytes
+ * produced before the error have been delivered.
+ *
+ * A reader is a resumable decode on the device (reader1.go:223-254 / decompress.go:13:
+ * decompress(need) returns once `need` bytes are pending): every refill continues the
+ * saved decoder state for about 1 MiB of output and stops.  Memory is bounded like the
+ * reference's: one refill chunk on the host, 2 x dictSize + one chunk of window on the
+ * device (less for streams of known size), a 4 MiB input window on the device.  The
+ * stream is decoded exactly once, whatever its size or compression ratio.  Two rare
+ * fallbacks decode the whole stream in one batch and skip what has been delivered:
+ * models with lc+lp > 8 (HBM-resident model) and malformed LZMA2 streams whose copies
+ * read window bytes of an earlier dictionary epoch.                                    */
 typedef struct xlz_reader xlz_reader;
 xlz_reader *xlz_new_reader1(xlz_ctx *ctx, const uint8_t *in, size_t in_len, int *err); /* NewReader1 */
 xlz_reader *xlz_new_reader2(xlz_ctx *ctx, const uint8_t *in, size_t in_len, int dict_size,
@@ -161,6 +179,10 @@ long xlz_reader_read(xlz_reader *r, uint8_t *p, size_t n, int *err);
 int xlz_reader_close(xlz_reader *r); /* readCloser.Close (readcloser.go:16-28); second call ->
                                         XLZ_ERR_CLOSED; the handle stays valid until _free       */
 void xlz_reader_free(xlz_reader *r);
+/* launches that refilled this reader, whole-stream fallback decodes (0 unless one of the two
+ * cases above), compressed bytes uploaded so far -- for tests of the one-pass property     */
+int xlz_reader_stats(const xlz_reader *r, uint64_t *refills, uint64_t *whole_decodes,
+                     uint64_t *in_uploaded);
 
 /* Multi-GPU form of xlz_decode_batch: one context per GPU; the batch is
  * split by stream (balanced by out_cap), every context decodes its shard on its own host

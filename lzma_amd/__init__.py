@@ -201,6 +201,20 @@ class Batch:
             raise LzmaError(st, "xlz_batch_stats")
         return a.value, b.value, c.value
 
+    def unit_trace(self):
+        """(t_start, t_end, in_len) numpy uint32 arrays, one entry per unit of the last run: ticks of
+        the device's 100 MHz clock since the first unit started (xlz_batch_unit_trace)."""
+        import numpy as np
+        n = ctypes.c_size_t()
+        st = N.lib().xlz_batch_unit_trace(self._h, None, None, None, 0, ctypes.byref(n))
+        if st != OK:
+            raise LzmaError(st, "xlz_batch_unit_trace")
+        a, b, c = (np.zeros(max(n.value, 1), dtype=np.uint32) for _ in range(3))
+        st = N.lib().xlz_batch_unit_trace(self._h, a.ctypes.data, b.ctypes.data, c.ctypes.data, n.value, ctypes.byref(n))
+        if st != OK:
+            raise LzmaError(st, "xlz_batch_unit_trace")
+        return a[: n.value], b[: n.value], c[: n.value]
+
     def download(self, i, length):
         buf = ctypes.create_string_buffer(max(int(length), 1))
         st = N.lib().xlz_batch_download(self._h, i, ctypes.cast(buf, ctypes.c_void_p), int(length))
@@ -284,6 +298,12 @@ class _Reader:
                 return b"".join(out), None
             if e is not None:
                 return b"".join(out), e
+
+    def stats(self):
+        """(refill launches, whole-stream fallback decodes, compressed bytes uploaded) -- xlz_reader_stats"""
+        a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        N.lib().xlz_reader_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return a.value, b.value, c.value
 
     def Close(self):
         """readCloser.Close (readcloser.go:16-28)."""

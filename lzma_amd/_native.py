@@ -42,7 +42,7 @@ EXPORTS = [
     "xlz_batch_stats", "xlz_batch_destroy", "xlz_new_reader1", "xlz_new_reader2",
     "xlz_new_lzma_decompressor_for_sevenzip", "xlz_new_lzma2_decompressor_for_sevenzip",
     "xlz_reader_read", "xlz_reader_close", "xlz_reader_free", "xlz_xz_index", "xlz_xz_decode",
-    "xlz_decode_batch_multi",
+    "xlz_decode_batch_multi", "xlz_batch_unit_trace", "xlz_reader_stats",
 ]
 
 
@@ -138,6 +138,8 @@ def lib():
     L.xlz_reader_close.argtypes = [vp]
     L.xlz_reader_free.argtypes = [vp]
     L.xlz_reader_free.restype = None
+    L.xlz_reader_stats.argtypes = [vp] + [ctypes.POINTER(ctypes.c_uint64)] * 3
+    L.xlz_batch_unit_trace.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]
     L.xlz_decode_batch_multi.argtypes = [ctypes.POINTER(vp), sz, ctypes.POINTER(StreamDesc), sz, ctypes.POINTER(Result)]
     L.xlz_xz_index.argtypes = [vp, sz, ctypes.POINTER(XzBlock), sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint64)]
     L.xlz_xz_decode.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(ctypes.c_uint64), i32, ctypes.POINTER(sz)]

@@ -54,38 +54,55 @@ enum : uint32_t {
 
 enum : uint32_t {
     UNIT_F_LAST = 1,        // the parent stream's input ends with this unit
-    UNIT_F_HAVE_READER = 2, // not the stream's first unit: Reader2.lzmaReader already exists
-    UNIT_F_BIG_MODEL = 4    // model does not fit LDS: decoded by the HBM-model launch
+    UNIT_F_HAVE_READER = 2, // an LZMA chunk precedes this unit in its stream: Reader2.lzmaReader exists
+    UNIT_F_BIG_MODEL = 4,   // model does not fit LDS: decoded by the HBM-model launch
+    UNIT_F_RESUME = 8,      // continue from the UnitState saved by an earlier launch (pull readers)
+    UNIT_F_MORE_INPUT = 16, // in_len is a window of a longer input: pause (not EOF) when it runs low
+    UNIT_F_NOT_FIRST = 32   // LZMA2: earlier units of the stream precede this one (their bytes may be read as
+                            // stale window content, window.go:135-140)
 };
 
 struct Unit {
     uint64_t in_off;      // byte offset of the payload in the input arena
     uint64_t out_off;     // byte offset of this unit's output in the output arena
     uint64_t unpack_size; // LZMA1: header size, all-ones = undefined (state.go:135-151)
+    uint64_t state;       // resumable units: device address of the unit's UnitState, else 0
     uint32_t in_len;      // payload bytes available to this unit
     uint32_t out_cap;     // bytes this unit may write
     uint32_t dict_size;   // window size (already clamped the way the reference clamps it)
     uint32_t stream;      // index of the parent stream
-    uint8_t lc, lp, pb, kind;
+    uint8_t lc, lp, pb, kind; // LZMA2: lc = the largest lc+lp the host's header scan saw, lp = pb = 0
     uint32_t flags;
     uint32_t expect_out;  // LZMA2: output the host scan predicts for this unit
-    uint32_t pad0;
-    uint64_t pad1;
+    uint32_t pause_at;    // resumable units: stop at the first packet / chunk boundary with pos >= pause_at
+    uint32_t rebase;      // UNIT_F_RESUME: the host moved the window down by this many bytes (pos, wbase follow)
+    uint32_t in_skip;     // UNIT_F_RESUME: input bytes consumed before in_off (the input window moved)
+    uint32_t pad[1];
 };
-static_assert(sizeof(Unit) == 64, "Unit must stay 64 bytes");
+static_assert(sizeof(Unit) == 80, "Unit layout is shared with the host");
 
 struct UnitResult {
-    uint32_t out_len;
-    uint32_t in_consumed;
+    uint64_t out_len;     // bytes in the unit's output range after this launch (pos)
+    uint64_t in_consumed; // input bytes pulled from the unit's source so far
     int32_t status;
-    uint32_t aux; // bit0: LZMA2 unit ended on an end-of-stream control byte; bit1: a copy reached
-                  // in front of the current dictionary epoch (stale window bytes read as 0)
+    uint32_t aux;         // AUX_* bits
+    uint32_t t_start, t_end; // 100 MHz device clock (s_memrealtime), low 32 bits: slot occupancy, tail
+};
+static_assert(sizeof(UnitResult) == 32, "UnitResult layout is shared with the host");
+
+enum : uint32_t {
+    AUX_END_MARK = 1,  // LZMA2 unit ended on an end-of-stream control byte
+    AUX_STALE = 2,     // a copy reached in front of the current dictionary epoch and the launch had no
+                       // epoch table: the bytes read there are NOT exact, the host decodes the stream
+                       // again with one (window.go:135-140 does not clear the buffer)
+    AUX_NEED_INPUT = 4 // paused because the input window ran low (UNIT_F_MORE_INPUT)
 };
 
 // device-side status values = include/xlz.h
 enum : int32_t {
     ST_OK = 0,
     ST_OK_INPUT_EOF = 1,
+    ST_PAUSED = 2, // resumable unit stopped at pause_at / for more input; state saved
     ST_ERR_RESULT = -1,
     ST_ERR_PROPS = -2,
     ST_ERR_HEADER_EOF = -3,
@@ -95,13 +112,27 @@ enum : int32_t {
     ST_ERR_UNSUPPORTED = -9
 };
 
+// Saved decoder state of a resumable unit (HBM): 64 words of registers, then the LDS model, then the
+// matched-literal half of the model (which lives here for the unit's whole life, not in a
+// workgroup slot).
+constexpr uint32_t kStateWords = 64;
+static inline constexpr uint32_t state_probs_off() { return kStateWords * 4; }
+static inline constexpr uint32_t state_mprobs_off(uint32_t lc_lp) { return state_probs_off() + ((num_probs(lc_lp) * 2 + 15) & ~15u); }
+static inline constexpr uint32_t state_bytes(uint32_t lc_lp) { return state_mprobs_off(lc_lp) + num_matched_probs(lc_lp) * 2; }
+
+// one dictionary epoch of an LZMA2 unit that a later epoch may still read (exact launches only)
+struct Epoch {
+    uint32_t start, len; // output offset of the epoch's first byte, bytes it wrote
+};
+constexpr uint32_t kMaxEpochs = 8192; // strictly decreasing lengths: needs > 32 MiB of output to overflow
+
 struct LaunchParams {
     const uint8_t *in_arena;
     uint8_t *out_arena;
     const Unit *units;
     const uint32_t *order; // work-queue order (heaviest first)
     UnitResult *results;
-    uint32_t *queue;       // one zeroed word per launch
+    uint32_t *queue;       // 64 words of queue (word 0 = head), then 256 bytes of dump space for predicated stores
     uint32_t n_units;
     uint32_t max_lc_lp;    // sizes the model: dynamic LDS, or one scratch slot per workgroup
     // "big model" launch (lc+lp too large for 160 KiB of LDS; the reference allows lc<=8, lp<=4):
@@ -114,6 +145,9 @@ struct LaunchParams {
     // the HBM-model launch keeps them behind the model inside its scratch slot)
     uint16_t *mlit;
     uint32_t mlit_stride;
+    // exact launches (streams that read across an LZMA2 dictionary reset): kMaxEpochs entries per
+    // workgroup; nullptr in ordinary launches, which only flag AUX_STALE
+    Epoch *epochs;
 };
 
 // implemented in xlz_kernel.hip

@@ -119,6 +119,7 @@ struct xlz_batch {
     uint64_t algo_in = 0; // compressed payload bytes handed to the device
     // per-stream results of the latest run (filled lazily by collect())
     std::vector<xlz_result> final_results;
+    std::vector<UnitResult> unit_results; // of the main launch (timestamps: xlz_batch_unit_trace)
     bool collected = false;
     uint64_t sum_in = 0, sum_out = 0;
 };
@@ -192,14 +193,10 @@ extern "C" uint64_t xlz_decode_unpack_size(const uint8_t h[8])
 // ---------------------------------------------------------------- context ----
 namespace {
 
-// host threads for a staging job of `bytes` bytes: one per 32 MiB, at most 8 (or XLZ_HOST_THREADS)
+// host threads for a staging job of `bytes` bytes: one per 32 MiB, at most 8
 unsigned host_threads(size_t bytes)
 {
     unsigned cap = 8;
-    if (const char *e = getenv("XLZ_HOST_THREADS")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= 64) cap = (unsigned)v;
-    }
     const unsigned hw = std::thread::hardware_concurrency();
     if (hw && hw < cap) cap = hw;
     const unsigned want = (unsigned)(bytes / (32u << 20)) + 1;
@@ -235,7 +232,7 @@ extern "C" int xlz_ctx_create(int device, xlz_ctx **out)
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&c->queue, 256) != hipSuccess) {
+        hipMalloc(&c->queue, 512) != hipSuccess) {
         delete c;
         return XLZ_ERR_DEVICE;
     }
@@ -346,6 +343,7 @@ void plan_lzma_raw(const xlz_stream_desc &s, StreamPlan &pl, Unit &u, bool &has_
 struct Lz2Unit {
     uint32_t in_start, in_len;
     uint64_t out_start, expect_out;
+    bool have_reader; // an LZMA chunk precedes the unit: Reader2.lzmaReader exists (reader2.go:146-153)
 };
 
 void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint32_t &max_lc_lp)
@@ -355,10 +353,12 @@ void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint
     size_t cand_pos = 0; // pending split: a stored chunk reset the dictionary here
     uint64_t cand_out = 0;
     bool cand = false;
-    auto cut = [&](size_t at, uint64_t at_out) {
-        units.push_back({(uint32_t)unit_start, (uint32_t)(at - unit_start), unit_out, at_out - unit_out});
+    bool seen_lzma = false, cand_seen_lzma = false, unit_seen_lzma = false; // an LZMA chunk before: here / the candidate / the unit
+    auto cut = [&](size_t at, uint64_t at_out, bool lzma_before) {
+        units.push_back({(uint32_t)unit_start, (uint32_t)(at - unit_start), unit_out, at_out - unit_out, unit_seen_lzma});
         unit_start = at;
         unit_out = at_out;
+        unit_seen_lzma = lzma_before;
     };
     while (pos < len) {
         const uint8_t c = in[pos];
@@ -377,6 +377,7 @@ void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint
                 cand = true;
                 cand_pos = pos;
                 cand_out = out;
+                cand_seen_lzma = seen_lzma;
             }
             const size_t body = std::min<size_t>(unc, len - pos - hl);
             pos += hl + body;
@@ -389,14 +390,15 @@ void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint
             const uint8_t props = in[pos + 5];
             if (props >= 225) break; // the walker reports ErrIncorrectProperties here
             max_lc_lp = std::max<uint32_t>(max_lc_lp, (props % 9) + (props / 9) % 5);
-            if (sub == 7 && pos != 0 && pos != unit_start) cut(pos, out);
-            else if (cand && cand_pos != unit_start) cut(cand_pos, cand_out);
+            if (sub == 7 && pos != 0 && pos != unit_start) cut(pos, out, seen_lzma);
+            else if (cand && cand_pos != unit_start) cut(cand_pos, cand_out, cand_seen_lzma);
         }
+        seen_lzma = true;
         cand = false; // a compressed chunk without new props keeps the model: no cut
         pos += hl + std::min(comp, len - pos - hl);
         out += unc;
     }
-    units.push_back({(uint32_t)unit_start, (uint32_t)(len - unit_start), unit_out, out - unit_out});
+    units.push_back({(uint32_t)unit_start, (uint32_t)(len - unit_start), unit_out, out - unit_out, unit_seen_lzma});
 }
 
 int batch_free(xlz_batch *b)
@@ -487,7 +489,9 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
                 v.out_cap = (uint32_t)(last ? room : std::min<uint64_t>(room, lu[k].expect_out));
                 v.expect_out = (uint32_t)lu[k].expect_out;
                 v.stream = (uint32_t)i;
-                v.flags = (last ? UNIT_F_LAST : 0u) | (k ? UNIT_F_HAVE_READER : 0u) | (big ? UNIT_F_BIG_MODEL : 0u);
+                v.flags = (last ? UNIT_F_LAST : 0u) | (lu[k].have_reader ? UNIT_F_HAVE_READER : 0u) |
+                          (k ? UNIT_F_NOT_FIRST : 0u) | (big ? UNIT_F_BIG_MODEL : 0u);
+                v.lc = (uint8_t)mx; // sizes the model storage; the real lc/lp/pb come from the chunk headers
                 b->units.push_back(v);
                 unit_src_off.push_back(lu[k].in_start);
             }
@@ -626,6 +630,7 @@ extern "C" int xlz_batch_run(xlz_batch *b)
     p.order = b->d_order;
     p.results = b->d_results;
     p.queue = ctx->queue;
+    p.epochs = nullptr; // ordinary launch: copies that reach across a dictionary reset are only flagged
     if (b->n_normal) { // models in LDS
         p.n_units = b->n_normal;
         p.max_lc_lp = b->max_lc_lp;
@@ -672,7 +677,9 @@ extern "C" int xlz_batch_last_kernel_ms(xlz_batch *b, float *ms)
 
 namespace {
 
-// Launch `units` (already laid out against the batch's arenas) and fetch their results.
+// Launch `units` (already laid out against the batch's arenas) and fetch their results.  These are
+// always EXACT launches: every workgroup gets an epoch table, so copies that reach across an LZMA2
+// dictionary reset read the bytes the reference's uncleared window holds (window.go:135-140).
 int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResult> &res, bool big)
 {
     xlz_ctx *ctx = b->ctx;
@@ -682,11 +689,15 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
     Unit *d_units = nullptr;
     uint32_t *d_order = nullptr;
     UnitResult *d_res = nullptr;
+    Epoch *d_epochs = nullptr;
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
+    const uint32_t grid = std::min<uint32_t>((uint32_t)n, big ? big_model_grid(ctx->num_cus)
+                                                              : decode_grid(b->max_lc_lp, ctx->num_cus));
     int st = XLZ_ERR_DEVICE;
     if (hipMalloc(&d_units, n * sizeof(Unit)) == hipSuccess && hipMalloc(&d_order, n * sizeof(uint32_t)) == hipSuccess &&
         hipMalloc(&d_res, n * sizeof(UnitResult)) == hipSuccess &&
+        hipMalloc(&d_epochs, (size_t)grid * kMaxEpochs * sizeof(Epoch)) == hipSuccess &&
         hipMemcpy(d_units, units.data(), n * sizeof(Unit), hipMemcpyHostToDevice) == hipSuccess &&
         hipMemcpy(d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess &&
         hipMemsetAsync(ctx->queue, 0, 256, ctx->stream) == hipSuccess) {
@@ -704,6 +715,7 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
         p.mlit = big ? nullptr : b->d_mlit;
         p.mlit_stride = big ? 0 : b->mlit_stride;
         p.order_base = 0;
+        p.epochs = d_epochs;
         if (launch_decode(p, ctx->num_cus, ctx->stream) == 0 && hipStreamSynchronize(ctx->stream) == hipSuccess &&
             hipMemcpy(res.data(), d_res, n * sizeof(UnitResult), hipMemcpyDeviceToHost) == hipSuccess)
             st = XLZ_OK;
@@ -711,6 +723,7 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
     if (d_units) (void)hipFree(d_units);
     if (d_order) (void)hipFree(d_order);
     if (d_res) (void)hipFree(d_res);
+    if (d_epochs) (void)hipFree(d_epochs);
     return st;
 }
 
@@ -724,7 +737,8 @@ int collect(xlz_batch *b)
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    std::vector<UnitResult> ur(b->units.size());
+    std::vector<UnitResult> &ur = b->unit_results;
+    ur.resize(b->units.size());
     if (!ur.empty())
         HIP_TRY(hipMemcpy(ur.data(), b->d_results, ur.size() * sizeof(UnitResult), hipMemcpyDeviceToHost));
     b->final_results.assign(b->n, xlz_result{});
@@ -746,6 +760,14 @@ int collect(xlz_batch *b)
         }
         uint64_t out = 0, in_base = 0;
         bool settled = false;
+        // a unit read window bytes of an earlier dictionary epoch (AUX_STALE): the ordinary launch
+        // returns zeros there, the reference returns what its uncleared buffer holds -- decode the
+        // stream again as one unit of an exact launch
+        for (uint32_t k = 0; k < pl.n_units && !settled; k++)
+            if (ur[pl.first_unit + k].aux & AUX_STALE) {
+                redo.push_back(i);
+                settled = true;
+            }
         for (uint32_t k = 0; k < pl.n_units && !settled; k++) {
             const Unit &un = b->units[pl.first_unit + k];
             const UnitResult &u = ur[pl.first_unit + k];
@@ -755,7 +777,7 @@ int collect(xlz_batch *b)
                 r.out_len = out + u.out_len;
                 r.in_consumed = in_base + u.in_consumed;
                 settled = true;
-            } else if (u.status == ST_OK && !(u.aux & 1u) && u.out_len == un.expect_out && u.in_consumed == un.in_len) {
+            } else if (u.status == ST_OK && !(u.aux & AUX_END_MARK) && u.out_len == un.expect_out && u.in_consumed == un.in_len) {
                 out += u.out_len;
                 in_base += u.in_consumed;
             } else if (u.status < 0 && u.status != ST_ERR_OUT_CAP) {
@@ -789,6 +811,7 @@ int collect(xlz_batch *b)
             u.dict_size = pl.dict_size;
             u.unpack_size = kUnknownSize;
             u.stream = (uint32_t)i;
+            u.lc = b->units[pl.first_unit].lc;
             u.flags = UNIT_F_LAST | (big ? UNIT_F_BIG_MODEL : 0u);
             units.push_back(u);
         }
@@ -833,6 +856,28 @@ extern "C" int xlz_batch_stats(xlz_batch *b, uint64_t *in_bytes, uint64_t *out_b
     if (in_bytes) *in_bytes = b->sum_in;
     if (out_bytes) *out_bytes = b->sum_out;
     if (units) *units = b->units.size();
+    return XLZ_OK;
+}
+
+extern "C" int xlz_batch_unit_trace(xlz_batch *b, uint32_t *t_start, uint32_t *t_end, uint32_t *in_len, size_t cap,
+                                    size_t *n_units)
+{
+    if (!b || !b->ran || !n_units) return XLZ_ERR_BAD_ARG;
+    int st = collect(b);
+    if (st != XLZ_OK) return st;
+    *n_units = b->unit_results.size();
+    uint32_t t0 = 0;
+    bool first = true;
+    for (const UnitResult &u : b->unit_results) // the launch's first start is the origin
+        if (first || (int32_t)(u.t_start - t0) < 0) {
+            t0 = u.t_start;
+            first = false;
+        }
+    for (size_t k = 0; k < b->unit_results.size() && k < cap; k++) {
+        if (t_start) t_start[k] = b->unit_results[k].t_start - t0;
+        if (t_end) t_end[k] = b->unit_results[k].t_end - t0;
+        if (in_len) in_len[k] = b->units[k].in_len;
+    }
     return XLZ_OK;
 }
 
@@ -1046,23 +1091,50 @@ extern "C" int xlz_decode_batch_multi(xlz_ctx *const *ctxs, size_t n_ctx, const 
 }
 
 // ---------------------------------------------------------------- readers ----
-// Pull-style mirror of Reader1 / Reader2 / readCloser (reader1.go:223-254,
-// reader2.go:216-250, readcloser.go:9-41) on top of the batch engine.
+// Pull-style mirror of Reader1 / Reader2 / readCloser (reader1.go:223-254, reader2.go:216-250,
+// readcloser.go:9-41).
+//
+// A reader is a SESSION on the device: the unit's decoder state (range coder, reps, window
+// position, the whole probability model) is saved in HBM when the wave has produced the next
+// `kChunk` bytes and restored by the next launch (UnitState, xlz_format.h) -- the counterpart of
+// the reference's decompress(need) returning once window.pending >= need (decompress.go:13).
+// Memory is bounded like the reference's (O(dictSize), window.go:18-29): the device keeps the last
+// dictSize bytes of output in front of the bytes being produced and slides them down when the
+// buffer is full; the host holds one chunk.  Nothing is ever decoded twice and the input is read
+// in one pass (it is fed to the device through a bounded window too).
+struct Session {
+    uint8_t *d_ctl = nullptr;   // Unit | order | UnitResult | UnitState | input window
+    uint8_t *d_win = nullptr;   // output window: [history | bytes of this refill | slack]
+    size_t win_cap = 0, win_max = 0;
+    size_t off_state = 0, off_in = 0, in_buf = 0;
+    Unit unit;
+    uint32_t model_lc_lp = 0;
+    uint32_t pos = 0;           // bytes in d_win after the last launch
+    uint32_t rebase = 0;        // the window was moved down by this much since the last launch
+    uint64_t in_skip = 0;       // input bytes in front of the device's input window
+    uint64_t in_loaded = 0;     // input bytes uploaded so far (absolute end of the window)
+    uint64_t consumed = 0;      // input bytes the decoder has read
+    bool started = false;
+    size_t payload_off = 0;     // where the unit's input starts inside reader.in (header stripped)
+};
+
 struct xlz_reader {
     xlz_ctx *ctx = nullptr;
     xlz_stream_desc desc;
     std::vector<uint8_t> in;
-    std::vector<uint8_t> out;
+    std::vector<uint8_t> chunk;  // decoded bytes not yet handed to Read
     size_t rd = 0;
-    bool decoded = false;
+    bool finished = false;       // the stream's end (or error) has been reached; status is final
     bool closed = false;
-    bool is_closer = false; // built by a *ForSevenZip constructor: wraps errors like readCloser
+    bool is_closer = false;      // built by a *ForSevenZip constructor: wraps errors like readCloser
     int32_t status = XLZ_OK;
-    // batching: the stream is queued at construction and decoded by the context's batcher thread
-    bool queued = false;
-    int call_status = XLZ_OK;
-    uint64_t cap = 0;
-    bool cap_known = false;
+    int call_status = XLZ_OK;    // a device failure (not a stream status)
+    uint64_t delivered = 0;      // decoded bytes handed to the chunk buffer so far
+    Session *ss = nullptr;
+    bool whole = false;          // fallback: decode the whole stream in one exact batch (see reader_whole)
+    // batching: refills of concurrent readers are decoded by the context's batcher thread in one launch
+    bool refill_pending = false;
+    uint64_t n_refills = 0, n_whole = 0;
 };
 
 // Background coalescer of readers (one per context).
@@ -1078,6 +1150,11 @@ struct Batcher {
 };
 
 namespace {
+
+constexpr size_t kChunk = 1u << 20;       // bytes a refill aims for (decompress(need), need = 1 MiB)
+constexpr size_t kWinSlack = 65536 + 1024; // a refill overshoots by < one stored chunk / one match + a 64-lane row
+constexpr size_t kInBuf = 4u << 20;       // device-side input window of a session
+constexpr size_t kCtlHead = 256;          // Unit (80) | order (4) | UnitResult (32)
 
 xlz_reader *reader_new(xlz_ctx *ctx, const uint8_t *in, size_t in_len)
 {
@@ -1098,43 +1175,272 @@ int check_rc_init(const uint8_t *p, size_t n)
     return XLZ_OK;
 }
 
-void reader_initial_cap(xlz_reader *r)
+void session_free(Session *ss)
 {
-    // Output size: the header's, or a guess that is grown until it fits.
-    r->cap_known = false;
+    if (!ss) return;
+    if (ss->d_ctl) (void)hipFree(ss->d_ctl);
+    if (ss->d_win) (void)hipFree(ss->d_win);
+    delete ss;
+}
+
+// Device side of a reader.  XLZ_OK, XLZ_ERR_DEVICE, or XLZ_ERR_UNSUPPORTED (model too large for
+// LDS: the whole-stream path decodes those).
+int session_open(xlz_reader *r)
+{
+    Session *ss = new (std::nothrow) Session;
+    if (!ss) return XLZ_ERR_DEVICE;
+    Unit &u = ss->unit;
+    memset(&u, 0, sizeof u);
+    uint64_t known = kUnknownSize;
+    if (r->desc.format == XLZ_FMT_LZMA2_RAW) {
+        std::vector<Lz2Unit> lu;
+        uint32_t mx = 0;
+        scan_lzma2(r->in.data(), r->in.size(), lu, mx);
+        u.kind = UNIT_LZMA2;
+        u.dict_size = r->desc.dict_size < kLzmaDicMin ? 8u * 1024 * 1024 : r->desc.dict_size; // reader2.go:88-91
+        u.unpack_size = kUnknownSize;
+        u.lc = (uint8_t)mx;
+        ss->model_lc_lp = mx;
+    } else {
+        xlz_stream_desc d = r->desc;
+        d.in = r->in.data();
+        d.in_len = r->in.size();
+        StreamPlan pl;
+        bool has = false;
+        if (r->desc.format == XLZ_FMT_LZMA_ALONE)
+            plan_lzma_alone(d, pl, u, has);
+        else
+            plan_lzma_raw(d, pl, u, has);
+        if (!has) { // the constructors have already refused these
+            delete ss;
+            return XLZ_ERR_BAD_ARG;
+        }
+        ss->payload_off = pl.header_len;
+        ss->model_lc_lp = (uint32_t)u.lc + u.lp;
+        known = u.unpack_size;
+    }
+    if (ss->model_lc_lp > kMaxLcLpLds) {
+        delete ss;
+        return XLZ_ERR_UNSUPPORTED;
+    }
+    u.flags = UNIT_F_LAST;
+    // output window: twice the dictionary (history + room to slide without overlap) + one refill;
+    // a stream of known size never needs more than its size; start small, grow on demand
+    ss->win_max = 2 * (size_t)u.dict_size + kChunk + kWinSlack;
+    if (known != kUnknownSize && known + kWinSlack < ss->win_max) ss->win_max = (size_t)known + kWinSlack;
+    ss->win_cap = std::min<size_t>(ss->win_max, 2 * kChunk + kWinSlack);
+    ss->in_buf = std::min<size_t>(kInBuf, align_up(r->in.size() - ss->payload_off + 16, 256) + kArenaTailPad);
+    ss->off_state = kCtlHead;
+    ss->off_in = align_up(ss->off_state + state_bytes(ss->model_lc_lp), 256);
+    if (hipMalloc(&ss->d_ctl, ss->off_in + ss->in_buf) != hipSuccess || hipMalloc(&ss->d_win, ss->win_cap) != hipSuccess) {
+        session_free(ss);
+        return XLZ_ERR_DEVICE;
+    }
+    const uint32_t zero = 0;
+    if (hipMemcpy(ss->d_ctl + 128, &zero, 4, hipMemcpyHostToDevice) != hipSuccess) { // order[0] = 0
+        session_free(ss);
+        return XLZ_ERR_DEVICE;
+    }
+    r->ss = ss;
+    return XLZ_OK;
+}
+
+// Make room for the next refill (slide the history down, or grow the buffer), move the input window
+// and fill in the unit.  Called with ctx->mu held, device set.
+int session_prepare(xlz_reader *r, hipStream_t stream)
+{
+    Session *ss = r->ss;
+    Unit &u = ss->unit;
+    // ---- output window
+    if ((size_t)ss->pos + kChunk + kWinSlack > ss->win_cap) {
+        const size_t keep = std::min<size_t>(ss->pos, u.dict_size);
+        if (ss->win_cap < ss->win_max) { // grow (the history may still be shorter than the dictionary)
+            size_t want = std::min(ss->win_max, std::max(ss->win_cap * 2, (size_t)ss->pos + kChunk + kWinSlack));
+            uint8_t *nw = nullptr;
+            if (hipMalloc(&nw, want) != hipSuccess) return XLZ_ERR_DEVICE;
+            if (hipMemcpyAsync(nw, ss->d_win, ss->pos, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+                hipStreamSynchronize(stream) != hipSuccess) {
+                (void)hipFree(nw);
+                return XLZ_ERR_DEVICE;
+            }
+            (void)hipFree(ss->d_win);
+            ss->d_win = nw;
+            ss->win_cap = want;
+        }
+        if ((size_t)ss->pos + kChunk + kWinSlack > ss->win_cap) {
+            // full size reached: only the last dictSize bytes can still be referenced (window.go:18-29);
+            // win_max = 2 * dictSize + ... guarantees source and destination do not overlap
+            if ((size_t)ss->pos - keep < keep) return XLZ_ERR_DEVICE; // cannot happen (see win_max)
+            if (hipMemcpyAsync(ss->d_win, ss->d_win + (ss->pos - keep), keep, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                return XLZ_ERR_DEVICE;
+            ss->rebase += (uint32_t)(ss->pos - keep);
+            ss->pos = (uint32_t)keep;
+        }
+    }
+    // ---- input window: [in_skip, in_loaded) of the payload is on the device
+    const uint64_t total = r->in.size() - ss->payload_off;
+    const uint64_t margin = u.kind == UNIT_LZMA2 ? 70000 : 4096;
+    if (!ss->started || (ss->in_loaded < total && ss->in_loaded - ss->consumed < margin)) {
+        ss->in_skip = ss->consumed & ~(uint64_t)255;
+        const uint64_t end = std::min<uint64_t>(total, ss->in_skip + ss->in_buf - kArenaTailPad);
+        if (hipMemcpyAsync(ss->d_ctl + ss->off_in, r->in.data() + ss->payload_off + ss->in_skip, (size_t)(end - ss->in_skip),
+                           hipMemcpyHostToDevice, stream) != hipSuccess ||
+            hipMemsetAsync(ss->d_ctl + ss->off_in + (end - ss->in_skip), 0, kArenaTailPad, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) // r->in is pageable: the copy has been staged when this returns
+            return XLZ_ERR_DEVICE;
+        ss->in_loaded = end;
+    }
+    u.in_off = (uint64_t)(ss->d_ctl + ss->off_in);
+    u.in_len = (uint32_t)(ss->in_loaded - ss->in_skip);
+    u.in_skip = (uint32_t)ss->in_skip;
+    u.out_off = (uint64_t)ss->d_win;
+    u.out_cap = (uint32_t)(ss->win_cap - kOutTailPad);
+    u.pause_at = ss->pos + (uint32_t)kChunk;
+    u.rebase = ss->rebase;
+    u.state = (uint64_t)(ss->d_ctl + ss->off_state);
+    u.flags = UNIT_F_LAST | (ss->started ? UNIT_F_RESUME : 0u) | (ss->in_loaded < total ? UNIT_F_MORE_INPUT : 0u);
+    return XLZ_OK;
+}
+
+// One refill of every reader in `rs` as ONE launch: each reader's unit continues from its saved
+// state and stops after about kChunk more bytes.  Fills r->chunk / r->finished / r->status.
+int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs)
+{
+    if (rs.empty()) return XLZ_OK;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = rs.size();
+    uint32_t max_lc_lp = 0;
+    std::vector<Unit> units(n);
+    for (size_t i = 0; i < n; i++) {
+        int st = session_prepare(rs[i], ctx->stream);
+        if (st != XLZ_OK) return st;
+        units[i] = rs[i]->ss->unit;
+        max_lc_lp = std::max(max_lc_lp, rs[i]->ss->model_lc_lp);
+    }
+    // units / order / results of this launch: in the first reader's control block when it is alone,
+    // else in a scratch allocation
+    Unit *d_units = nullptr;
+    uint32_t *d_order = nullptr;
+    UnitResult *d_res = nullptr;
+    uint8_t *scratch = nullptr;
+    if (n == 1) {
+        d_units = reinterpret_cast<Unit *>(rs[0]->ss->d_ctl);
+        d_order = reinterpret_cast<uint32_t *>(rs[0]->ss->d_ctl + 128);
+        d_res = reinterpret_cast<UnitResult *>(rs[0]->ss->d_ctl + 160);
+    } else {
+        const size_t o_order = align_up(n * sizeof(Unit), 256), o_res = o_order + align_up(n * 4, 256);
+        HIP_TRY(hipMalloc(&scratch, o_res + n * sizeof(UnitResult)));
+        d_units = reinterpret_cast<Unit *>(scratch);
+        d_order = reinterpret_cast<uint32_t *>(scratch + o_order);
+        d_res = reinterpret_cast<UnitResult *>(scratch + o_res);
+        std::vector<uint32_t> order(n);
+        std::iota(order.begin(), order.end(), 0u);
+        if (hipMemcpyAsync(d_order, order.data(), n * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            (void)hipFree(scratch);
+            return XLZ_ERR_DEVICE;
+        }
+    }
+    uint16_t *d_mlit = nullptr; // resumable units keep their matched-literal tables in their state blocks
+    int st = XLZ_ERR_DEVICE;
+    std::vector<UnitResult> res(n);
+    if (hipMemcpyAsync(d_units, units.data(), n * sizeof(Unit), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+        hipMemsetAsync(ctx->queue, 0, 256, ctx->stream) == hipSuccess) {
+        LaunchParams p;
+        memset(&p, 0, sizeof p);
+        p.in_arena = nullptr; // units carry absolute device addresses
+        p.out_arena = nullptr;
+        p.units = d_units;
+        p.order = d_order;
+        p.results = d_res;
+        p.queue = ctx->queue;
+        p.n_units = (uint32_t)n;
+        p.max_lc_lp = max_lc_lp;
+        p.mlit = d_mlit;
+        p.mlit_stride = 0;
+        if (launch_decode(p, ctx->num_cus, ctx->stream) == 0 &&
+            hipMemcpyAsync(res.data(), d_res, n * sizeof(UnitResult), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+            hipStreamSynchronize(ctx->stream) == hipSuccess)
+            st = XLZ_OK;
+    }
+    if (st == XLZ_OK) {
+        for (size_t i = 0; i < n; i++) {
+            xlz_reader *r = rs[i];
+            Session *ss = r->ss;
+            const UnitResult &u = res[i];
+            const uint32_t new_pos = (uint32_t)u.out_len;
+            ss->started = true;
+            ss->rebase = 0;
+            ss->consumed = u.in_consumed;
+            r->n_refills++;
+            if ((u.aux & AUX_STALE) || u.status == ST_ERR_UNSUPPORTED) {
+                // a copy reached across an LZMA2 dictionary reset (the bytes of this refill are not exact),
+                // or the stream's real properties exceed what its headers announced: malformed streams
+                // only.  The whole-stream path has the epoch table / the HBM model and skips what has
+                // been delivered.
+                r->whole = true;
+                continue;
+            }
+            const size_t fresh = new_pos > ss->pos ? new_pos - ss->pos : 0;
+            r->chunk.resize(fresh);
+            r->rd = 0;
+            if (fresh && hipMemcpyAsync(r->chunk.data(), ss->d_win + ss->pos, fresh, hipMemcpyDeviceToHost, ctx->stream) !=
+                             hipSuccess)
+                st = XLZ_ERR_DEVICE;
+            ss->pos = new_pos;
+            r->delivered += fresh;
+            if (u.status != ST_PAUSED) {
+                r->finished = true;
+                r->status = u.status;
+            }
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) st = XLZ_ERR_DEVICE;
+    }
+    if (scratch) (void)hipFree(scratch);
+    return st;
+}
+
+// Fallback for what a session cannot do (models beyond LDS; malformed LZMA2 streams that read
+// across a dictionary reset): the whole stream through the batch path, which has the HBM-model
+// launch and the exact (epoch table) launch; the bytes already delivered are skipped.
+int reader_whole(xlz_reader *r)
+{
+    r->n_whole++;
+    uint64_t cap = 0;
+    bool known = false;
     if (r->desc.format == XLZ_FMT_LZMA_ALONE) {
         uint64_t u = xlz_decode_unpack_size(r->in.data() + 5);
-        if (u != kUnknownSize) {
-            r->cap_known = true;
-            r->cap = u;
-        }
+        if (u != kUnknownSize) known = true, cap = u;
     } else if (r->desc.format == XLZ_FMT_LZMA_RAW && r->desc.unpack_size != kUnknownSize) {
-        r->cap_known = true;
-        r->cap = r->desc.unpack_size;
+        known = true;
+        cap = r->desc.unpack_size;
     }
-    if (!r->cap_known) r->cap = std::max<uint64_t>(1u << 16, (uint64_t)r->in.size() * 6);
-    if (r->cap > kMaxUnitBytes) r->cap = kMaxUnitBytes;
-}
-
-void reader_fill_desc(xlz_reader *r)
-{
-    r->out.resize((size_t)r->cap);
-    r->desc.in = r->in.data();
-    r->desc.in_len = r->in.size();
-    r->desc.out = r->out.data();
-    r->desc.out_cap = r->out.size();
-}
-
-// true: finished; false: the guessed capacity was too small, try again with a larger one
-bool reader_take_result(xlz_reader *r, const xlz_result &res)
-{
-    if (res.status == XLZ_ERR_OUT_CAP && !r->cap_known && r->cap < kMaxUnitBytes) {
-        r->cap = std::min<uint64_t>(r->cap * 4, kMaxUnitBytes);
-        return false;
+    if (!known) cap = std::max<uint64_t>(1u << 16, std::max<uint64_t>((uint64_t)r->in.size() * 6, r->delivered * 2));
+    std::vector<uint8_t> out;
+    for (;;) {
+        if (cap > kMaxUnitBytes) cap = kMaxUnitBytes;
+        out.resize((size_t)cap);
+        xlz_stream_desc d = r->desc;
+        d.in = r->in.data();
+        d.in_len = r->in.size();
+        d.out = out.data();
+        d.out_cap = out.size();
+        xlz_result res;
+        int st = xlz_decode_batch(r->ctx, &d, 1, &res);
+        if (st != XLZ_OK) return st;
+        if (res.status == XLZ_ERR_OUT_CAP && !known && cap < kMaxUnitBytes) {
+            cap *= 4;
+            continue;
+        }
+        const size_t skip = (size_t)std::min<uint64_t>(r->delivered, res.out_len);
+        r->chunk.assign(out.begin() + skip, out.begin() + (size_t)res.out_len);
+        r->rd = 0;
+        r->delivered = res.out_len;
+        r->finished = true;
+        r->status = res.status;
+        return XLZ_OK;
     }
-    r->status = res.status;
-    r->out.resize((size_t)res.out_len);
-    return true;
 }
 
 void batcher_loop(Batcher *bt)
@@ -1143,7 +1449,7 @@ void batcher_loop(Batcher *bt)
     for (;;) {
         bt->cv_work.wait(lk, [&] { return bt->stop || !bt->pending.empty(); });
         if (bt->stop && bt->pending.empty()) return;
-        // give concurrent constructors a moment to join this batch
+        // give concurrent readers a moment to join this launch
         bt->cv_work.wait_for(lk, std::chrono::microseconds(bt->window_us),
                              [&] { return bt->stop || bt->pending.size() >= bt->max_streams; });
         std::vector<xlz_reader *> work;
@@ -1152,61 +1458,59 @@ void batcher_loop(Batcher *bt)
             bt->pending.pop_front();
         }
         lk.unlock();
-        std::vector<xlz_stream_desc> descs(work.size());
-        std::vector<xlz_result> res(work.size());
-        for (size_t i = 0; i < work.size(); i++) {
-            reader_fill_desc(work[i]);
-            descs[i] = work[i]->desc;
-        }
-        const int st = xlz_decode_batch(bt->ctx, descs.data(), descs.size(), res.data());
+        const int st = sessions_step(bt->ctx, work);
         lk.lock();
         bt->n_batches++;
         bt->n_streams += work.size();
-        for (size_t i = 0; i < work.size(); i++) {
-            xlz_reader *r = work[i];
-            if (st != XLZ_OK) {
-                r->call_status = st;
-                r->decoded = true;
-            } else if (reader_take_result(r, res[i])) {
-                r->decoded = true;
-            } else {
-                bt->pending.push_back(r); // larger output buffer next round
-            }
+        for (xlz_reader *r : work) {
+            if (st != XLZ_OK) r->call_status = st;
+            r->refill_pending = false;
         }
         bt->cv_done.notify_all();
     }
 }
 
-void reader_enqueue(xlz_reader *r)
+// more decoded bytes into r->chunk (or the end of the stream into r->finished / r->status)
+int reader_refill(xlz_reader *r)
 {
-    Batcher *bt = r->ctx->batcher;
-    if (!bt) return;
-    reader_initial_cap(r);
-    std::lock_guard<std::mutex> lk(bt->mu);
-    r->queued = true;
-    bt->pending.push_back(r);
-    bt->cv_work.notify_one();
+    if (!r->ss && !r->whole) {
+        int st = XLZ_OK;
+        {
+            std::lock_guard<std::mutex> lock(r->ctx->mu);
+            HIP_TRY(hipSetDevice(r->ctx->device));
+            st = session_open(r);
+        }
+        if (st == XLZ_ERR_UNSUPPORTED)
+            r->whole = true;
+        else if (st != XLZ_OK)
+            return st;
+    }
+    if (!r->whole) {
+        Batcher *bt = r->ctx->batcher;
+        if (bt) { // the batcher thread steps it together with its contemporaries
+            std::unique_lock<std::mutex> lk(bt->mu);
+            r->refill_pending = true;
+            bt->pending.push_back(r);
+            bt->cv_work.notify_one();
+            bt->cv_done.wait(lk, [&] { return !r->refill_pending; });
+            if (r->call_status != XLZ_OK) return r->call_status;
+        } else {
+            std::vector<xlz_reader *> one{r};
+            int st = sessions_step(r->ctx, one);
+            if (st != XLZ_OK) return st;
+        }
+    }
+    if (r->whole && !r->finished) return reader_whole(r);
+    return XLZ_OK;
 }
 
-int reader_decode(xlz_reader *r)
+void reader_release_device(xlz_reader *r)
 {
-    if (r->queued) { // the batcher thread decodes it together with its contemporaries
-        Batcher *bt = r->ctx->batcher;
-        std::unique_lock<std::mutex> lk(bt->mu);
-        bt->cv_done.wait(lk, [&] { return r->decoded; });
-        return r->call_status;
-    }
-    if (r->decoded) return XLZ_OK;
-    reader_initial_cap(r);
-    for (;;) {
-        reader_fill_desc(r);
-        xlz_result res;
-        int st = xlz_decode_batch(r->ctx, &r->desc, 1, &res);
-        if (st != XLZ_OK) return st;
-        if (reader_take_result(r, res)) break;
-    }
-    r->decoded = true;
-    return XLZ_OK;
+    if (!r->ss) return;
+    std::lock_guard<std::mutex> lock(r->ctx->mu);
+    (void)hipSetDevice(r->ctx->device);
+    session_free(r->ss);
+    r->ss = nullptr;
 }
 
 } // namespace
@@ -1228,10 +1532,8 @@ extern "C" xlz_reader *xlz_new_reader1(xlz_ctx *ctx, const uint8_t *in, size_t i
         r = reader_new(ctx, in, in_len);
         if (!r)
             e = XLZ_ERR_BAD_ARG;
-        else {
+        else
             r->desc.format = XLZ_FMT_LZMA_ALONE;
-            reader_enqueue(r);
-        }
     }
     if (err) *err = e;
     return r;
@@ -1272,7 +1574,6 @@ extern "C" xlz_reader *xlz_new_reader2(xlz_ctx *ctx, const uint8_t *in, size_t i
             } else {
                 r->desc.format = XLZ_FMT_LZMA2_RAW;
                 r->desc.dict_size = (uint32_t)dict_size;
-                reader_enqueue(r);
             }
         }
     }
@@ -1306,7 +1607,6 @@ extern "C" xlz_reader *xlz_new_lzma_decompressor_for_sevenzip(xlz_ctx *ctx, cons
                 r->desc.dict_size = xlz_decode_dict_size(props + 1);
                 r->desc.unpack_size = unpack_size;
                 r->is_closer = true;
-                reader_enqueue(r);
             }
         }
     }
@@ -1336,7 +1636,8 @@ extern "C" xlz_reader *xlz_new_lzma2_decompressor_for_sevenzip(xlz_ctx *ctx, con
     return r;
 }
 
-// Reader1.Read / Reader2.Read / readCloser.Read
+// Reader1.Read / Reader2.Read / readCloser.Read (reader1.go:223-254): drain what is pending, decode
+// more when the caller's buffer is not full yet, io.EOF only once everything has been delivered.
 extern "C" long xlz_reader_read(xlz_reader *r, uint8_t *p, size_t n, int *err)
 {
     int e = XLZ_OK;
@@ -1345,13 +1646,22 @@ extern "C" long xlz_reader_read(xlz_reader *r, uint8_t *p, size_t n, int *err)
         e = XLZ_ERR_BAD_ARG;
     } else if (r->closed) {
         e = XLZ_ERR_CLOSED; // readcloser.go:31-33
-    } else if ((e = reader_decode(r)) == XLZ_OK) {
-        const size_t left = r->out.size() - r->rd;
-        const size_t k = std::min(left, n);
-        if (k) memcpy(p, r->out.data() + r->rd, k);
-        r->rd += k;
-        got = (long)k;
-        if (r->rd == r->out.size() && (k < n || n == 0)) e = r->status >= 0 ? XLZ_EOF : r->status;
+    } else {
+        for (;;) {
+            const size_t left = r->chunk.size() - r->rd;
+            const size_t k = std::min(left, n - (size_t)got);
+            if (k) memcpy(p + got, r->chunk.data() + r->rd, k);
+            r->rd += k;
+            got += (long)k;
+            if ((size_t)got == n) break; // p is full (the reference's Read(p) with len(p) == 0 never returns)
+            // the chunk is drained here
+            if (r->finished) { // everything produced has been handed over: io.EOF, or the decode error
+                e = r->status >= 0 ? XLZ_EOF : r->status;
+                break;
+            }
+            if ((e = reader_refill(r)) != XLZ_OK) break;
+        }
+        if (n == 0 && r->finished && r->rd == r->chunk.size()) e = r->status >= 0 ? XLZ_EOF : r->status;
     }
     if (err) *err = e;
     return got;
@@ -1362,19 +1672,29 @@ extern "C" int xlz_reader_close(xlz_reader *r)
 {
     if (!r) return XLZ_ERR_BAD_ARG;
     if (r->closed) return XLZ_ERR_CLOSED;
-    if (r->queued) (void)reader_decode(r); // its buffers are in use until the batch is done
     r->closed = true;
+    reader_release_device(r);
     r->in.clear();
     r->in.shrink_to_fit();
-    r->out.clear();
-    r->out.shrink_to_fit();
+    r->chunk.clear();
+    r->chunk.shrink_to_fit();
     return XLZ_OK;
 }
 
 extern "C" void xlz_reader_free(xlz_reader *r)
 {
-    if (r && r->queued) (void)reader_decode(r);
+    if (!r) return;
+    reader_release_device(r);
     delete r;
+}
+
+extern "C" int xlz_reader_stats(const xlz_reader *r, uint64_t *refills, uint64_t *whole_decodes, uint64_t *in_uploaded)
+{
+    if (!r) return XLZ_ERR_BAD_ARG;
+    if (refills) *refills = r->n_refills;
+    if (whole_decodes) *whole_decodes = r->n_whole;
+    if (in_uploaded) *in_uploaded = r->ss ? r->ss->in_loaded : 0;
+    return XLZ_OK;
 }
 
 static void batcher_shutdown(Batcher *bt)

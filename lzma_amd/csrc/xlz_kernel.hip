@@ -56,7 +56,10 @@ constexpr uint32_t kFastInput = 32;   // >= lzmaRequiredInputMax = 20 (types.go:
 constexpr uint32_t kFastOutput = 336; // >= maxMatchLen 273 (types.go:46) + 63: the fast path's copies store whole
                                       // 64-lane rows and must stay inside the unit's own output range
 
-enum : int { RUN_END = 0, RUN_INPUT_EOF = 1, RUN_ERR_RESULT = 2, RUN_OUT_CAP = 3, RUN_CONTINUE = 4 };
+constexpr uint32_t kLzma1InputMargin = 64;     // UNIT_F_MORE_INPUT: ask for more input below this (a packet needs <= 20)
+constexpr uint32_t kLzma2InputMargin = 67584;  // ... LZMA2: a whole chunk (6-byte header + 64 KiB) must be in the window
+
+enum : int { RUN_END = 0, RUN_INPUT_EOF = 1, RUN_ERR_RESULT = 2, RUN_OUT_CAP = 3, RUN_CONTINUE = 4, RUN_PAUSE = 5 };
 
 // Everything a unit carries between packets / chunks.  Except `vin` all members are
 // wave-uniform; after inlining they live in SGPRs.
@@ -75,8 +78,8 @@ struct Dec {
     // LZMA state (state.go:28-45)
     uint32_t state, rep0, rep1, rep2, rep3;
     uint32_t lc, lp_mask, pos_mask;
-    bool size_defined;
-    uint32_t bytes_left;
+    uint32_t size_defined; // 0 / 1 (kept as a word: it is saved and restored)
+    uint64_t bytes_left; // state.go:123-129 keeps 64 bits
     // window (window.go:8-16) over the flat output
     uint32_t pos;        // bytes of output produced by this unit
     uint32_t wbase;      // output offset of the last dictionary reset (0 for LZMA1)
@@ -85,7 +88,17 @@ struct Dec {
     uint32_t out_cap;
     uint32_t prev_byte;  // byte at distance 1 (0 while the window is empty)
     uint32_t match_byte; // byte at distance rep0+1, valid right after a match / rep
-    uint32_t stale;      // a copy reached in front of the current dictionary epoch
+    uint32_t stale;      // a copy reached in front of the current dictionary epoch and no epoch table is there
+    // pull readers: the unit stops at the first packet / chunk boundary with pos >= pause_at
+    uint32_t pause_at;
+    uint32_t in_margin;  // LZMA1 + UNIT_F_MORE_INPUT: pause for more input below this many bytes, else 0
+    uint32_t need_input; // that pause happened
+    uint32_t in_base;    // input bytes consumed before the unit's input window (UNIT_F_RESUME)
+    bool epoch0_clean;   // nothing precedes the unit's first dictionary epoch: bytes in front of it are 0
+    // exact launches: earlier dictionary epochs a copy may still read (window.Reset keeps the buffer)
+    Epoch *epochs;
+    uint32_t n_epochs;
+    uint8_t *dump;       // 64 bytes per lane-row that predicated-off lanes store to
 };
 
 __device__ __forceinline__ uint32_t umod_small(uint32_t i, uint32_t d)
@@ -96,6 +109,71 @@ __device__ __forceinline__ uint32_t umod_small(uint32_t i, uint32_t d)
     if (r < 0) r += (int32_t)d;
     if ((uint32_t)r >= d) r -= (int32_t)d;
     return (uint32_t)r;
+}
+
+// The byte the reference's window holds at circular index c (0 <= c < dict_size) while the
+// current dictionary epoch has not written there yet: window.Reset (window.go:135-140) keeps the
+// buffer, so it is the last byte any EARLIER epoch of the stream wrote at c, and 0 if none did
+// (zero-filled at allocation, window.go:18-29).  The epochs still visible are kept as a stack
+// with strictly decreasing lengths (an epoch hides every earlier one that was not longer), so
+// the first entry from the top that is long enough holds the byte.  Exact launches only.
+__device__ __forceinline__ uint32_t stale_byte(const uint8_t *__restrict__ out, const Dec &d, uint32_t c, bool want)
+{
+    uint32_t b = 0;
+    bool found = !want;
+    for (uint32_t k = d.n_epochs; k-- > 0;) { // wave-uniform trip count, selects instead of branches
+        const uint32_t start = RFL(d.epochs[k].start), len = RFL(d.epochs[k].len);
+        const bool hit = !found && len > c;
+        uint32_t o = start + c;
+        if (len > d.dict_size) // the epoch wrapped: the LAST write to index c
+            o += ((len - 1 - c) / d.dict_size) * d.dict_size;
+        const uint32_t v = out[hit ? o : start];
+        b = hit ? v : b;
+        found = found || hit;
+    }
+    return b;
+}
+
+// dictionary reset (window.Reset): the epoch [wbase, pos) ends; remember it for stale reads
+__device__ __forceinline__ bool epoch_push(Dec &d)
+{
+    if (!d.epochs) return true;
+    const uint32_t len = d.pos - d.wbase;
+    if (len == 0) return true;
+    while (d.n_epochs && RFL(d.epochs[d.n_epochs - 1].len) <= len) d.n_epochs--;
+    if (d.n_epochs == kMaxEpochs) return false;
+    Epoch e;
+    e.start = d.wbase;
+    e.len = len;
+    d.epochs[d.n_epochs++] = e; // every lane stores the same 8 bytes
+    return true;
+}
+
+// window.CopyMatch when the copy reaches in front of the current dictionary epoch and the launch
+// has an epoch table: every byte is the reference's (window.go:55-87 over the uncleared circular
+// buffer).  Rare (malformed LZMA2 streams), so plain and slow; also yields prevByte / matchByte.
+__device__ __forceinline__ void wave_copy_exact(uint8_t *__restrict__ out, Dec &d, uint32_t dist, uint32_t len,
+                                                uint32_t lane)
+{
+    const uint32_t pos = d.pos;
+    const uint64_t lo = (uint64_t)dist + d.wbase;
+    const uint32_t fill = pos - d.wbase; // bytes of the current epoch; the window is not full here
+    const bool wrap = dist <= len;
+    for (uint32_t base = 0; base <= len; base += kWave) { // i == len too: the next packet's matchByte
+        const uint32_t i = min(base + lane, len);
+        uint32_t j = i;
+        if (wrap) j = umod_small(i, dist); // byte i repeats byte i mod dist (i < 1024, dist <= 273 here)
+        const uint64_t vs = (uint64_t)pos + j;
+        const bool ok = vs >= lo;
+        const uint32_t raw = out[ok ? vs - dist : 0];
+        // circular index of the source: window.pos + j - dist + size (window.go:57-61), window.pos = fill
+        const uint32_t sb = stale_byte(out, d, fill + j + d.dict_size - dist, !ok);
+        const uint32_t b = ok ? raw : sb;
+        uint8_t *dst = (base + lane) < len ? out + ((uint64_t)pos + i) : d.dump + lane;
+        *dst = (uint8_t)b;
+        if (len - 1 >= base && len - 1 < base + kWave) d.prev_byte = (uint32_t)__builtin_amdgcn_readlane((int)b, len - 1 - base);
+        if (len < base + kWave) d.match_byte = (uint32_t)__builtin_amdgcn_readlane((int)b, len - base);
+    }
 }
 
 // window.CopyMatch (window.go:55-87) over the flat output, all 64 lanes.
@@ -114,8 +192,13 @@ __device__ __forceinline__ uint32_t umod_small(uint32_t i, uint32_t d)
 // overwritten by later packets before anything can read them.
 //
 // PRECISE = true (checked path, i.e. near the end of a unit's output range, where the next
-// bytes may belong to a neighbouring unit of the same LZMA2 stream): lanes >= len write
-// their own source byte back to where they read it instead of touching bytes past the copy.
+// bytes may belong to a neighbouring unit of the same LZMA2 stream): lanes >= len store to the
+// launch's dump row instead of touching bytes past the copy.
+//
+// A source in front of the current dictionary epoch reads as 0 -- exact for the first epoch of a
+// stream (zero-filled window, window.go:18-29); later epochs can see the previous epoch's bytes
+// in the reference (window.go:135-140): with an epoch table (exact launch) wave_copy_exact
+// reproduces them, without one the unit is flagged (AUX_STALE) and the host runs such a launch.
 template <bool PRECISE>
 __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ out, Dec &d, uint32_t dist, uint32_t len,
                                           uint32_t lane)
@@ -123,7 +206,13 @@ __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ out, Dec &d, uin
     const uint32_t pos = d.pos;
     const uint64_t lo = (uint64_t)dist + d.wbase; // virtual index >= wbase  <=>  pos + j >= lo
     const bool wrap = dist <= len;                // some i in [0, len] needs i mod dist
-    if ((uint64_t)pos < lo) d.stale = 1;
+    if ((uint64_t)pos < lo && !(d.wbase == 0 && d.epoch0_clean)) {
+        if (d.epochs) {
+            wave_copy_exact(out, d, dist, len, lane);
+            return;
+        }
+        d.stale = 1;
+    }
     if (len < kWave) {
         uint32_t j = lane;
         if (wrap) j = umod_small(lane, dist);
@@ -133,10 +222,12 @@ __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ out, Dec &d, uin
         const uint64_t sa = ok ? vs - dist : 0;
         const uint32_t raw = out[sa];
         const uint32_t b = ok ? raw : 0u;
-        if (PRECISE)
-            out[lane < len ? (uint64_t)pos + lane : sa] = (uint8_t)(lane < len ? b : raw);
-        else
+        if (PRECISE) {
+            uint8_t *dst = lane < len ? out + ((uint64_t)pos + lane) : d.dump + lane;
+            *dst = (uint8_t)b;
+        } else {
             out[pos + lane] = (uint8_t)b;
+        }
         d.prev_byte = (uint32_t)__builtin_amdgcn_readlane((int)b, len - 1);
         d.match_byte = (uint32_t)__builtin_amdgcn_readlane((int)b, len);
     } else {
@@ -150,10 +241,12 @@ __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ out, Dec &d, uin
             const uint64_t sa = ok ? vs - dist : 0;
             const uint32_t raw = out[sa];
             const uint32_t b = ok ? raw : 0u;
-            if (PRECISE)
-                out[i < len ? (uint64_t)pos + i : sa] = (uint8_t)(i < len ? b : raw);
-            else
+            if (PRECISE) {
+                uint8_t *dst = i < len ? out + ((uint64_t)pos + i) : d.dump + lane;
+                *dst = (uint8_t)b;
+            } else {
                 out[pos + i] = (uint8_t)b;
+            }
         }
         // bytes len-1 and len of the copy, re-read (long matches are rare)
         const uint32_t i = len - 1 + (lane & 1); // lanes 0 and 1 matter
@@ -346,7 +439,7 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
         out[d.pos] = (uint8_t)symbol; // window.PutByte :168 (all lanes, same byte, same address)
         d.pos++;
         if (++d.wpos >= d.dict_size) d.wpos -= d.dict_size; // window.go:38-41
-        d.prev_byte = symbol;
+        d.prev_byte = RFL(symbol); // (the readfirstlane keeps prev_byte's phi web scalar, see sv_store)
         d.state = upd_literal(d.state); // :171
         d.bytes_left--;                 // :172 (wraps harmlessly when the size is undefined)
         return RUN_CONTINUE;
@@ -449,8 +542,8 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
     // window.CopyMatch + size bookkeeping, :657-668, 936-947, 1030-1041, 1106-1117
     {
         bool truncated = false, overflow = false;
-        if (d.size_defined && d.bytes_left < length) {
-            length = d.bytes_left;
+        if (d.size_defined && (uint32_t)d.bytes_left < length) { // uint32(s.bytesLeft) < length, decompress.go:657
+            length = (uint32_t)d.bytes_left;
             truncated = true;
         }
         if (length > d.out_cap - d.pos) {
@@ -550,9 +643,15 @@ __device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint16_t *__res
     for (;;) {
         // decompress.go:14-20
         if (d.size_defined && d.bytes_left == 0 && d.code == 0) return RUN_END;
+        // pull readers: decompress(need) returns once enough bytes are pending (decompress.go:13)
+        if (d.pos >= d.pause_at) return RUN_PAUSE;
         // keep kFastInput bytes of window ahead of the packet
         if (d.arel > kInWindow - kFastInput) in_window(d, in_pos(d), lane);
         const uint32_t in_left = d.aend - in_pos(d);
+        if (in_left < d.in_margin) { // the input window of a longer stream runs low: not an EOF
+            d.need_input = 1;
+            return RUN_PAUSE;
+        }
         const bool fast = allow_fast && in_left >= kFastInput && (d.out_cap - d.pos) >= kFastOutput &&
                           (!d.size_defined || d.bytes_left >= kFastOutput);
         if (!fast) {
@@ -563,10 +662,10 @@ __device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint16_t *__res
         // a packet may START while arel <= arel_lim and pos < pos_lim
         const uint32_t arel_lim = min(kInWindow - kFastInput, d.arel + (in_left - kFastInput));
         uint32_t room = d.out_cap - d.pos - kFastOutput;
-        if (d.size_defined) room = min(room, d.bytes_left - kFastOutput);
+        if (d.size_defined) room = (uint32_t)min((uint64_t)room, d.bytes_left - kFastOutput);
         const uint32_t pos0 = d.pos;
         uint32_t len = 0;
-        const uint32_t ec = lzma_fast_loop(d, out, mprobs, lane, hv, arel_lim, pos0 + room + 1, len);
+        const uint32_t ec = lzma_fast_loop(d, out, mprobs, lane, hv, arel_lim, min(pos0 + room + 1, d.pause_at), len);
         d.bytes_left -= d.pos - pos0; // :172,660,665 ... (wraps harmlessly when the size is undefined)
         if (ec == FX_ERR) return RUN_ERR_RESULT; // :651-653, :690-692
         if (ec == FX_MARKER) {                    // end marker :633-645 (bytesLeft > 0 here if defined)
@@ -614,8 +713,8 @@ __device__ __forceinline__ void probs_reset(uint16_t *probs, uint32_t nprobs, ui
 __device__ __forceinline__ void set_unpack_size(Dec &d, uint64_t u)
 {
     // state.go:123-151: defined unless all eight bytes are 0xFF
-    d.size_defined = u != ~(uint64_t)0;
-    d.bytes_left = (uint32_t)u; // host guarantees a defined size is < 4 GiB
+    d.size_defined = u != ~(uint64_t)0 ? 1u : 0u;
+    d.bytes_left = u;
 }
 
 // ---- LZMA2 framing (reader2.go:100-298), one wave walking the chunks of a unit ----
@@ -640,6 +739,17 @@ __device__ __forceinline__ void reload_context(Dec &d, const uint8_t *__restrict
     const bool ok = (uint64_t)d.pos >= lo;
     uint32_t b = out[ok ? d.pos - dist : 0];
     b = ok ? b : 0u;
+    if (!(d.wbase == 0 && d.epoch0_clean)) { // bytes in front of this epoch may be an earlier epoch's
+        const uint32_t fill = d.pos - d.wbase;
+        const bool full = fill >= d.dict_size;
+        const bool valid = dist <= d.dict_size; // GetByte with a larger distance indexes out of the reference's buffer
+        if (d.epochs) {
+            const uint32_t sb = stale_byte(out, d, fill + d.dict_size - dist, !ok && !full && valid);
+            b = (!ok && !full && valid) ? sb : b;
+        } else if (__builtin_amdgcn_readlane((int)(uint32_t)(!ok && !full), 1)) {
+            d.stale = 1; // matchByte would come from an earlier epoch (prevByte is 0 on an empty window)
+        }
+    }
     d.prev_byte = (uint32_t)__builtin_amdgcn_readlane((int)b, 0);
     d.match_byte = (uint32_t)__builtin_amdgcn_readlane((int)b, 1);
     if (d.pos == d.wbase) d.prev_byte = 0; // window.IsEmpty (decompress.go:50-53)
@@ -669,6 +779,8 @@ struct Walk {
     uint32_t lc_lp;
     uint32_t h5;       // header[5] persists across chunks (reader2.go:37,147)
     bool last_unit, have_reader, first_chunk;
+    bool more_input;   // UNIT_F_MORE_INPUT: the unit's input is a window of a longer stream
+    uint32_t model_lc_lp; // largest lc+lp this unit's model storage was sized for
 };
 
 enum : int32_t { WALK_RUN_CHUNK = 1000 }; // lzma2_next: a compressed chunk is set up, run it
@@ -682,6 +794,11 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
 {
     for (;;) {
         d.aend = w.unit_end;
+        if (d.pos >= d.pause_at) return ST_PAUSED; // pull readers: enough bytes are pending
+        if (w.more_input && w.unit_end - in_pos(d) < kLzma2InputMargin) { // a whole chunk must be in the window
+            d.need_input = 1;
+            return ST_PAUSED;
+        }
         if (in_pos(d) == w.unit_end) // ReadByte fails (reader2.go:103-110)
             return w.last_unit ? ST_ERR_UNEXPECTED_EOF : ST_OK;
         if (d.arel > kInWindow - kFastInput) in_window(d, in_pos(d), lane);
@@ -689,7 +806,7 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
         IN_BYTE(c);
         // decodeChunkType (reader2.go:175-199): 0x03..0x7F fall through to end-of-stream
         if (c == 0 || (c >= 3 && c < 0x80)) {
-            aux |= 1u;
+            aux |= AUX_END_MARK;
             return ST_OK;
         }
         const bool stored = c < 3;
@@ -708,6 +825,7 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
         }
         uint32_t unc = (h1 << 8) | h2; // :130
         if (c == 1 || sub == 7) {      // dictionary reset: window.Reset (:132-134, window.go:135-140)
+            if (!epoch_push(d)) return ST_ERR_UNSUPPORTED; // more visible epochs than the table holds
             d.wbase = d.pos;
             d.wpos = 0;
             d.prev_byte = 0; // window.IsEmpty again (decompress.go:50-53)
@@ -724,8 +842,10 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
             d.pos += n;
             d.wpos += n; // window.ReadFrom (window.go:146-153); the dictionary may be smaller than n
             while (d.wpos >= d.dict_size) d.wpos -= d.dict_size;
-            // out of room: the byte that did not fit has been read (as in the oracle's byte loop)
-            in_window(d, in_pos(d) + n + (overflow ? 1u : 0u), lane);
+            // out of room: window.ReadFrom still drains the chunk from the source (window.go:142-155;
+            // the oracle's byte loop does the same), only then does the missing room surface
+            if (overflow) n = min(unc, w.unit_end - in_pos(d));
+            in_window(d, in_pos(d) + n, lane);
             if (overflow) return ST_ERR_OUT_CAP;
             reload_context(d, out, lane);
             continue;
@@ -737,7 +857,8 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
             // NewReader1ForReader2 / Renew: props from header[5] (reader2.go:146-165)
             if (w.h5 >= 225) return ST_ERR_PROPS; // DecodeProp, reader1.go:211-213
             const uint32_t lc = w.h5 % 9, r = w.h5 / 9, lp = r % 5, pb = r / 5;
-            if (lc + lp > max_lc_lp) return ST_ERR_UNSUPPORTED; // LDS is sized by the host's header scan
+            if (lc + lp > max_lc_lp || lc + lp > w.model_lc_lp)
+                return ST_ERR_UNSUPPORTED; // LDS / the saved state are sized by the host's header scan
             d.lc = lc;
             d.lp_mask = (1u << lp) - 1;
             d.pos_mask = (1u << pb) - 1;
@@ -749,10 +870,44 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
         w.first_chunk = !w.have_reader;
         w.have_reader = true;
         // Reopen: SetUnpackSize + limitByteReader + rangeDec.Init (reader1.go:166-176)
-        d.size_defined = true;
+        d.size_defined = 1;
         d.bytes_left = unc;
         d.aend = min(in_pos(d) + comp, w.unit_end);
         return WALK_RUN_CHUNK;
+    }
+}
+
+// ---- pull readers: decoder state saved to / restored from HBM between launches ----------
+// Word indices inside a UnitState (xlz_format.h): everything a unit carries across a pause.
+enum : uint32_t {
+    SV_RANGE, SV_CODE, SV_STATE, SV_REP0, SV_REP1, SV_REP2, SV_REP3, SV_LC, SV_LP_MASK, SV_POS_MASK, SV_SIZE_DEFINED,
+    SV_BYTES_LEFT_LO, SV_BYTES_LEFT_HI, SV_POS, SV_WBASE, SV_WPOS, SV_PREV, SV_MATCH, SV_STALE, SV_CONSUMED, SV_CHUNK_END,
+    SV_LC_LP, SV_H5, SV_HAVE_READER, SV_FIRST_CHUNK, SV_PHASE, SV_AUX, SV_COUNT
+};
+static_assert(SV_COUNT <= kStateWords, "UnitState header too small");
+
+enum : uint32_t { PH_NEXT = 0, PH_CHUNK = 1 }; // between chunks (or not started) / inside lzma_run of a chunk
+
+// One word of saved state.  The wave-uniform value takes a scalar add and an explicit v_mov on its way
+// to the store: with a plain store LLVM's SGPR-copy fixing turns loop-carried values that are only
+// ever moved (the four reps) into VGPR phis, which the fast loop's "s" asm constraints cannot take
+// ("illegal VGPR to SGPR copy").
+__device__ __forceinline__ void sv_store(uint32_t *st, uint32_t idx, uint32_t value)
+{
+    uint32_t v, z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    value += z; // a scalar ALU op on the value (z is opaque to the compiler)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(value));
+    st[idx] = v;
+}
+
+__device__ __forceinline__ void model_copy(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint32_t nprobs,
+                                           uint32_t lane)
+{
+    const uint32_t nw = nprobs / 2;
+    for (uint32_t base = 0; base < nw; base += kWave) {
+        const uint32_t i = min(base + lane, nw - 1);
+        dst[i] = src[i];
     }
 }
 
@@ -760,7 +915,7 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
 // 0).  BIG = true (lc+lp > 6): the model is a slot of HBM scratch and only the checked C++
 // packet decoder runs -- slow, but the reference's whole parameter range decodes.
 template <bool BIG>
-__device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *probs, uint16_t *__restrict__ mprobs)
+__device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *probs, uint16_t *__restrict__ wg_mprobs)
 {
     const uint32_t lane = threadIdx.x;
     const HeadVec hv = head_vectors(lane);
@@ -771,6 +926,7 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
         // 256-byte block (a branch here would make the whole loop divergent, see wave_copy)
         const uint32_t q = RFL(atomicAdd(p.queue + lane, lane == 0 ? 1u : 0u));
         if (q >= p.n_units) break; // every wave reaches this once the queue is drained
+        const uint32_t t_start = (uint32_t)wall_clock64();
 
         const uint32_t ui = RFL(p.order[p.order_base + q]);
         const Unit *up = p.units + ui;
@@ -779,6 +935,7 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
         const uint64_t in_off = rfl64(up->in_off);
         const uint64_t out_off = rfl64(up->out_off);
         const uint64_t unpack = rfl64(up->unpack_size);
+        const uint64_t state_addr = rfl64(up->state);
         const uint32_t in_len = RFL(up->in_len);
         const bool lzma2 = RFL(up->kind) == UNIT_LZMA2;
         const uint32_t flags = RFL(up->flags);
@@ -786,66 +943,159 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
         d.dict_size = RFL(up->dict_size);
         const uint32_t lc = RFL(up->lc), lp = RFL(up->lp), pb = RFL(up->pb);
         uint8_t *__restrict__ out = p.out_arena + out_off;
+        // a resumable unit keeps the matched-literal half of its model in its own state block
+        uint32_t *const st = reinterpret_cast<uint32_t *>(state_addr);
+        uint16_t *__restrict__ mprobs =
+            st ? reinterpret_cast<uint16_t *>(state_addr + state_mprobs_off(lc + lp)) : wg_mprobs;
+        const bool resume = (flags & UNIT_F_RESUME) != 0;
 
-        d.lc = lc;
-        d.lp_mask = (1u << lp) - 1;
-        d.pos_mask = (1u << pb) - 1;
-        d.state = 0;
-        d.rep0 = d.rep1 = d.rep2 = d.rep3 = 0;
-        d.pos = 0;
-        d.wbase = 0;
-        d.wpos = 0;
-        d.prev_byte = 0;
-        d.match_byte = 0;
-        d.stale = 0;
-        d.range = 0;
-        d.code = 0;
-        set_unpack_size(d, unpack);
+        d.dump = reinterpret_cast<uint8_t *>(p.queue + 64);
+        d.epochs = p.epochs ? p.epochs + (size_t)blockIdx.x * kMaxEpochs : nullptr;
+        d.n_epochs = 0;
+        d.epoch0_clean = !lzma2 || !(flags & UNIT_F_NOT_FIRST);
+        d.pause_at = st ? RFL(up->pause_at) : 0xFFFFFFFFu;
+        d.in_margin = (!lzma2 && (flags & UNIT_F_MORE_INPUT)) ? kLzma1InputMargin : 0u;
+        d.need_input = 0;
+        d.in_base = resume ? RFL(up->in_skip) : 0u;
         in_open(d, p.in_arena, in_off, in_len, lane);
         w.unit_end = d.abase + in_len;
-        w.lc_lp = lc + lp;
-        w.h5 = 0;
         w.last_unit = (flags & UNIT_F_LAST) != 0;
-        w.have_reader = (flags & UNIT_F_HAVE_READER) != 0;
-        w.first_chunk = true;
-        if (!lzma2) { // newState -> Reset (state.go:47-61)
-            probs_reset(probs, num_probs(lc + lp), lane);
-            mprobs_reset(mprobs, num_matched_probs(lc + lp), lane);
+        w.more_input = lzma2 && (flags & UNIT_F_MORE_INPUT);
+        w.model_lc_lp = st ? lc + lp : 0xFFu; // only a saved state block is sized per unit (LDS: per launch)
+
+        uint32_t phase = PH_NEXT;
+        uint32_t aux = 0;
+        if (resume) {
+            d.range = RFL(st[SV_RANGE]);
+            d.code = RFL(st[SV_CODE]);
+            d.state = RFL(st[SV_STATE]);
+            d.rep0 = RFL(st[SV_REP0]);
+            d.rep1 = RFL(st[SV_REP1]);
+            d.rep2 = RFL(st[SV_REP2]);
+            d.rep3 = RFL(st[SV_REP3]);
+            d.lc = RFL(st[SV_LC]);
+            d.lp_mask = RFL(st[SV_LP_MASK]);
+            d.pos_mask = RFL(st[SV_POS_MASK]);
+            d.size_defined = RFL(st[SV_SIZE_DEFINED]);
+            d.bytes_left = ((uint64_t)RFL(st[SV_BYTES_LEFT_HI]) << 32) | RFL(st[SV_BYTES_LEFT_LO]);
+            // the host may have moved the window down (the last dict_size bytes stay reachable)
+            const uint32_t rebase = RFL(up->rebase);
+            const uint32_t wb = RFL(st[SV_WBASE]);
+            d.pos = RFL(st[SV_POS]) - rebase;
+            d.wbase = wb > rebase ? wb - rebase : 0u;
+            if (wb < rebase) d.epoch0_clean = false; // the epoch's start left the buffer (only if it is full anyway)
+            d.wpos = RFL(st[SV_WPOS]);
+            d.prev_byte = RFL(st[SV_PREV]);
+            d.match_byte = RFL(st[SV_MATCH]);
+            d.stale = RFL(st[SV_STALE]);
+            w.lc_lp = RFL(st[SV_LC_LP]);
+            w.h5 = RFL(st[SV_H5]);
+            w.have_reader = RFL(st[SV_HAVE_READER]) != 0;
+            w.first_chunk = RFL(st[SV_FIRST_CHUNK]) != 0;
+            phase = RFL(st[SV_PHASE]);
+            aux = RFL(st[SV_AUX]);
+            // input: continue at the saved position inside the (possibly moved) input window
+            const uint32_t consumed = RFL(st[SV_CONSUMED]);
+            in_window(d, d.abase + (consumed - d.in_base), lane);
+            // inside an LZMA2 chunk the limitedByteReader's end stays where the chunk header put it
+            d.aend = (lzma2 && phase == PH_CHUNK) ? min(d.abase + (RFL(st[SV_CHUNK_END]) - d.in_base), w.unit_end) : w.unit_end;
+            model_copy(reinterpret_cast<uint32_t *>(probs), st + kStateWords, num_probs(w.lc_lp), lane);
+        } else {
+            d.lc = lc;
+            d.lp_mask = (1u << lp) - 1;
+            d.pos_mask = (1u << pb) - 1;
+            d.state = 0;
+            d.rep0 = d.rep1 = d.rep2 = d.rep3 = 0;
+            d.pos = 0;
+            d.wbase = 0;
+            d.wpos = 0;
+            d.prev_byte = 0;
+            d.match_byte = 0;
+            d.stale = 0;
+            d.range = 0;
+            d.code = 0;
+            set_unpack_size(d, unpack);
+            w.lc_lp = lc + lp;
+            w.h5 = 0;
+            w.have_reader = (flags & UNIT_F_HAVE_READER) != 0;
+            w.first_chunk = true;
+            if (!lzma2) { // newState -> Reset (state.go:47-61)
+                probs_reset(probs, num_probs(lc + lp), lane);
+                mprobs_reset(mprobs, num_matched_probs(lc + lp), lane);
+            }
         }
 
         int32_t status;
-        uint32_t aux = 0;
         // LZMA1: exactly one "chunk" (the whole stream).  LZMA2: one per compressed chunk.
-        for (bool once = true;; once = false) {
-            if (lzma2) {
-                status = lzma2_next(d, w, probs, mprobs, p.in_arena + in_off, out, p.max_lc_lp, lane, aux);
-                if (status != WALK_RUN_CHUNK) break;
-            } else if (!once) {
-                break;
-            }
-            const int ir = rc_init(d); // Reader1.initialize / Reopen (reader1.go:149-176)
-            if (ir == 1) { // io.EOF: a constructor error, or -- raw, from a later LZMA2 chunk -- a clean EOF
-                status = (!lzma2 || w.first_chunk) ? ST_ERR_HEADER_EOF : ST_OK_INPUT_EOF;
-                break;
-            }
-            if (ir == 2) {
-                status = ST_ERR_RC_INIT;
-                break;
+        for (;;) {
+            if (phase != PH_CHUNK) {
+                if (lzma2) {
+                    status = lzma2_next(d, w, probs, mprobs, p.in_arena + in_off, out, p.max_lc_lp, lane, aux);
+                    if (status != WALK_RUN_CHUNK) break;
+                }
+                const int ir = rc_init(d); // Reader1.initialize / Reopen (reader1.go:149-176)
+                if (ir == 1) { // io.EOF: a constructor error, or -- raw, from a later LZMA2 chunk -- a clean EOF
+                    status = (!lzma2 || w.first_chunk) ? ST_ERR_HEADER_EOF : ST_OK_INPUT_EOF;
+                    break;
+                }
+                if (ir == 2) {
+                    status = ST_ERR_RC_INIT;
+                    break;
+                }
+                phase = PH_CHUNK;
             }
             const int r = lzma_run(d, probs, mprobs, out, lane, hv, !big);
+            if (r == RUN_PAUSE) {
+                status = ST_PAUSED;
+                break;
+            }
             status = r == RUN_END ? ST_OK
                                   : r == RUN_INPUT_EOF ? ST_OK_INPUT_EOF
                                                        : r == RUN_OUT_CAP ? ST_ERR_OUT_CAP : ST_ERR_RESULT;
             // LZMA2: io.EOF from the chunk -> next startChunk (reader2.go:234-241); the unread
             // rest of a chunk is NOT skipped by the reference
-            if (status < 0) break;
+            if (status < 0 || !lzma2) break;
+            phase = PH_NEXT;
+        }
+        const uint32_t consumed = d.in_base + (in_pos(d) - d.abase);
+        if (status == ST_PAUSED) { // every lane stores the same words
+            sv_store(st, SV_RANGE, d.range);
+            sv_store(st, SV_CODE, d.code);
+            sv_store(st, SV_STATE, d.state);
+            sv_store(st, SV_REP0, d.rep0);
+            sv_store(st, SV_REP1, d.rep1);
+            sv_store(st, SV_REP2, d.rep2);
+            sv_store(st, SV_REP3, d.rep3);
+            sv_store(st, SV_LC, d.lc);
+            sv_store(st, SV_LP_MASK, d.lp_mask);
+            sv_store(st, SV_POS_MASK, d.pos_mask);
+            sv_store(st, SV_SIZE_DEFINED, d.size_defined);
+            sv_store(st, SV_BYTES_LEFT_LO, (uint32_t)d.bytes_left);
+            sv_store(st, SV_BYTES_LEFT_HI, (uint32_t)(d.bytes_left >> 32));
+            sv_store(st, SV_POS, d.pos);
+            sv_store(st, SV_WBASE, d.wbase);
+            sv_store(st, SV_WPOS, d.wpos);
+            sv_store(st, SV_PREV, d.prev_byte);
+            sv_store(st, SV_MATCH, d.match_byte);
+            sv_store(st, SV_STALE, d.stale);
+            sv_store(st, SV_CONSUMED, consumed);
+            sv_store(st, SV_CHUNK_END, d.in_base + (d.aend - d.abase));
+            sv_store(st, SV_LC_LP, w.lc_lp);
+            sv_store(st, SV_H5, w.h5);
+            sv_store(st, SV_HAVE_READER, w.have_reader ? 1u : 0u);
+            sv_store(st, SV_FIRST_CHUNK, w.first_chunk ? 1u : 0u);
+            sv_store(st, SV_PHASE, phase);
+            sv_store(st, SV_AUX, aux);
+            model_copy(st + kStateWords, reinterpret_cast<const uint32_t *>(probs), num_probs(w.lc_lp), lane);
         }
         {
-            UnitResult res; // every lane stores the same 16 bytes
+            UnitResult res; // every lane stores the same 32 bytes
             res.out_len = d.pos;
-            res.in_consumed = in_pos(d) - d.abase;
+            res.in_consumed = consumed;
             res.status = status;
-            res.aux = aux | (d.stale << 1);
+            res.aux = aux | (d.stale ? AUX_STALE : 0u) | (d.need_input ? AUX_NEED_INPUT : 0u);
+            res.t_start = t_start;
+            res.t_end = (uint32_t)wall_clock64();
             p.results[ui] = res;
         }
     }
@@ -873,10 +1123,6 @@ static uint32_t decode_per_cu(uint32_t max_lc_lp)
     uint32_t per_cu = fit;
     if (per_cu > 16) per_cu = 16;  // measured: 12..16 resident waves is the plateau
     if (per_cu > 4) per_cu &= ~3u; // equal load on the four SIMDs
-    if (const char *e = getenv("XLZ_PER_CU")) { // tuning knob
-        const uint32_t v = (uint32_t)atoi(e);
-        if (v >= 1 && v <= fit && v <= 32) per_cu = v;
-    }
     return per_cu;
 }
 

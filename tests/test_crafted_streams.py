@@ -1,0 +1,206 @@
+"""Streams no compressor writes, built packet by packet with tests/lzma_craft.py: a match as the
+very first packet (window.CheckDistance's off-by-one, window.go:89-91), rep matches and matched
+literals that read window bytes of an EARLIER dictionary epoch after an LZMA2 dictionary reset
+(window.Reset keeps the buffer, window.go:135-140), distances at the edge of the dictionary,
+maximum-length matches, truncated first chunks behind stored chunks (reader2.go:146-153).
+
+CPU: the crafter against liblzma (valid streams) and the oracle.  GPU: the HIP path against the
+oracle on bytes, status and consumed input."""
+import lzma
+import random
+
+import pytest
+
+import oracle
+from lzma_craft import (Encoder, Window, alone_header, lzma2_lzma_chunk, lzma2_stored, props_byte)
+
+
+def _random_valid_stream(seed, lc, lp, pb, dict_size, n_packets):
+    rnd = random.Random(seed)
+    e = Encoder(lc, lp, pb, dict_size)
+    for k in range(n_packets):
+        fill = len(e.w.total)
+        r = rnd.random()
+        if fill == 0 or r < 0.35:
+            e.literal(rnd.randrange(256) if rnd.random() < 0.5 else (fill * 7) & 0xFF)
+        elif r < 0.65:
+            d = rnd.choice([1, 2, 3, 5, 17, 200, 4000, fill, max(1, fill - 1), dict_size])
+            d = max(1, min(d, fill, dict_size))
+            e.match(d, rnd.choice([2, 3, 9, 10, 17, 18, 64, 65, 273]))
+        elif r < 0.8:
+            e.short_rep()
+        else:
+            e.rep(rnd.randrange(4), rnd.choice([2, 8, 9, 16, 20, 100, 273]))
+    return e
+
+
+def test_crafter_writes_valid_lzma_that_liblzma_and_the_oracle_decode():
+    for seed, (lc, lp, pb, ds) in enumerate([(3, 0, 2, 65536), (0, 0, 0, 4096), (2, 1, 1, 8192), (4, 0, 4, 1 << 20),
+                                             (0, 4, 0, 5000), (1, 1, 3, 4096)]):
+        e = _random_valid_stream(seed, lc, lp, pb, ds, 700)
+        want = bytes(e.w.total)
+        e.end_marker()
+        blob = alone_header(lc, lp, pb, ds) + e.payload()
+        if ds % 16 == 0 or len(want) <= ds:  # else the reference's wrapped posState leaves the format (parity note 1)
+            assert lzma.decompress(blob, format=lzma.FORMAT_ALONE) == want
+        got = oracle.lzma1_alone(blob, len(want) + 10)
+        if ds % 16 == 0 or len(want) <= ds:
+            assert got == (want, 0, len(blob))
+
+
+def crafted_lzma1():
+    """(name, blob, out_cap) -- LZMA1 edge cases"""
+    out = []
+    # the very first packet is a match: distance 1 at position 0 passes CheckDistance (rep0 <= pos)
+    for length in (2, 5, 64, 273):
+        e = Encoder()
+        e.match(1, length)
+        e.literal(65)
+        e.match(3, 7)
+        e.end_marker()
+        out.append(("first packet is a match of %d" % length, alone_header(3, 0, 2, 65536) + e.payload(), 1000))
+    # ... the same with a defined size and no end marker
+    e = Encoder()
+    e.match(1, 9)
+    e.literal(66)
+    out.append(("first packet match, known size", alone_header(3, 0, 2, 65536, size=10) + e.payload(), 10))
+    # first packet a match with distance 2: rejected (rep0 = 1 > pos = 0)
+    e = Encoder()
+    e.match(2, 4, copy=False)
+    out.append(("first packet distance 2", alone_header(3, 0, 2, 65536) + e.payload() + bytes(8), 100))
+    # first packet a rep match / short rep: window empty -> ErrResultError (decompress.go:690-692)
+    e = Encoder()
+    e.short_rep()
+    out.append(("short rep on an empty window", alone_header(3, 0, 2, 65536) + e.payload(), 100))
+    # distance == dictSize exactly once the window is full, and dictSize + 1 (rejected)
+    for extra in (0, 1):
+        e = Encoder(0, 0, 0, 4096)
+        for i in range(4200):
+            e.literal((i * 31) & 0xFF)
+        e.match(4096 + extra, 20, copy=(extra == 0))
+        e.literal(1)
+        e.end_marker()
+        out.append(("distance dictSize + %d" % extra, alone_header(0, 0, 0, 4096) + e.payload(), 5000))
+    # maximum-length matches and reps back to back, overlapping (distance < length)
+    e = Encoder(3, 0, 2, 1 << 16)
+    for b in b"abcdefg":
+        e.literal(b)
+    for _ in range(40):
+        e.match(7, 273)
+        e.rep(0, 273)
+        e.short_rep()
+    e.end_marker()
+    out.append(("long overlapping copies", alone_header(3, 0, 2, 1 << 16) + e.payload(), 40 * 547 + 100))
+    return out
+
+
+def crafted_lzma2():
+    """(name, blob, dict_size, out_cap) -- LZMA2 streams whose copies cross a dictionary reset"""
+    out = []
+    for name, dict_size, first_len in (("unwritten", 1 << 16, 3000), ("short epoch", 4096, 4000),
+                                       ("wrapped epoch", 4096, 10_000)):
+        w = Window(dict_size)
+        e = Encoder(3, 0, 2, dict_size, window=w)
+        # chunk A (0xE0): epoch 1 -- text, then matches that leave four distinct reps behind
+        rnd = random.Random(first_len)
+        for i in range(first_len):
+            e.literal(rnd.randrange(97, 123))
+        e.match(min(first_len, dict_size) - 1, 5)
+        e.match(77, 4)
+        e.match(min(first_len, dict_size) // 2, 6)
+        e.match(1500, 3)
+        unc_a = len(w.total)
+        blob = lzma2_lzma_chunk(0xE0, unc_a, e.payload(), props_byte(3, 0, 2))
+        # stored chunk with a dictionary reset: epoch 2 starts, only 5 bytes in it
+        w.reset()
+        for b in b"RESET":
+            w.put(b)
+        blob += lzma2_stored(b"RESET", dict_reset=True)
+        # chunk B (0x80: nothing reset): the model, the state (>= 7: the first literal is a MATCHED
+        # literal whose matchByte lies behind the reset) and the four reps live on
+        e.new_chunk()
+        start = len(w.total)
+        e.literal(0x41)
+        e.rep(0, 8)       # rep0 = 1499: far behind the 5 + 1 bytes of this epoch -> stale window bytes
+        e.literal(0x42)   # matched literal again
+        e.rep(2, 30)
+        e.short_rep()
+        e.rep(3, 273)     # long: replicates stale bytes
+        e.rep(1, 2)
+        e.match(3, 4)     # a NEW distance inside the epoch is fine
+        e.rep(1, 100)
+        blob += lzma2_lzma_chunk(0x80, len(w.total) - start, e.payload())
+        # another reset and a third epoch that reads bytes of epoch 2 AND (where epoch 2 was short) epoch 1
+        w.reset()
+        for b in b"xy":
+            w.put(b)
+        blob += lzma2_stored(b"xy", dict_reset=True)
+        e.new_chunk()
+        start = len(w.total)
+        e.rep(0, 50)
+        e.rep(2, 273)
+        e.literal(0x43)
+        blob += lzma2_lzma_chunk(0x80, len(w.total) - start, e.payload())
+        blob += b"\x00"
+        out.append((name, blob, dict_size, len(w.total) + 100, bytes(w.total)))
+    return out
+
+
+def crafted_lzma2_framing():
+    """first LZMA chunk behind stored chunks: Reader2.lzmaReader is still nil there, so an EOF inside
+    rangeDec.Init is a constructor error (reader2.go:146-153)"""
+    e = Encoder()
+    for b in b"hello hello hello":
+        e.literal(b)
+    pay = e.payload()
+    good = lzma2_lzma_chunk(0xE0, 17, pay, props_byte(3, 0, 2))
+    out = []
+    for cut in (1, 2, 4, 5, 6, 8, 9, len(good) - 1):
+        out.append(("stored, then LZMA chunk cut at %d" % cut, lzma2_stored(b"abc", True) + good[:cut], 1 << 16, 100))
+        out.append(("stored, LZMA, then LZMA chunk cut at %d" % cut, lzma2_stored(b"abc", True) + good + good[:cut], 1 << 16, 100))
+    return out
+
+
+def test_crafted_streams_cpu_expectations():
+    """the crafter's own window model agrees with the oracle on what the crafted LZMA2 streams
+    decode to (two independent restatements of window.go's uncleared Reset)"""
+    for name, blob, ds, cap, want in crafted_lzma2():
+        got = oracle.lzma2_raw(blob, ds, cap)
+        assert got[1] == 0, name
+        assert got[0] == want, name
+        # the stale bytes matter: after the reset the copies brought back lower-case text of epoch 1
+        # (a decoder that clears the window on Reset, or reads zeros there, gives other bytes)
+        tail = want[want.index(b"RESET") + 5:]
+        if name != "unwritten":  # (there the reads land where no epoch ever wrote: zeros)
+            assert sum(1 for b in tail if 97 <= b <= 122) > 100, name
+    for name, blob, cap in crafted_lzma1():
+        oracle.lzma1_alone(blob, cap)  # must not crash; statuses are compared on the GPU
+
+
+@pytest.mark.gpu
+def test_crafted_streams_on_gpu(ctx):
+    import lzma_amd
+    from lzma_amd import FMT_LZMA2_RAW, FMT_LZMA_ALONE, Stream
+    c1 = crafted_lzma1()
+    got = lzma_amd.decode_batch(ctx, [Stream(b, FMT_LZMA_ALONE, out_cap=cap) for _, b, cap in c1])
+    for (name, b, cap), g in zip(c1, got):
+        assert g == oracle.lzma1_alone(b, cap), name
+    c2 = [(n, b, ds, cap) for n, b, ds, cap, _ in crafted_lzma2()] + crafted_lzma2_framing()
+    # alone, and inside a batch next to ordinary streams (the exact re-run must not disturb them)
+    import corpus
+    p = corpus.plain("T", 77, 50_000)
+    extra = Stream(corpus.compress_raw_lzma2(p), FMT_LZMA2_RAW, out_cap=len(p), dict_size=1 << 16)
+    streams = [Stream(b, FMT_LZMA2_RAW, out_cap=cap, dict_size=ds) for _, b, ds, cap in c2]
+    got = lzma_amd.decode_batch(ctx, streams + [extra])
+    for (name, b, ds, cap), g in zip(c2, got):
+        assert g == oracle.lzma2_raw(b, ds, cap), name
+    assert got[-1][0] == p
+    # the same streams through the pull readers (session -> whole-stream fallback for the stale ones)
+    for name, b, ds, cap in c2:
+        want = oracle.lzma2_raw(b, ds, cap)
+        r, err = lzma_amd.NewReader2(ctx, b, ds)
+        if r is None:
+            continue  # constructor errors are covered by test_reader_constructor_errors
+        out, e = r.read_all(chunk=1000)
+        assert out == want[0], name
+        assert (e is None) == (want[1] >= 0), name

@@ -1,0 +1,131 @@
+"""GPU: the pull readers as resumable device sessions (include/xlz.h; reader1.go:223-254,
+window.go:97-133: memory is O(dictSize), the stream is decoded exactly once)."""
+import gc
+import hashlib
+import lzma
+import resource
+
+import pytest
+
+import corpus
+import lzma_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def _rss_mib():
+    with open("/proc/self/statm") as f:
+        return int(f.read().split()[1]) * resource.getpagesize() / (1 << 20)
+
+
+def test_256_mib_stream_through_a_4_kib_buffer_in_bounded_memory(ctx):
+    """a 256 MiB long-repeats stream of UNKNOWN size (ratio ~0.0005: the old
+    reader re-decoded such streams five times into ever larger buffers) read with 4 KiB Reads:
+    one pass over the input, no whole-stream decode, resident memory grows by < 32 MiB."""
+    size = 256 << 20
+    comp = lzma.LZMACompressor(format=lzma.FORMAT_ALONE, filters=corpus.lzma1_filters(1 << 20, preset=1))
+    h = hashlib.sha256()
+    parts = []
+    for k in range(size >> 24):  # 16 MiB at a time: the plaintext never exists as a whole
+        p = corpus.plain("Z", 5000 + k, 1 << 24)
+        h.update(p)
+        parts.append(comp.compress(p))
+        del p
+    parts.append(comp.flush())
+    blob = b"".join(parts)
+    del parts, comp
+    assert blob[5:13] == b"\xff" * 8  # size unknown, end marker
+    gc.collect()
+    r, err = lzma_amd.NewReader1(ctx, blob)
+    assert err is None
+    b, e = r.Read(4096)  # first refill: session buffers exist now
+    got = hashlib.sha256(b)
+    total = len(b)
+    rss0 = _rss_mib()
+    peak = rss0
+    n = 0
+    while e is None:
+        b, e = r.Read(4096)
+        got.update(b)
+        total += len(b)
+        n += 1
+        if n % 4096 == 0:
+            peak = max(peak, _rss_mib())
+    assert e is lzma_amd.io_EOF
+    assert total == size and got.digest() == h.digest()
+    refills, whole, uploaded = r.stats()
+    assert whole == 0                                  # never decoded as a whole stream
+    assert uploaded == len(blob) - 13                  # the input went to the device exactly once
+    assert refills <= size // (1 << 20) + 8            # about one launch per MiB, none repeated
+    assert peak - rss0 < 32, (rss0, peak)
+
+
+@pytest.mark.parametrize("case", ["lzma1-random-11MiB", "lzma2-random-9MiB", "lzma2-text-24MiB", "lzma1-far-40MiB"])
+def test_sessions_move_their_input_and_output_windows(ctx, case):
+    """streams larger than the device-side windows: the 4 MiB input window is refilled
+    (UNIT_F_MORE_INPUT: LZMA1 and LZMA2, stored chunks included) and the output window slides
+    (8 MiB dictionary, matches 6-8 MiB back must still find their source after a slide)."""
+    if case == "lzma1-random-11MiB":
+        p = corpus.plain("R", 6001, 11 << 20)
+        r, err = lzma_amd.NewReader1(ctx, corpus.compress_alone(p, dict_size=1 << 16, preset=0))
+    elif case == "lzma2-random-9MiB":
+        p = corpus.plain("R", 6002, 9 << 20)   # stored chunks only, like randomfile.dat.lzma2
+        r, err = lzma_amd.NewReader2(ctx, corpus.compress_raw_lzma2(p, dict_size=1 << 16, preset=0), 1 << 16)
+    elif case == "lzma2-text-24MiB":
+        p = corpus.plain("M", 6003, 24 << 20)  # compressed chunks and stored chunks mixed, ~16 MiB of input
+        r, err = lzma_amd.NewReader2(ctx, corpus.compress_raw_lzma2(p, dict_size=1 << 20, preset=0), 1 << 20)
+    else:
+        p = corpus.plain("F", 6004, 40 << 20)
+        r, err = lzma_amd.NewReader1(ctx, corpus.compress_alone(p, dict_size=8 << 20, lc=2, lp=1, pb=1, preset=0,
+                                                                known_size=True))
+    assert err is None
+    h = hashlib.sha256()
+    total = 0
+    sizes = [1, 4096, 100_000, 3, 1 << 20, 65537]
+    k = 0
+    while True:
+        b, e = r.Read(sizes[k % len(sizes)])
+        k += 1
+        h.update(b)
+        total += len(b)
+        if e is not None:
+            break
+    assert e is lzma_amd.io_EOF and total == len(p)
+    assert h.digest() == hashlib.sha256(p).digest()
+    refills, whole, _ = r.stats()
+    assert whole == 0 and refills >= len(p) >> 20
+
+
+def test_reader_errors_arrive_after_the_bytes_before_them(ctx):
+    """a corrupted byte deep inside a 5 MiB stream: every byte the decoder produced before the error
+    is delivered, then the error (the batch API's view of the same stream is the oracle's)"""
+    import oracle
+    p = corpus.plain("T", 6100, 5 << 20)
+    c = bytearray(corpus.compress_alone(p, preset=0))
+    c[len(c) * 3 // 4] ^= 0x40
+    c = bytes(c)
+    want = oracle.lzma1_alone(c, len(p) + 1000)
+    r, err = lzma_amd.NewReader1(ctx, c)
+    assert err is None
+    out, e = r.read_all(chunk=50_000)
+    assert out == want[0]
+    if want[1] < 0:
+        assert isinstance(e, lzma_amd.LzmaError) and e.status == want[1]
+    else:
+        assert e is None
+    # truncated input: the reference ends with a clean io.EOF (parity note 4)
+    r, err = lzma_amd.NewReader1(ctx, c[: len(c) // 3])
+    out, e = r.read_all(chunk=8191)
+    want = oracle.lzma1_alone(c[: len(c) // 3], len(p))
+    assert e is None and want[1] == lzma_amd.OK_INPUT_EOF and out == want[0]
+
+
+def test_zero_length_read_and_tiny_streams(ctx, golden):
+    exp, data = golden
+    r, err = lzma_amd.NewReader1(ctx, data["a.lzma"])
+    b, e = r.Read(0)
+    assert b == b"" and e is None            # (the reference's Read(p) with len(p) == 0 never returns)
+    out, e = r.read_all(chunk=5)
+    assert e is None and len(out) == 327
+    b, e = r.Read(0)
+    assert b == b"" and e is lzma_amd.io_EOF
