@@ -196,6 +196,28 @@ def verify_all(batch, n, osz, digests, tag):
     log("[%s] verified %d streams bit-exact (sha256 of every output byte) in %.1f s" % (tag, n, time.time() - t0))
 
 
+def occupancy(batch, kernel_ms):
+    """Slot occupancy of the persistent grid in the LAST launch, from the per-unit timestamps the
+    waves take with s_memrealtime (100 MHz): busy wave-time / (slots x launch span).  The rest is
+    tail: slots idling behind the slowest units of the last round."""
+    import numpy as np
+    t0, t1, in_len = batch.unit_trace()
+    slots, lds = batch.launch_info()
+    if len(t0) == 0 or slots == 0:
+        return None
+    dur = (t1.astype(np.int64) - t0.astype(np.int64)) / 100.0  # us
+    span = float(t1.max() - t0.min()) / 100.0
+    corr = float(np.corrcoef(in_len.astype(np.float64), dur)[0, 1]) if len(dur) > 2 and dur.std() > 0 else None
+    q = np.percentile(dur, [0, 50, 90, 99, 100]) / 1e3
+    return {"slot_occupancy": round(float(dur.sum()) / (slots * span), 4), "slots": int(slots), "lds_bytes_per_slot": int(lds),
+            "units": int(len(dur)), "rounds": round(len(dur) / slots, 2), "launch_span_ms": round(span / 1e3, 3),
+            "unit_ms": {"min": round(q[0], 3), "p50": round(q[1], 3), "p90": round(q[2], 3), "p99": round(q[3], 3),
+                        "max": round(q[4], 3)},
+            "corr_queue_key_vs_time": None if corr is None else round(corr, 3),
+            "source": "live: per-unit s_memrealtime stamps of the last timed launch (xlz_batch_unit_trace); the "
+                      "queue key is the unit's compressed size"}
+
+
 def kernel_rev():
     """Identity of the kernel sources the numbers belong to (profiles are tied to it)."""
     h = hashlib.sha1()
@@ -218,7 +240,7 @@ def profile_for(name):
     return e
 
 
-def roofline(name, cin, cout, units, kernel_ms):
+def roofline(name, cin, cout, units, kernel_ms, occ=None):
     algo = cin + cout  # per launch: compressed bytes read once + decoded bytes written once
     achieved = algo / 1e9 / (kernel_ms / 1e3)
     prof = profile_for(name)
@@ -227,11 +249,16 @@ def roofline(name, cin, cout, units, kernel_ms):
          "traffic": prof["traffic_bytes_per_launch"] if prof else None,
          "kernel": "xlz::xlz_decode_kernel", "kernel_ms": round(kernel_ms, 3),
          "algorithmic_bytes_per_launch": algo, "units_per_launch": units}
+    issue = dict(occ) if occ else {}
     if prof:
         r["traffic_from_profile"] = {"source": prof["source"], "kernel_rev": prof["kernel_rev"],
                                      "fetch": prof["fetch_bytes_per_launch_raw"], "write": prof["write_bytes_per_launch"]}
-        if "issue" in prof:
-            r["issue"] = prof["issue"]
+        if "issue" in prof:  # SQ instruction counters of the committed profile, per CU cycle
+            issue["from_profile"] = prof["issue"]
+    if issue:
+        # the kernel is bound by instruction issue, three orders of magnitude under the HBM roof
+        # (DESIGN.md section 3): this is the roofline a reader can act on
+        r["issue"] = issue
     return r
 
 
@@ -395,8 +422,9 @@ def main():
         t_local, kernel_ms = timed_steps(ctx, batch, steps, warmup, torch.cuda.synchronize, barrier if world > 1 else None)
         verify_all(batch, len(comp), osz, dig, "rank %d %s" % (rank, name))
         cin, cout, units = batch.stats()
+        occ = occupancy(batch, kernel_ms)
         batch.close()
-        return t_local, kernel_ms, cin, cout, units
+        return t_local, kernel_ms, cin, cout, units, occ
 
     def cpu_leg(name, target_s):
         if args.no_cpu_baseline:
@@ -410,7 +438,7 @@ def main():
     if world > 1:
         name = "cfg3"
         spec = specs[name]
-        t_local, kernel_ms, cin, cout, units = gpu_leg(name, args.steps, args.warmup)
+        t_local, kernel_ms, cin, cout, units, occ = gpu_leg(name, args.steps, args.warmup)
         t_max = multigpu.max_over_ranks(t_local, dist, device="cuda" if backend == "nccl" else "cpu")
         n_mine = multigpu.max_over_ranks(float(len(corp[name][0])), dist, device="cuda" if backend == "nccl" else "cpu")
         sums = torch.tensor([float(len(corp[name][0])), float(cin), float(cout)], dtype=torch.float64,
@@ -433,7 +461,7 @@ def main():
                            "compression_ratio": round(sums[1].item() / sums[2].item(), 4), "bit_exact": "all",
                            "parallelism": "one batch sharded by stream x%d (partition_by_weight), no collective" % world,
                            "n1_reference": "configs[cfg3] of the --gpus 1 line is the 1-GPU point of this curve"},
-                "roofline": dict(roofline(name, cin, cout, units, kernel_ms), note="rank 0's shard"),
+                "roofline": dict(roofline(name, cin, cout, units, kernel_ms, occ), note="rank 0's shard"),
                 "cpu_baseline": cpu,
             }
             print(json.dumps(line), flush=True)
@@ -445,7 +473,7 @@ def main():
     for name in names:
         head = name == args.headline
         steps, warmup = (args.steps, args.warmup) if head else (args.side_steps, 1)
-        t_local, kernel_ms, cin, cout, units = gpu_leg(name, steps, warmup)
+        t_local, kernel_ms, cin, cout, units, occ = gpu_leg(name, steps, warmup)
         spec = specs[name]
         n = len(corp[name][0])
         total_out = n * out_size_of(spec) * steps
@@ -454,7 +482,7 @@ def main():
             "value": round(total_out / GIB / t_local, 4), "unit": "GiB/s", "steps": steps, "warmup": warmup,
             "ms_per_step": round(t_local / steps * 1e3, 3), "kernel_ms": round(kernel_ms, 3),
             "streams": n, "bytes_per_stream": out_size_of(spec), "compression_ratio": round(cin / cout, 4),
-            "bit_exact": "all", "roofline": roofline(name, cin, cout, units, kernel_ms),
+            "bit_exact": "all", "roofline": roofline(name, cin, cout, units, kernel_ms, occ),
         }
     for name in names:  # CPU legs after all GPU work: the host cores are quiet
         head = name == args.headline

@@ -1,11 +1,17 @@
 // Package lzmagpu is the cgo shim a maintainer of kulaginds/lzma would add to route the
 // decode hot path ((*Reader1).decompress and the LZMA2 framing around it) through libxlz.so,
-// the MI355X decoder declared in include/xlz.h.  It keeps the reference's constructors
-// and the io.Reader / io.ReadCloser surface; the GPU needs a whole compressed stream, so a
-// constructor slurps its source first.
+// the MI355X decoder declared in include/xlz.h.  It keeps the reference's constructors, the
+// concrete *Reader1 / *Reader2 types with their Read / Reset / Reopen methods and the
+// io.ReadCloser of the sevenzip constructors; the device wants the compressed stream as one
+// buffer, so a constructor slurps its source first (the decoded side is streamed: a reader holds
+// one refill chunk, see include/xlz.h).
 //
-// NOT COMPILED IN THIS REPOSITORY: the build image has no Go toolchain.  The same C entry
-// points are exercised through ctypes (lzma_amd/__init__.py, tests/test_gpu_parity.py).
+// NOT COMPILED IN THIS REPOSITORY: the build image has no Go toolchain (go, gccgo: not found).
+// The same C entry points are exercised by a plain C caller (tests/c/reader_demo.c) and through
+// ctypes (lzma_amd/__init__.py, tests/).  cgo rules this file follows: no Go pointer to memory
+// that itself holds Go pointers crosses into C (arrays of descriptors are C.malloc'ed and the
+// buffers they point to are pinned with runtime.Pinner for the duration of the call); C handles
+// are released by Close or by a finalizer.
 package lzmagpu
 
 /*
@@ -20,6 +26,7 @@ import (
 	"errors"
 	"fmt"
 	"io"
+	"runtime"
 	"sync"
 	"unsafe"
 )
@@ -35,32 +42,48 @@ var (
 	ErrUnsupported            = errors.New("lzma: stream not supported by the GPU path")
 )
 
-// statusToError maps include/xlz.h status codes back onto the values the reference returns.
-func statusToError(st C.int, constructor bool) error {
+// readError maps a status of xlz_reader_read / a per-stream batch status onto the value the
+// reference's Read returns.
+func readError(st C.int) error {
 	switch st {
 	case C.XLZ_OK, C.XLZ_OK_INPUT_EOF:
 		return nil
 	case C.XLZ_EOF:
 		return io.EOF
-	case C.XLZ_ERR_RESULT:
+	case C.XLZ_ERR_RESULT, C.XLZ_ERR_RC_INIT:
 		return ErrResultError
 	case C.XLZ_ERR_PROPS:
-		if constructor {
-			return fmt.Errorf("decode prop: %w", ErrIncorrectProperties) // reader1.go:85
-		}
 		return ErrIncorrectProperties
-	case C.XLZ_ERR_HEADER_EOF:
-		return io.EOF // wrapped "decode dict size: %w" etc. by the caller's context if needed
-	case C.XLZ_ERR_RC_INIT:
-		return fmt.Errorf("rangeDec.Init: %w", ErrResultError) // reader1.go:155
+	case C.XLZ_ERR_HEADER_EOF: // "rangeDec.Init: EOF" out of a first LZMA2 chunk (reader2.go:146-153)
+		return fmt.Errorf("rangeDec.Init: %w", io.EOF)
 	case C.XLZ_ERR_UNEXPECTED_EOF:
 		return io.ErrUnexpectedEOF
 	case C.XLZ_ERR_CLOSED:
 		return errAlreadyClosed
-	case C.XLZ_ERR_NEED_ONE_READER:
-		return errNeedOneReader
-	case C.XLZ_ERR_INSUFFICIENT_PROPS:
-		return errInsufficientProperties
+	case C.XLZ_ERR_UNSUPPORTED:
+		return ErrUnsupported
+	}
+	return ErrDevice
+}
+
+// reader1CtorError reproduces the wrapping of initializeFull / initialize (reader1.go:77-159).
+// The C constructor reports WHAT failed; WHERE follows from how much of the header was there.
+func reader1CtorError(st C.int, headerBytes int) error {
+	switch st {
+	case C.XLZ_ERR_PROPS:
+		return fmt.Errorf("decode prop: %w", ErrIncorrectProperties) // reader1.go:85
+	case C.XLZ_ERR_HEADER_EOF:
+		switch {
+		case headerBytes == 0:
+			return io.EOF // the very first ReadByte fails: returned as is (reader1.go:78-81)
+		case headerBytes < 5:
+			return fmt.Errorf("decode dict size: %w", io.EOF) // reader1.go:90
+		case headerBytes < 13:
+			return fmt.Errorf("decode unpack size: %w", io.EOF) // reader1.go:97
+		}
+		return fmt.Errorf("rangeDec.Init: %w", io.EOF) // reader1.go:155
+	case C.XLZ_ERR_RC_INIT:
+		return fmt.Errorf("rangeDec.Init: %w", ErrResultError) // reader1.go:155
 	case C.XLZ_ERR_UNSUPPORTED:
 		return ErrUnsupported
 	}
@@ -77,49 +100,112 @@ func context() (*C.xlz_ctx, error) {
 	ctxOnce.Do(func() {
 		if st := C.xlz_ctx_create(0, &ctx); st != C.XLZ_OK {
 			ctxErr = ErrDevice
+			return
 		}
+		// concurrent readers (one goroutine each, as with the reference) share launches
+		C.xlz_ctx_enable_batching(ctx, 200, 4096)
 	})
 	return ctx, ctxErr
 }
 
-// reader wraps an xlz_reader handle; it is what NewReader1 / NewReader2 return.
-type reader struct {
-	h      *C.xlz_reader
-	closer io.Closer // non-nil for the sevenzip constructors (readCloser, readcloser.go:9-12)
-	wrap   bool
+// handle owns an xlz_reader; freed by Close-then-finalizer or by the finalizer alone.
+type handle struct {
+	h *C.xlz_reader
 }
 
-func (r *reader) Read(p []byte) (int, error) {
+func newHandle(h *C.xlz_reader) *handle {
+	r := &handle{h: h}
+	runtime.SetFinalizer(r, func(r *handle) { C.xlz_reader_free(r.h) })
+	return r
+}
+
+func (r *handle) read(p []byte) (int, error) {
 	if len(p) == 0 {
-		return 0, nil // the reference spins forever here (SURVEY parity note 6)
+		return 0, nil // the reference never returns from Read(p) with len(p) == 0 (SURVEY parity note 6)
 	}
 	var st C.int
+	// p is a Go slice of bytes (no pointers inside): passing &p[0] for the duration of the call is allowed
 	n := C.xlz_reader_read(r.h, (*C.uint8_t)(unsafe.Pointer(&p[0])), C.size_t(len(p)), &st)
-	err := statusToError(st, false)
-	if err != nil && err != io.EOF && r.wrap {
-		err = fmt.Errorf("lzma: error reading: %w", err) // readcloser.go:36-38
-	}
-	return int(n), err
+	runtime.KeepAlive(r)
+	return int(n), readError(st)
 }
 
-func (r *reader) Close() error {
-	if st := C.xlz_reader_close(r.h); st != C.XLZ_OK {
+// Reader1 replaces lzma.Reader1 (reader1.go:10-16).
+type Reader1 struct{ *handle }
+
+// Read is (*Reader1).Read (reader1.go:223-254).
+func (r *Reader1) Read(p []byte) (int, error) { return r.read(p) }
+
+// Reset is (*Reader1).Reset (reader1.go:161-164).
+func (r *Reader1) Reset() {
+	C.xlz_reader_reset(r.h)
+	runtime.KeepAlive(r)
+}
+
+// Reopen is (*Reader1).Reopen (reader1.go:166-176): a new raw stream on the same window and model.
+func (r *Reader1) Reopen(inStream io.ByteReader, unpackSize uint64) error {
+	data, err := slurp(inStream)
+	if err != nil {
+		return err
+	}
+	p, n := cbuf(data)
+	st := C.xlz_reader_reopen(r.h, p, n, C.uint64_t(unpackSize)) // the library copies the bytes
+	runtime.KeepAlive(data)
+	runtime.KeepAlive(r)
+	switch st {
+	case C.XLZ_OK:
+		return nil
+	case C.XLZ_ERR_HEADER_EOF:
+		return io.EOF // rangeDec.Reopen returns Init's error unwrapped (reader1.go:170-173)
+	}
+	return readError(st)
+}
+
+// Reader2 replaces lzma.Reader2 (reader2.go:10-24).
+type Reader2 struct{ *handle }
+
+// Read is (*Reader2).Read (reader2.go:216-250).
+func (r *Reader2) Read(p []byte) (int, error) { return r.read(p) }
+
+// readCloser is readcloser.go:9-41.
+type readCloser struct {
+	*handle
+	c io.Closer
+}
+
+func (rc *readCloser) Read(p []byte) (int, error) {
+	n, err := rc.read(p)
+	if err != nil && err != io.EOF && err != errAlreadyClosed {
+		err = fmt.Errorf("lzma: error reading: %w", err) // readcloser.go:36-38
+	}
+	return n, err
+}
+
+func (rc *readCloser) Close() error {
+	if st := C.xlz_reader_close(rc.h); st != C.XLZ_OK {
 		return errAlreadyClosed // readcloser.go:17-19
 	}
-	if r.closer != nil {
-		if err := r.closer.Close(); err != nil {
-			return fmt.Errorf("lzma: error closing: %w", err) // readcloser.go:21-23
-		}
+	runtime.KeepAlive(rc)
+	if err := rc.c.Close(); err != nil {
+		return fmt.Errorf("lzma: error closing: %w", err) // readcloser.go:21-23
 	}
 	return nil
 }
 
-func slurp(br io.ByteReader) []byte {
+// slurp drains a ByteReader; any error other than io.EOF is the caller's to see (the reference
+// would meet it inside Read).
+func slurp(br io.ByteReader) ([]byte, error) {
+	if r, ok := br.(io.Reader); ok { // bufio.Reader, bytes.Reader, ...
+		return io.ReadAll(r)
+	}
 	var buf []byte
 	for {
 		b, err := br.ReadByte()
+		if err == io.EOF {
+			return buf, nil
+		}
 		if err != nil {
-			return buf
+			return buf, err
 		}
 		buf = append(buf, b)
 	}
@@ -133,35 +219,51 @@ func cbuf(b []byte) (*C.uint8_t, C.size_t) {
 }
 
 // NewReader1 replaces lzma.NewReader1 (reader1.go:18-24).
-func NewReader1(inStream io.ByteReader) (io.Reader, error) {
+func NewReader1(inStream io.ByteReader) (*Reader1, error) {
 	c, err := context()
 	if err != nil {
 		return nil, err
 	}
-	data := slurp(inStream)
+	data, err := slurp(inStream)
+	if err != nil {
+		return nil, err
+	}
 	p, n := cbuf(data)
 	var st C.int
 	h := C.xlz_new_reader1(c, p, n, &st) // the library copies the bytes
+	runtime.KeepAlive(data)
 	if h == nil {
-		return nil, statusToError(st, true)
+		return nil, reader1CtorError(st, len(data))
 	}
-	return &reader{h: h}, nil
+	return &Reader1{newHandle(h)}, nil
 }
 
 // NewReader2 replaces lzma.NewReader2 (reader2.go:26-41).
-func NewReader2(inStream io.Reader, dictSize int) (io.Reader, error) {
+func NewReader2(inStream io.Reader, dictSize int) (*Reader2, error) {
 	c, err := context()
 	if err != nil {
 		return nil, err
 	}
-	data, _ := io.ReadAll(inStream)
+	data, err := io.ReadAll(inStream)
+	if err != nil {
+		return nil, err
+	}
 	p, n := cbuf(data)
 	var st C.int
 	h := C.xlz_new_reader2(c, p, n, C.int(dictSize), &st)
+	runtime.KeepAlive(data)
 	if h == nil {
-		return nil, statusToError(st, true)
+		switch st { // startChunk's errors, returned unwrapped by the constructor (reader2.go:77-86)
+		case C.XLZ_ERR_PROPS:
+			return nil, ErrIncorrectProperties
+		case C.XLZ_ERR_HEADER_EOF:
+			return nil, fmt.Errorf("rangeDec.Init: %w", io.EOF)
+		case C.XLZ_ERR_RC_INIT:
+			return nil, fmt.Errorf("rangeDec.Init: %w", ErrResultError)
+		}
+		return nil, readError(st)
 	}
-	return &reader{h: h}, nil
+	return &Reader2{newHandle(h)}, nil
 }
 
 // NewLZMADecompressorForSevenZip replaces the bodgit/sevenzip constructor of reader1.go:32-61.
@@ -180,17 +282,29 @@ func sevenzip(lzma2 bool, props []byte, unpackSize uint64, readers []io.ReadClos
 	if len(readers) != 1 {
 		return nil, errNeedOneReader
 	}
+	if lzma2 && len(props) != 1 {
+		return nil, errInsufficientProperties // reader2.go:54-56
+	}
 	c, err := context()
 	if err != nil {
 		return nil, err
 	}
-	data, _ := io.ReadAll(readers[0])
+	data, err := io.ReadAll(readers[0])
+	if err != nil {
+		return nil, err
+	}
 	dp, dn := cbuf(data)
 	pp, pn := cbuf(props)
+	// the one-element pointer and length arrays live in C memory; the buffers they point to are pinned
 	ptrs := (**C.uint8_t)(C.malloc(C.size_t(unsafe.Sizeof(dp))))
 	lens := (*C.size_t)(C.malloc(C.size_t(unsafe.Sizeof(dn))))
 	defer C.free(unsafe.Pointer(ptrs))
 	defer C.free(unsafe.Pointer(lens))
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	if dp != nil {
+		pin.Pin(dp)
+	}
 	*ptrs, *lens = dp, dn
 	var st C.int
 	var h *C.xlz_reader
@@ -199,37 +313,85 @@ func sevenzip(lzma2 bool, props []byte, unpackSize uint64, readers []io.ReadClos
 	} else {
 		h = C.xlz_new_lzma_decompressor_for_sevenzip(c, pp, pn, C.uint64_t(unpackSize), ptrs, lens, 1, &st)
 	}
+	runtime.KeepAlive(props)
 	if h == nil {
-		return nil, statusToError(st, true)
+		if lzma2 {
+			switch st {
+			case C.XLZ_ERR_PROPS:
+				return nil, ErrIncorrectProperties
+			case C.XLZ_ERR_HEADER_EOF:
+				return nil, fmt.Errorf("rangeDec.Init: %w", io.EOF)
+			case C.XLZ_ERR_RC_INIT:
+				return nil, fmt.Errorf("rangeDec.Init: %w", ErrResultError)
+			}
+			return nil, readError(st)
+		}
+		// NewLZMADecompressorForSevenZip returns DecodeProp's error unwrapped (reader1.go:37-40) and
+		// initialize's wrapped (:57-60)
+		if st == C.XLZ_ERR_PROPS {
+			return nil, ErrIncorrectProperties
+		}
+		return nil, reader1CtorError(st, 13)
 	}
-	return &reader{h: h, closer: readers[0], wrap: true}, nil
+	return &readCloser{handle: newHandle(h), c: readers[0]}, nil
 }
 
 // DecodeBatch is the new entry the reference has no analogue for: n independent .lzma
 // streams decoded concurrently on the GPU (one wave per stream).  outs[i] must have the
-// capacity of stream i's decoded size.
+// capacity of stream i's decoded size.  Returns the decoded lengths and per-stream errors.
 func DecodeBatch(streams [][]byte, outs [][]byte) ([]int, []error, error) {
 	c, err := context()
 	if err != nil {
 		return nil, nil, err
 	}
 	n := len(streams)
-	descs := make([]C.xlz_stream_desc, n)
-	results := make([]C.xlz_result, n)
-	for i := range streams {
-		descs[i].in, descs[i].in_len = cbuf(streams[i])
-		descs[i].out, descs[i].out_cap = cbuf(outs[i][:cap(outs[i])])
-		descs[i].format = C.XLZ_FMT_LZMA_ALONE
+	if n != len(outs) {
+		return nil, nil, errors.New("lzma: DecodeBatch needs one output buffer per stream")
 	}
-	// the desc array holds Go pointers: pin them for the duration of the call (runtime.Pinner, Go >= 1.21)
-	if st := C.xlz_decode_batch(c, &descs[0], C.size_t(n), &results[0]); st != C.XLZ_OK {
+	if n == 0 {
+		return nil, nil, nil
+	}
+	// descriptor and result arrays in C memory (they hold pointers); every Go buffer they point
+	// to is pinned until the call returns
+	descs := (*C.xlz_stream_desc)(C.calloc(C.size_t(n), C.size_t(unsafe.Sizeof(C.xlz_stream_desc{}))))
+	results := (*C.xlz_result)(C.calloc(C.size_t(n), C.size_t(unsafe.Sizeof(C.xlz_result{}))))
+	if descs == nil || results == nil {
+		C.free(unsafe.Pointer(descs))
+		C.free(unsafe.Pointer(results))
+		return nil, nil, ErrDevice
+	}
+	defer C.free(unsafe.Pointer(descs))
+	defer C.free(unsafe.Pointer(results))
+	dv := unsafe.Slice(descs, n)
+	rv := unsafe.Slice(results, n)
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	for i := range streams {
+		ip, il := cbuf(streams[i])
+		op, ol := cbuf(outs[i][:cap(outs[i])])
+		if ip != nil {
+			pin.Pin(ip)
+		}
+		if op != nil {
+			pin.Pin(op)
+		}
+		dv[i].in, dv[i].in_len = ip, il
+		dv[i].out, dv[i].out_cap = op, ol
+		dv[i].format = C.XLZ_FMT_LZMA_ALONE
+	}
+	if st := C.xlz_decode_batch(c, descs, C.size_t(n), results); st != C.XLZ_OK {
 		return nil, nil, ErrDevice
 	}
 	lens := make([]int, n)
 	errs := make([]error, n)
-	for i := range results {
-		lens[i] = int(results[i].out_len)
-		errs[i] = statusToError(results[i].status, false)
+	for i := range rv {
+		lens[i] = int(rv[i].out_len)
+		switch rv[i].status {
+		case C.XLZ_ERR_PROPS, C.XLZ_ERR_HEADER_EOF, C.XLZ_ERR_RC_INIT: // what NewReader1 would have returned
+			errs[i] = reader1CtorError(rv[i].status, len(streams[i]))
+		default:
+			errs[i] = readError(rv[i].status)
+		}
 	}
 	return lens, errs, nil
 }
@@ -247,7 +409,7 @@ func DecodeXZ(file []byte, verify bool) ([]byte, error) {
 	var nBlocks C.size_t
 	var total C.uint64_t
 	if st := C.xlz_xz_index(fp, fl, nil, 0, &nBlocks, &total); st != C.XLZ_OK {
-		return nil, statusToError(st, true)
+		return nil, readError(st)
 	}
 	out := make([]byte, int(total)+1)
 	op, _ := cbuf(out)
@@ -256,8 +418,10 @@ func DecodeXZ(file []byte, verify bool) ([]byte, error) {
 	if verify {
 		v = 1
 	}
-	if st := C.xlz_xz_decode(c, fp, fl, op, C.size_t(total), &outLen, v, nil); st != C.XLZ_OK {
-		return nil, statusToError(st, false)
+	st := C.xlz_xz_decode(c, fp, fl, op, C.size_t(total), &outLen, v, nil)
+	runtime.KeepAlive(file)
+	if st != C.XLZ_OK {
+		return nil, readError(st)
 	}
 	return out[:int(outLen)], nil
 }

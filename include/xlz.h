@@ -139,6 +139,8 @@ int xlz_batch_stats(xlz_batch *batch, uint64_t *in_bytes, uint64_t *out_bytes, u
  * analysis of the persistent grid (bench.py: roofline.issue.slot_occupancy).                */
 int xlz_batch_unit_trace(xlz_batch *batch, uint32_t *t_start, uint32_t *t_end, uint32_t *in_len,
                          size_t cap, size_t *n_units);
+/* shape of the decode launch: resident single-wave workgroups (= wave slots) and LDS bytes each */
+int xlz_batch_launch_info(xlz_batch *batch, uint32_t *workgroups, uint32_t *lds_bytes);
 void xlz_batch_destroy(xlz_batch *batch);
 
 /* ---- pull-style readers mirroring the reference's Go surface --------------- */
@@ -176,6 +178,13 @@ xlz_reader *xlz_new_lzma2_decompressor_for_sevenzip(xlz_ctx *ctx, const uint8_t 
  * XLZ_EOF at end of stream; a negative status on error.                          */
 #define XLZ_EOF 100
 long xlz_reader_read(xlz_reader *r, uint8_t *p, size_t n, int *err);
+/* (*Reader1).Reset (reader1.go:161-164): the probability model, state and reps start over, the window
+ * and the input position stay.  (*Reader1).Reopen (reader1.go:166-176): continue on a NEW raw LZMA
+ * stream (no header) with the given unpack size (all-ones = unknown), same window and model; its
+ * return value is rangeDec.Reopen's error (XLZ_ERR_HEADER_EOF = io.EOF, XLZ_ERR_RESULT).  Readers
+ * made by xlz_new_reader1 / ..._lzma_decompressor_for_sevenzip only.                              */
+int xlz_reader_reset(xlz_reader *r);
+int xlz_reader_reopen(xlz_reader *r, const uint8_t *in, size_t in_len, uint64_t unpack_size);
 int xlz_reader_close(xlz_reader *r); /* readCloser.Close (readcloser.go:16-28); second call ->
                                         XLZ_ERR_CLOSED; the handle stays valid until _free       */
 void xlz_reader_free(xlz_reader *r);

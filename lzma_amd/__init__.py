@@ -201,6 +201,14 @@ class Batch:
             raise LzmaError(st, "xlz_batch_stats")
         return a.value, b.value, c.value
 
+    def launch_info(self):
+        """(resident single-wave workgroups = wave slots, LDS bytes per workgroup) of the decode launch"""
+        a, b = ctypes.c_uint32(), ctypes.c_uint32()
+        st = N.lib().xlz_batch_launch_info(self._h, ctypes.byref(a), ctypes.byref(b))
+        if st != OK:
+            raise LzmaError(st, "xlz_batch_launch_info")
+        return a.value, b.value
+
     def unit_trace(self):
         """(t_start, t_end, in_len) numpy uint32 arrays, one entry per unit of the last run: ticks of
         the device's 100 MHz clock since the first unit started (xlz_batch_unit_trace)."""
@@ -324,7 +332,18 @@ class _Reader:
 
 
 class Reader1(_Reader):
-    pass
+    def Reset(self):
+        """(*Reader1).Reset (reader1.go:161-164)"""
+        st = N.lib().xlz_reader_reset(self._h)
+        if st != OK:
+            raise LzmaError(st, "Reset")
+
+    def Reopen(self, data, unpack_size=UNKNOWN_SIZE):
+        """(*Reader1).Reopen(inStream, unpackSize) (reader1.go:166-176): returns err"""
+        st = N.lib().xlz_reader_reopen(self._h, bytes(data), len(data), unpack_size)
+        if st == ERR_HEADER_EOF:
+            return io_EOF
+        return None if st == OK else LzmaError(st)
 
 
 class Reader2(_Reader):

@@ -42,7 +42,7 @@ EXPORTS = [
     "xlz_batch_stats", "xlz_batch_destroy", "xlz_new_reader1", "xlz_new_reader2",
     "xlz_new_lzma_decompressor_for_sevenzip", "xlz_new_lzma2_decompressor_for_sevenzip",
     "xlz_reader_read", "xlz_reader_close", "xlz_reader_free", "xlz_xz_index", "xlz_xz_decode",
-    "xlz_decode_batch_multi", "xlz_batch_unit_trace", "xlz_reader_stats",
+    "xlz_decode_batch_multi", "xlz_batch_unit_trace", "xlz_reader_stats", "xlz_batch_launch_info", "xlz_reader_reset", "xlz_reader_reopen",
 ]
 
 
@@ -138,7 +138,10 @@ def lib():
     L.xlz_reader_close.argtypes = [vp]
     L.xlz_reader_free.argtypes = [vp]
     L.xlz_reader_free.restype = None
+    L.xlz_reader_reset.argtypes = [vp]
+    L.xlz_reader_reopen.argtypes = [vp, ctypes.c_char_p, sz, ctypes.c_uint64]
     L.xlz_reader_stats.argtypes = [vp] + [ctypes.POINTER(ctypes.c_uint64)] * 3
+    L.xlz_batch_launch_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     L.xlz_batch_unit_trace.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]
     L.xlz_decode_batch_multi.argtypes = [ctypes.POINTER(vp), sz, ctypes.POINTER(StreamDesc), sz, ctypes.POINTER(Result)]
     L.xlz_xz_index.argtypes = [vp, sz, ctypes.POINTER(XzBlock), sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint64)]

@@ -58,8 +58,11 @@ enum : uint32_t {
     UNIT_F_BIG_MODEL = 4,   // model does not fit LDS: decoded by the HBM-model launch
     UNIT_F_RESUME = 8,      // continue from the UnitState saved by an earlier launch (pull readers)
     UNIT_F_MORE_INPUT = 16, // in_len is a window of a longer input: pause (not EOF) when it runs low
-    UNIT_F_NOT_FIRST = 32   // LZMA2: earlier units of the stream precede this one (their bytes may be read as
+    UNIT_F_NOT_FIRST = 32,  // LZMA2: earlier units of the stream precede this one (their bytes may be read as
                             // stale window content, window.go:135-140)
+    UNIT_F_RESET_MODEL = 64, // UNIT_F_RESUME + (*Reader1).Reset (reader1.go:161-164): state.Reset before continuing
+    UNIT_F_REOPEN = 128      // UNIT_F_RESUME + (*Reader1).Reopen (reader1.go:166-176): the input is a NEW stream
+                             // (range coder re-initialised, unpack_size applies), window and model live on
 };
 
 struct Unit {

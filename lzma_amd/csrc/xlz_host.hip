@@ -881,6 +881,15 @@ extern "C" int xlz_batch_unit_trace(xlz_batch *b, uint32_t *t_start, uint32_t *t
     return XLZ_OK;
 }
 
+extern "C" int xlz_batch_launch_info(xlz_batch *b, uint32_t *workgroups, uint32_t *lds_bytes)
+{
+    if (!b) return XLZ_ERR_BAD_ARG;
+    const uint32_t grid = std::min<uint32_t>(b->n_normal, decode_grid(b->max_lc_lp, b->ctx->num_cus));
+    if (workgroups) *workgroups = grid;
+    if (lds_bytes) *lds_bytes = decode_lds_bytes(b->max_lc_lp);
+    return XLZ_OK;
+}
+
 extern "C" int xlz_batch_device_output(xlz_batch *b, size_t i, void **dptr, size_t *cap)
 {
     if (!b || i >= b->n || !dptr) return XLZ_ERR_BAD_ARG;
@@ -1135,6 +1144,7 @@ struct xlz_reader {
     // batching: refills of concurrent readers are decoded by the context's batcher thread in one launch
     bool refill_pending = false;
     uint64_t n_refills = 0, n_whole = 0;
+    bool pending_reset = false, pending_reopen = false; // (*Reader1).Reset / Reopen before the next refill
 };
 
 // Background coalescer of readers (one per context).
@@ -1299,6 +1309,9 @@ int session_prepare(xlz_reader *r, hipStream_t stream)
     u.rebase = ss->rebase;
     u.state = (uint64_t)(ss->d_ctl + ss->off_state);
     u.flags = UNIT_F_LAST | (ss->started ? UNIT_F_RESUME : 0u) | (ss->in_loaded < total ? UNIT_F_MORE_INPUT : 0u);
+    if (ss->started && r->pending_reset) u.flags |= UNIT_F_RESET_MODEL; // before the first launch the model is fresh anyway
+    if (ss->started && r->pending_reopen) u.flags |= UNIT_F_REOPEN;
+    r->pending_reset = r->pending_reopen = false;
     return XLZ_OK;
 }
 
@@ -1686,6 +1699,63 @@ extern "C" void xlz_reader_free(xlz_reader *r)
     if (!r) return;
     reader_release_device(r);
     delete r;
+}
+
+// (*Reader1).Reset, reader1.go:161-164: state.Reset (every probability back to 1024, state and reps
+// to 0) and isEndOfStream = false; window, range coder and input stay.
+extern "C" int xlz_reader_reset(xlz_reader *r)
+{
+    if (!r) return XLZ_ERR_BAD_ARG;
+    if (r->closed) return XLZ_ERR_CLOSED;
+    if (r->desc.format == XLZ_FMT_LZMA2_RAW || r->whole) return XLZ_ERR_UNSUPPORTED; // a Reader1 method
+    r->pending_reset = true;
+    r->finished = false;
+    return XLZ_OK;
+}
+
+// (*Reader1).Reopen, reader1.go:166-176: a NEW compressed stream (raw: no header) continues on the
+// same window and model: SetUnpackSize, then rangeDec.Reopen -> Init on the new source, whose
+// error is returned as is (io.EOF -> XLZ_ERR_HEADER_EOF, first byte != 0 -> XLZ_ERR_RESULT).
+extern "C" int xlz_reader_reopen(xlz_reader *r, const uint8_t *in, size_t in_len, uint64_t unpack_size)
+{
+    if (!r || (!in && in_len)) return XLZ_ERR_BAD_ARG;
+    if (r->closed) return XLZ_ERR_CLOSED;
+    if (r->desc.format == XLZ_FMT_LZMA2_RAW || r->whole) return XLZ_ERR_UNSUPPORTED;
+    if (!r->ss) { // not started yet: open the session on the current stream's parameters first
+        std::lock_guard<std::mutex> lock(r->ctx->mu);
+        HIP_TRY(hipSetDevice(r->ctx->device));
+        int st = session_open(r);
+        if (st != XLZ_OK) return st;
+    }
+    const int e = check_rc_init(in, in_len);
+    r->in.assign(in, in + in_len);
+    Session *ss = r->ss;
+    ss->payload_off = 0;
+    ss->in_skip = ss->in_loaded = ss->consumed = 0;
+    ss->unit.unpack_size = unpack_size;
+    // a known size no longer bounds the window: the new stream appends to it
+    ss->win_max = 2 * (size_t)ss->unit.dict_size + kChunk + kWinSlack;
+    if (ss->in_buf < kInBuf) { // the input window was sized for the first stream
+        uint8_t *nc = nullptr;
+        std::lock_guard<std::mutex> lock(r->ctx->mu);
+        HIP_TRY(hipSetDevice(r->ctx->device));
+        HIP_TRY(hipMalloc(&nc, ss->off_in + kInBuf));
+        if (hipMemcpy(nc, ss->d_ctl, ss->off_in, hipMemcpyDeviceToDevice) != hipSuccess) {
+            (void)hipFree(nc);
+            return XLZ_ERR_DEVICE;
+        }
+        (void)hipFree(ss->d_ctl);
+        ss->d_ctl = nc;
+        ss->in_buf = kInBuf;
+    }
+    if (ss->started) {
+        r->pending_reopen = true;
+    } else { // nothing decoded yet: the first launch simply starts on the new stream
+        ss->unit.kind = UNIT_LZMA1;
+    }
+    r->finished = false;
+    r->status = XLZ_OK;
+    return e == XLZ_ERR_RC_INIT ? XLZ_ERR_RESULT : e;
 }
 
 extern "C" int xlz_reader_stats(const xlz_reader *r, uint64_t *refills, uint64_t *whole_decodes, uint64_t *in_uploaded)

@@ -584,6 +584,10 @@ static_assert(P_IS_MATCH == 0 && P_IS_REP == 192 && P_IS_REP_G0 == 204 && P_IS_R
 
 enum : uint32_t { FX_LIMIT = 0, FX_ERR = 1, FX_MARKER = 2, FX_COPY = 3 };
 
+#ifndef XLZ_FASTPATH_INC // A/B builds of generator variants (tools/gen_fastpath.py --variant ... --out ...)
+#define XLZ_FASTPATH_INC "xlz_fastpath.inc"
+#endif
+
 // Per-lane constants of the head gather: lane j fetches the j-th context-selected probability a
 // packet can start with; its LDS byte address is hc + state * hms + state2 * hm2.
 struct HeadVec {
@@ -620,7 +624,7 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_
     asm volatile("v_mov_b32 %0, %1" : "=v"(vlpm) : "s"(d.lp_mask));
     asm volatile("v_mov_b32 %0, %1" : "=v"(vpm) : "s"(d.pos_mask));
     asm volatile(
-#include "xlz_fastpath.inc"
+#include XLZ_FASTPATH_INC
         : [range] "+s"(d.range), [code] "+s"(d.code), [cur] "+s"(d.cur), [arel] "+s"(d.arel), [state] "+s"(d.state),
           [rep0] "+s"(d.rep0), [rep1] "+s"(d.rep1), [rep2] "+s"(d.rep2), [rep3] "+s"(d.rep3), [pos] "+s"(d.pos),
           [wpos] "+s"(d.wpos), [prev] "+s"(d.prev_byte), [mb] "+s"(d.match_byte), [exitc] "=&s"(exitc),
@@ -629,7 +633,7 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_
           [lc] "s"(d.lc), [lc8] "s"(8u - d.lc), [wbase] "s"(d.wbase), [outp] "s"(out), [mptr] "s"(mprobs),
           [vin] "v"(d.vin), [vlane] "v"(lane), [vhc] "v"(hv.hc), [vhms] "v"(hv.hms), [vhm2] "v"(hv.hm2),
           [vlitnext] "v"(hv.lit_next), [vlpm] "v"(vlpm), [vpm] "v"(vpm)
-        : "scc", "vcc", "memory", "s76", "s77", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
+        : "scc", "vcc", "memory", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
           "s93", "s94", "s95", "s96", "s97", "s98", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46",
           "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62",
           "v63");
@@ -995,11 +999,18 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
             phase = RFL(st[SV_PHASE]);
             aux = RFL(st[SV_AUX]);
             // input: continue at the saved position inside the (possibly moved) input window
-            const uint32_t consumed = RFL(st[SV_CONSUMED]);
+            // ((*Reader1).Reopen: the input is a new stream, read from its first byte)
+            const uint32_t consumed = (flags & UNIT_F_REOPEN) ? d.in_base : RFL(st[SV_CONSUMED]);
             in_window(d, d.abase + (consumed - d.in_base), lane);
             // inside an LZMA2 chunk the limitedByteReader's end stays where the chunk header put it
             d.aend = (lzma2 && phase == PH_CHUNK) ? min(d.abase + (RFL(st[SV_CHUNK_END]) - d.in_base), w.unit_end) : w.unit_end;
             model_copy(reinterpret_cast<uint32_t *>(probs), st + kStateWords, num_probs(w.lc_lp), lane);
+            if (flags & UNIT_F_RESET_MODEL) state_reset(d, probs, mprobs, w.lc_lp, lane); // (*Reader1).Reset
+            if (flags & UNIT_F_REOPEN) { // (*Reader1).Reopen: SetUnpackSize, then rangeDec.Reopen on the new input
+                set_unpack_size(d, unpack);
+                d.aend = w.unit_end;
+                phase = PH_NEXT;
+            }
         } else {
             d.lc = lc;
             d.lp_mask = (1u << lp) - 1;
@@ -1058,7 +1069,7 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
             phase = PH_NEXT;
         }
         const uint32_t consumed = d.in_base + (in_pos(d) - d.abase);
-        if (status == ST_PAUSED) { // every lane stores the same words
+        if (st) { // a resumable unit keeps its state whatever ended the launch (Reopen continues after an end too)
             sv_store(st, SV_RANGE, d.range);
             sv_store(st, SV_CODE, d.code);
             sv_store(st, SV_STATE, d.state);

@@ -129,3 +129,50 @@ def test_zero_length_read_and_tiny_streams(ctx, golden):
     assert e is None and len(out) == 327
     b, e = r.Read(0)
     assert b == b"" and e is lzma_amd.io_EOF
+
+
+def test_reader1_reset_and_reopen(ctx):
+    """(*Reader1).Reset / Reopen (reader1.go:161-176) are what Reader2 does between LZMA2 chunks
+    (reader2.go:155-167): so a raw stream A, then Reopen(B) [with or without Reset], must give the
+    bytes of the LZMA2 stream  E0(A) 80(B)  /  E0(A) A0(B)  -- decoded by the oracle."""
+    import random
+    import struct
+    import oracle
+    from lzma_craft import Encoder, Window, lzma2_lzma_chunk, props_byte
+    for with_reset in (False, True):
+        rnd = random.Random(11 + with_reset)
+        ds = 1 << 16
+        w = Window(ds)
+        e = Encoder(3, 0, 2, ds, window=w)
+        for i in range(3000):
+            e.literal(rnd.randrange(97, 110))
+        for _ in range(200):
+            e.match(rnd.randrange(1, 2500), rnd.choice([2, 5, 30, 273]))
+            e.literal(rnd.randrange(97, 110))
+        pay_a, n_a = e.payload(), len(w.total)
+        e.new_chunk()
+        if with_reset:
+            e.reset_state()
+        for _ in range(300):   # B's matches reach back into A's bytes: the window lives on
+            e.match(rnd.randrange(1, n_a), rnd.choice([2, 9, 64, 200]))
+            if not with_reset:
+                e.rep(rnd.randrange(4), rnd.choice([2, 17]))
+            e.literal(rnd.randrange(65, 90))
+        pay_b, n_b = e.payload(), len(w.total) - n_a
+        framed = lzma2_lzma_chunk(0xE0, n_a, pay_a, props_byte(3, 0, 2)) + \
+            lzma2_lzma_chunk(0xA0 if with_reset else 0x80, n_b, pay_b) + b"\x00"
+        want = oracle.lzma2_raw(framed, ds, n_a + n_b)
+        assert want[1] == 0 and want[0] == bytes(w.total)
+        r, err = lzma_amd.NewLZMADecompressorForSevenZip(ctx, bytes([props_byte(3, 0, 2)]) + struct.pack("<I", ds), n_a,
+                                                         [pay_a])
+        assert err is None
+        r.__class__ = lzma_amd.Reader1  # the Go shim returns *Reader1 from NewReader1; same handle type here
+        out_a, e1 = r.read_all(chunk=777)
+        assert e1 is None and out_a == want[0][:n_a]
+        if with_reset:
+            r.Reset()
+        assert r.Reopen(pay_b, n_b) is None
+        out_b, e2 = r.read_all(chunk=4096)
+        assert e2 is None and out_b == want[0][n_a:]
+        assert r.Reopen(b"", 5) is lzma_amd.io_EOF                       # rangeDec.Reopen -> Init: io.EOF, unwrapped
+        assert r.Reopen(b"\x01\0\0\0\0", 5).status == lzma_amd.ERR_RESULT  # first byte != 0: ErrResultError

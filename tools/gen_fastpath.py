@@ -57,6 +57,7 @@ LEN_CHOICE, LEN_CHOICE2, LEN_LOW, LEN_MID, LEN_HIGH = 0, 1, 4, 132, 260
 # head gather lanes (the per-lane address constants are built in xlz_kernel.hip: head_vectors)
 H_IS_MATCH, H_IS_REP, H_G0, H_G1, H_G2, H_REP0_LONG, H_LEN_C, H_LEN_C2, H_REP_C, H_REP_C2 = range(10)
 
+VARIANT = set()  # experimental code paths switched on from the command line (A/B builds)
 lines = []
 stubs = []
 finish_sites = []
@@ -101,7 +102,7 @@ def decide():
     """)
 
 
-def nchk(prefix=None, pick=None, mid=None):
+def nchk(prefix=None, pick=None, mid=None, late_test=False):
     """normalisation test; the stub is emitted out of line at the end of the block.
     prefix / pick: functions that emit the first instructions of the NEXT decision -- the
     range-only VALU product (bounds) and the lane read of its bound.  They are hoisted in front of
@@ -113,9 +114,13 @@ def nchk(prefix=None, pick=None, mid=None):
     if prefix:
         label(k + "b")
         prefix()
-        emit("s_lshr_b32 s81, %[range], 24")
-        if pick:
+        if late_test:  # the pick itself uses SCC (level 7 of an 8-level tree: block 2 or 3): test after it
             pick()
+            emit("s_lshr_b32 s81, %[range], 24")
+        else:
+            emit("s_lshr_b32 s81, %[range], 24")
+            if pick:
+                pick()
         emit("s_cbranch_scc0 %s" % L(k))
     else:
         emit("s_lshr_b32 s80, %[range], 24")
@@ -336,6 +341,59 @@ def walk_rec(nbits, blocks, entries=None):
             fetch_level(k + 1, blocks)
 
 
+def walk8(blocks, entries=None):
+    """8-level walk with the bounds from a VALU product (as walk()): nothing is recorded, a level is
+    6 scalar instructions + one lane read instead of 8 + 2.  gather8() finds the eight probabilities
+    again for the update.  entries = label prefix: <prefix>k enters at level k >= 1 with s88 set."""
+    if not entries:
+        level_prefix(0, blocks)
+        emit("s_mov_b32 s88, 1")
+        emit("v_readlane_b32 s80, v55, 1")
+    for k in range(8):
+        if entries:
+            if k == 0:
+                continue
+            label("%sd%d" % (entries, k))
+        decide()
+        emit("s_addc_u32 s88, s88, s88")
+        if k + 1 < 8:
+            nchk(prefix=lambda: level_prefix(k + 1, blocks), pick=lambda: level_pick(k + 1), late_test=(k + 1 == 7))
+        else:
+            nchk()
+    if entries:  # out of line: the bound of the level entered at, then into the chain
+        deferred.append(lambda: walk8_entries(blocks, entries))
+
+
+def walk8_entries(blocks, entries):
+    for k in range(1, 8):
+        label("%s%d" % (entries, k))
+        level_prefix(k, blocks)
+        emit("s_nop 0")
+        level_pick(k)
+        emit("s_branch %s" % L("%sd%d" % (entries, k)))
+
+
+def gather8(blocks, dst="v54"):
+    """the eight probabilities a finished 8-level walk met -> lanes 0..7 of dst (lane k = level k):
+    slot_k = s88 >> (8 - k) lives in block slot_k >> 6 at lane slot_k & 63; one ds_bpermute per block
+    (its lane select wraps mod 64), then lane 6 takes block 1 and lane 7 block 2 or 3."""
+    emit("""
+    v_lshrrev_b32 v60, v19, s88
+    v_lshlrev_b32 v61, 2, v60
+    ds_bpermute_b32 v62, v61, %s
+    ds_bpermute_b32 v63, v61, %s
+    ds_bpermute_b32 v28, v61, %s
+    ds_bpermute_b32 v34, v61, %s
+    s_bitcmp1_b32 s88, 7
+    s_cselect_b64 vcc, -1, 0
+    s_waitcnt lgkmcnt(0)
+    v_cndmask_b32 %s, v62, v63, s[78:79]
+    v_cndmask_b32 v28, v28, v34, vcc
+    v_cmp_eq_u32 vcc, 7, %%[vlane]
+    v_cndmask_b32 %s, %s, v28, vcc
+    """ % (blocks[0], blocks[1], blocks[2], blocks[3], dst, dst, dst))
+
+
 def tree_update_rec(nb, base, store=True):
     """model updates of a walk_rec in ONE vector operation, lane k = level k: slot = s88 >> (8-k),
     !bit = (s88 >> (7-k)) & 1, p = v54; lanes >= 8 store to the unused slot (v38).  The per-lane
@@ -500,8 +558,13 @@ def literal_tail():
 
 def plain_literal():
     """plain literal (:127-175) with its blocks in v50..v53 and base in v39; ends at pktl"""
-    walk_rec(8, LIT_BLOCKS)
-    literal_tail()
+    if "lit8" in VARIANT:
+        walk8(LIT_BLOCKS)
+        literal_tail()
+        gather8(LIT_BLOCKS)
+    else:
+        walk_rec(8, LIT_BLOCKS)
+        literal_tail()
     tree_update_rec(8, "v39")
     literal_context(prev_v="v32")
     emit("s_branch %s" % L("pktl"))
@@ -586,9 +649,15 @@ def sec_packet_general():
     for k in range(1, 8):
         label("mx%d" % k)
         emit("s_mov_b32 s98, %d\ns_branch %s" % (k, L("pw%d" % k)))
-    walk_rec(8, LIT_BLOCKS, entries="pw")
+    if "lit8" in VARIANT:
+        walk8(LIT_BLOCKS, entries="pw")
+    else:
+        walk_rec(8, LIT_BLOCKS, entries="pw")
     label("mlfin")
     literal_tail()
+    if "lit8" in VARIANT:  # levels decided in the plain table: their probabilities, gathered; v54 keeps the matched ones
+        gather8(LIT_BLOCKS, dst="v33")
+        emit("v_cmp_gt_u32 vcc, s98, %[vlane]\nv_cndmask_b32 v54, v33, v54, vcc")
     # lanes < s98 -> matched table (HBM; the rest to its unused slot 0), lanes s98..7 -> plain table
     emit("v_cmp_gt_u32 vcc, s98, %[vlane]")
     tree_update_rec(8, "v39", store=False)
@@ -765,10 +834,17 @@ def sec_copy():
     s_cbranch_scc0 %s
     """ % L("x3"))
     need_copy_done(inline=True)  # the new source may overlap the bytes the pending copy still has to store
+    emit("v_add_u32 v48, %[pos], %[vlane]\nv_subrev_u32 v61, s93, v48")
+    if "cmask" in VARIANT:  # only lanes 0..len fetch (byte len is the next matchByte): fewer sectors touched
+        emit("""
+        s_sub_u32 s80, 63, s89
+        s_lshr_b64 exec, -1, s80
+        global_load_ubyte v49, v61, %[outp]
+        s_mov_b64 exec, -1
+        """)
+    else:
+        emit("global_load_ubyte v49, v61, %[outp]")
     emit("""
-    v_add_u32 v48, %[pos], %[vlane]
-    v_subrev_u32 v61, s93, v48
-    global_load_ubyte v49, v61, %[outp]
     s_mov_b32 s94, 1
     s_mov_b32 s95, s89
     s_add_u32 %[pos], %[pos], s89
@@ -827,6 +903,8 @@ def gen():
     """)
     # constants of tree_update_rec
     emit("v_sub_u32 v19, 8, %[vlane]\nv_sub_u32 v18, 7, %[vlane]\nv_cmp_gt_u32 s[76:77], 8, %[vlane]")
+    if "lit8" in VARIANT:
+        emit("v_cmp_eq_u32 s[78:79], 6, %[vlane]")  # gather8: lane 6 takes block 1
     # v21, lane = raw length 0..7: byte address of posSlot[min(len, 3)]; v20, lane = state:
     # stateUpdateMatch (state.go:165-171)
     emit("""
@@ -873,6 +951,11 @@ def render():
 
 
 if __name__ == "__main__":
+    # dev: --variant a,b selects experimental code paths (VARIANT), --out writes another .inc for an A/B build
+    if "--variant" in sys.argv:
+        VARIANT.update(v for v in sys.argv[sys.argv.index("--variant") + 1].split(",") if v)
+    if "--out" in sys.argv:
+        OUT = sys.argv[sys.argv.index("--out") + 1]
     text, final, n_nops = render()
     with open(OUT, "w") as f:
         f.write(text)
