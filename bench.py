@@ -340,6 +340,8 @@ def main():
                     help="N=1: comma list of side configs to run (%s), 'all' or 'none'" % ",".join(SIDE))
     ap.add_argument("--headline", default="cfg2-T", choices=list(CONFIGS), help="N=1: the config reported as `value`")
     ap.add_argument("--scale", type=float, default=1.0, help="dev runs: multiply every config's stream count")
+    ap.add_argument("--trace-out", default="", help="dev: save the per-unit (t_start, t_end, in_len) stamps of every config "
+                                                     "as <prefix><config>.npz")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=12.0)
     ap.add_argument("--side-cpu-target-s", type=float, default=4.0)
@@ -423,6 +425,10 @@ def main():
         verify_all(batch, len(comp), osz, dig, "rank %d %s" % (rank, name))
         cin, cout, units = batch.stats()
         occ = occupancy(batch, kernel_ms)
+        if args.trace_out:
+            import numpy as np
+            t0_, t1_, il_ = batch.unit_trace()
+            np.savez_compressed(args.trace_out + name + ".npz", t_start=t0_, t_end=t1_, in_len=il_)
         batch.close()
         return t_local, kernel_ms, cin, cout, units, occ
 

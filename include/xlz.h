@@ -220,10 +220,50 @@ typedef struct xlz_xz_block {
 int xlz_xz_index(const uint8_t *file, size_t len, xlz_xz_block *blocks, size_t max_blocks,
                  size_t *n_blocks, uint64_t *total_uncompressed);
 /* Decode a whole .xz file into out as ONE GPU batch.  verify != 0: check every block's CRC32 /
- * CRC64 on the host; *unverified (optional) = number of blocks whose check type is not
- * implemented (SHA-256).  A failed check or a block that does not match the index:
+ * CRC64 / SHA-256 on the host; *unverified (optional) = number of blocks whose check type is a
+ * reserved one.  A failed check or a block that does not match the index:
  * XLZ_ERR_RESULT.                                                                             */
 int xlz_xz_decode(xlz_ctx *ctx, const uint8_t *file, size_t len, uint8_t *out, size_t out_cap,
+                  uint64_t *out_len, int verify, size_t *unverified);
+
+/* ---- .7z container front-end ----------------------------
+ * Outside the reference, which only offers the two bodgit/sevenzip decompressor constructors
+ * (reader1.go:28-61 method 03 01 01, reader2.go:45-75 method 21).  A .7z archive keeps its data in
+ * folders, each ONE compressed stream with out-of-band properties -- exactly what those
+ * constructors take -- and folders are independent, so an archive is one batch.  Folders with a
+ * single LZMA, LZMA2 or Copy coder are decoded; coder chains (BCJ + LZMA ...), encryption and
+ * external / multi-volume layouts are reported as unsupported.  File names are not parsed: the
+ * output is the folders' bytes back to back = the archive's files back to back.                */
+enum { XLZ_7Z_UNSUPPORTED = 0, XLZ_7Z_LZMA = 1, XLZ_7Z_LZMA2 = 2, XLZ_7Z_COPY = 3 };
+typedef struct xlz_7z_folder {
+    uint64_t pack_off;   /* the folder's packed stream inside the file                           */
+    uint64_t pack_len;
+    uint64_t unpack_off; /* where its bytes go in the decoded output                             */
+    uint64_t unpack_len;
+    uint32_t method;     /* XLZ_7Z_*                                                             */
+    uint32_t dict_size;  /* LZMA: LE32 of props[1:5]; LZMA2: DecodeDictSize2(props[0])           */
+    uint32_t crc;        /* CRC32 of the folder's output when has_crc                            */
+    uint32_t first_substream, n_substreams; /* its files in the substream array                  */
+    uint8_t props;       /* LZMA: the lc/lp/pb byte; LZMA2: the dictionary byte                  */
+    uint8_t has_crc;
+    uint8_t reserved[2];
+} xlz_7z_folder;
+typedef struct xlz_7z_substream { /* one file's bytes inside a (solid) folder                    */
+    uint64_t size;
+    uint32_t crc;
+    uint32_t has_crc;
+} xlz_7z_substream;
+/* Folder list of a .7z archive.  An encoded (compressed) header -- what 7-Zip writes by default --
+ * is itself an LZMA folder and is decoded on the GPU first: ctx may be NULL only for archives with a
+ * plain header.  Arrays may be NULL with capacity 0 to obtain the counts; XLZ_ERR_OUT_CAP when a
+ * non-zero capacity is too small (the counts are still set).                                      */
+int xlz_7z_index(xlz_ctx *ctx, const uint8_t *file, size_t len, xlz_7z_folder *folders,
+                 size_t max_folders, size_t *n_folders, xlz_7z_substream *substreams,
+                 size_t max_substreams, size_t *n_substreams, uint64_t *total_unpacked);
+/* Decode every folder of a .7z archive into out as ONE GPU batch.  verify != 0: CRC32 of every file
+ * (or folder) that carries one; *unverified (optional) = folders without any CRC.  XLZ_ERR_UNSUPPORTED
+ * when a folder's coder chain is not a single LZMA / LZMA2 / Copy coder.                         */
+int xlz_7z_decode(xlz_ctx *ctx, const uint8_t *file, size_t len, uint8_t *out, size_t out_cap,
                   uint64_t *out_len, int verify, size_t *unverified);
 
 #ifdef __cplusplus

@@ -425,3 +425,39 @@ def xz_decode(ctx, data, verify=True):
     if st != OK:
         raise LzmaError(st, "xlz_xz_decode")
     return out.raw[: out_len.value]
+
+
+# ---- .7z container front-end (include/xlz.h: xlz_7z_index / xlz_7z_decode) -------------------
+def sevenzip_index(data, ctx=None):
+    """Folder list of a .7z archive: (list of folder dicts, list of (size, crc or None) per file, total
+    decoded size).  ctx is needed when the archive's header is itself compressed (7-Zip's default)."""
+    buf = ctypes.create_string_buffer(data, len(data)) if len(data) else ctypes.create_string_buffer(1)
+    h = ctx._h if ctx is not None else None
+    nf, ns, total = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_uint64()
+    st = N.lib().xlz_7z_index(h, ctypes.cast(buf, ctypes.c_void_p), len(data), None, 0, ctypes.byref(nf), None, 0,
+                              ctypes.byref(ns), ctypes.byref(total))
+    if st != OK:
+        raise LzmaError(st, "xlz_7z_index")
+    fo = (N.SzFolder * max(nf.value, 1))()
+    su = (N.SzSubstream * max(ns.value, 1))()
+    st = N.lib().xlz_7z_index(h, ctypes.cast(buf, ctypes.c_void_p), len(data), fo, nf.value, ctypes.byref(nf), su, ns.value,
+                              ctypes.byref(ns), ctypes.byref(total))
+    if st != OK:
+        raise LzmaError(st, "xlz_7z_index")
+    fields = [f for f, _ in N.SzFolder._fields_ if f != "reserved"]
+    return ([{f: getattr(fo[i], f) for f in fields} for i in range(nf.value)],
+            [(su[i].size, su[i].crc if su[i].has_crc else None) for i in range(ns.value)], total.value)
+
+
+def sevenzip_decode(ctx, data, verify=True):
+    """Decode every folder of a .7z archive as one GPU batch -> the files' bytes back to back."""
+    _, _, total = sevenzip_index(data, ctx)
+    buf = ctypes.create_string_buffer(data, len(data))
+    out = ctypes.create_string_buffer(max(total, 1))
+    out_len = ctypes.c_uint64()
+    unverified = ctypes.c_size_t()
+    st = N.lib().xlz_7z_decode(ctx._h, ctypes.cast(buf, ctypes.c_void_p), len(data), ctypes.cast(out, ctypes.c_void_p),
+                               total, ctypes.byref(out_len), 1 if verify else 0, ctypes.byref(unverified))
+    if st != OK:
+        raise LzmaError(st, "xlz_7z_decode")
+    return out.raw[: out_len.value]

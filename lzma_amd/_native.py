@@ -42,7 +42,7 @@ EXPORTS = [
     "xlz_batch_stats", "xlz_batch_destroy", "xlz_new_reader1", "xlz_new_reader2",
     "xlz_new_lzma_decompressor_for_sevenzip", "xlz_new_lzma2_decompressor_for_sevenzip",
     "xlz_reader_read", "xlz_reader_close", "xlz_reader_free", "xlz_xz_index", "xlz_xz_decode",
-    "xlz_decode_batch_multi", "xlz_batch_unit_trace", "xlz_reader_stats", "xlz_batch_launch_info", "xlz_reader_reset", "xlz_reader_reopen",
+    "xlz_decode_batch_multi", "xlz_batch_unit_trace", "xlz_reader_stats", "xlz_batch_launch_info", "xlz_reader_reset", "xlz_reader_reopen", "xlz_7z_index", "xlz_7z_decode",
 ]
 
 
@@ -79,6 +79,27 @@ class XzBlock(ctypes.Structure):
         ("dict_size", ctypes.c_uint32),
         ("check_type", ctypes.c_uint32),
     ]
+
+
+class SzFolder(ctypes.Structure):
+    _fields_ = [
+        ("pack_off", ctypes.c_uint64),
+        ("pack_len", ctypes.c_uint64),
+        ("unpack_off", ctypes.c_uint64),
+        ("unpack_len", ctypes.c_uint64),
+        ("method", ctypes.c_uint32),
+        ("dict_size", ctypes.c_uint32),
+        ("crc", ctypes.c_uint32),
+        ("first_substream", ctypes.c_uint32),
+        ("n_substreams", ctypes.c_uint32),
+        ("props", ctypes.c_uint8),
+        ("has_crc", ctypes.c_uint8),
+        ("reserved", ctypes.c_uint8 * 2),
+    ]
+
+
+class SzSubstream(ctypes.Structure):
+    _fields_ = [("size", ctypes.c_uint64), ("crc", ctypes.c_uint32), ("has_crc", ctypes.c_uint32)]
 
 
 _lib = None
@@ -145,6 +166,9 @@ def lib():
     L.xlz_batch_unit_trace.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]
     L.xlz_decode_batch_multi.argtypes = [ctypes.POINTER(vp), sz, ctypes.POINTER(StreamDesc), sz, ctypes.POINTER(Result)]
     L.xlz_xz_index.argtypes = [vp, sz, ctypes.POINTER(XzBlock), sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint64)]
+    L.xlz_7z_index.argtypes = [vp, vp, sz, ctypes.POINTER(SzFolder), sz, ctypes.POINTER(sz), ctypes.POINTER(SzSubstream), sz,
+                               ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint64)]
+    L.xlz_7z_decode.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(ctypes.c_uint64), i32, ctypes.POINTER(sz)]
     L.xlz_xz_decode.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(ctypes.c_uint64), i32, ctypes.POINTER(sz)]
     _lib = L
     return L

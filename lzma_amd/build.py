@@ -10,8 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libxlz.so")
-SOURCES = ["xlz_kernel.hip", "xlz_host.hip", "xlz_xz.hip"]
-HEADERS = ["xlz_format.h", "xlz_fastpath.inc", os.path.join("..", "..", "include", "xlz.h")]
+SOURCES = ["xlz_kernel.hip", "xlz_host.hip", "xlz_xz.hip", "xlz_7z.hip"]
+HEADERS = ["xlz_format.h", "xlz_check.h", "xlz_fastpath.inc", os.path.join("..", "..", "include", "xlz.h")]
 ARCH = "gfx950"
 
 

@@ -151,7 +151,11 @@ struct LaunchParams {
     // exact launches (streams that read across an LZMA2 dictionary reset): kMaxEpochs entries per
     // workgroup; nullptr in ordinary launches, which only flag AUX_STALE
     Epoch *epochs;
+    // one word per hardware wave slot of the device (kPrioTabWords): the compressed bytes the wave in
+    // that slot still has to decode, 0 when idle -- the waves of a SIMD rank themselves by it (rotate_priority)
+    uint32_t *prio_tab;
 };
+constexpr uint32_t kPrioTabWords = 1u << 20; // XCC_ID[3:0] : HW_ID[15:0]
 
 // implemented in xlz_kernel.hip
 int launch_decode(const LaunchParams &p, int num_cus, void *stream /* hipStream_t */);

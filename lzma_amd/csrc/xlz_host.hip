@@ -76,6 +76,7 @@ struct xlz_ctx {
     int num_cus = 0;
     hipStream_t stream = nullptr;
     uint32_t *queue = nullptr; // work-queue head, re-zeroed on the stream before each launch
+    uint32_t *prio_tab = nullptr; // LaunchParams.prio_tab: one word per hardware wave slot, zero when idle
     hipEvent_t ev[8] = {};
     std::mutex mu;
     HostPipe pipe;
@@ -93,6 +94,7 @@ struct StreamPlan {
     uint32_t in_len = 0;  // LZMA2: stream length
     uint32_t dict_size = 0;
     bool lzma2 = false;
+    bool oversize = false; // >= 4 GiB of input or output: not in the arenas, decoded as a session by xlz_decode_batch
 };
 
 struct xlz_batch {
@@ -232,7 +234,10 @@ extern "C" int xlz_ctx_create(int device, xlz_ctx **out)
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&c->queue, 512) != hipSuccess) {
+        hipMalloc(&c->queue, 512) != hipSuccess || hipMalloc(&c->prio_tab, kPrioTabWords * sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(c->prio_tab, 0, kPrioTabWords * sizeof(uint32_t)) != hipSuccess) {
+        if (c->queue) (void)hipFree(c->queue);
+        if (c->prio_tab) (void)hipFree(c->prio_tab);
         delete c;
         return XLZ_ERR_DEVICE;
     }
@@ -246,6 +251,7 @@ extern "C" void xlz_ctx_destroy(xlz_ctx *c)
     if (c->batcher) batcher_shutdown(c->batcher);
     (void)hipSetDevice(c->device);
     if (c->queue) (void)hipFree(c->queue);
+    if (c->prio_tab) (void)hipFree(c->prio_tab);
     if (c->pipe.pin_in) (void)hipHostFree(c->pipe.pin_in);
     for (int i = 0; i < HostPipe::kRing; i++) {
         if (c->pipe.ring[i]) (void)hipHostFree(c->pipe.ring[i]);
@@ -460,7 +466,8 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
 
         if (u.kind == UNIT_LZMA2) {
             if (s.in_len > kMaxUnitBytes || s.out_cap > kMaxUnitBytes) {
-                pl.host_status = XLZ_ERR_UNSUPPORTED;
+                pl.host_status = XLZ_ERR_UNSUPPORTED; // (xlz_decode_batch decodes these as sessions)
+                pl.oversize = true;
                 continue;
             }
             std::vector<Lz2Unit> lu;
@@ -508,7 +515,8 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
         // 32-bit byte counters on the device: a defined size must fit them
         const bool size_too_big = u.unpack_size != kUnknownSize && u.unpack_size > kMaxUnitBytes;
         if (payload > kMaxUnitBytes || cap > kMaxUnitBytes || size_too_big) {
-            pl.host_status = XLZ_ERR_UNSUPPORTED;
+            pl.host_status = XLZ_ERR_UNSUPPORTED; // (xlz_decode_batch decodes these as sessions)
+            pl.oversize = true;
             continue;
         }
         const bool big = (uint32_t)u.lc + u.lp > kMaxLcLpLds;
@@ -630,6 +638,7 @@ extern "C" int xlz_batch_run(xlz_batch *b)
     p.order = b->d_order;
     p.results = b->d_results;
     p.queue = ctx->queue;
+    p.prio_tab = ctx->prio_tab;
     p.epochs = nullptr; // ordinary launch: copies that reach across a dictionary reset are only flagged
     if (b->n_normal) { // models in LDS
         p.n_units = b->n_normal;
@@ -716,6 +725,7 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
         p.mlit_stride = big ? 0 : b->mlit_stride;
         p.order_base = 0;
         p.epochs = d_epochs;
+        p.prio_tab = ctx->prio_tab;
         if (launch_decode(p, ctx->num_cus, ctx->stream) == 0 && hipStreamSynchronize(ctx->stream) == hipSuccess &&
             hipMemcpy(res.data(), d_res, n * sizeof(UnitResult), hipMemcpyDeviceToHost) == hipSuccess)
             st = XLZ_OK;
@@ -1040,6 +1050,8 @@ int download_all(xlz_batch *b, const xlz_stream_desc *streams, const xlz_result 
 
 } // namespace
 
+static int decode_oversize(xlz_ctx *ctx, const xlz_stream_desc *streams, xlz_result *results, const std::vector<size_t> &idx);
+
 extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_result *results)
 {
     if (!ctx || (!streams && n) || (!results && n)) return XLZ_ERR_BAD_ARG;
@@ -1051,7 +1063,11 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     st = xlz_batch_run(b);
     if (st == XLZ_OK) st = xlz_batch_results(b, results);
     if (st == XLZ_OK) st = download_all(b, streams, results);
+    std::vector<size_t> big; // streams of 4 GiB and more do not fit a unit's 32-bit counters: sessions
+    for (size_t i = 0; i < n && st == XLZ_OK; i++)
+        if (b->plans[i].oversize) big.push_back(i);
     xlz_batch_destroy(b);
+    if (st == XLZ_OK && !big.empty()) st = decode_oversize(ctx, streams, results, big);
     return st;
 }
 
@@ -1130,7 +1146,9 @@ struct Session {
 struct xlz_reader {
     xlz_ctx *ctx = nullptr;
     xlz_stream_desc desc;
-    std::vector<uint8_t> in;
+    std::vector<uint8_t> in;     // the reader's own copy of the compressed stream ...
+    const uint8_t *src = nullptr; // ... or a borrowed buffer (oversize streams of xlz_decode_batch): src/src_len is
+    size_t src_len = 0;          // what the session reads
     std::vector<uint8_t> chunk;  // decoded bytes not yet handed to Read
     size_t rd = 0;
     bool finished = false;       // the stream's end (or error) has been reached; status is final
@@ -1172,6 +1190,8 @@ xlz_reader *reader_new(xlz_ctx *ctx, const uint8_t *in, size_t in_len)
     if (!r) return nullptr;
     r->ctx = ctx;
     r->in.assign(in, in + in_len);
+    r->src = r->in.data();
+    r->src_len = r->in.size();
     memset(&r->desc, 0, sizeof r->desc);
     return r;
 }
@@ -1205,7 +1225,7 @@ int session_open(xlz_reader *r)
     if (r->desc.format == XLZ_FMT_LZMA2_RAW) {
         std::vector<Lz2Unit> lu;
         uint32_t mx = 0;
-        scan_lzma2(r->in.data(), r->in.size(), lu, mx);
+        scan_lzma2(r->src, r->src_len, lu, mx);
         u.kind = UNIT_LZMA2;
         u.dict_size = r->desc.dict_size < kLzmaDicMin ? 8u * 1024 * 1024 : r->desc.dict_size; // reader2.go:88-91
         u.unpack_size = kUnknownSize;
@@ -1213,8 +1233,8 @@ int session_open(xlz_reader *r)
         ss->model_lc_lp = mx;
     } else {
         xlz_stream_desc d = r->desc;
-        d.in = r->in.data();
-        d.in_len = r->in.size();
+        d.in = r->src;
+        d.in_len = r->src_len;
         StreamPlan pl;
         bool has = false;
         if (r->desc.format == XLZ_FMT_LZMA_ALONE)
@@ -1238,8 +1258,11 @@ int session_open(xlz_reader *r)
     // a stream of known size never needs more than its size; start small, grow on demand
     ss->win_max = 2 * (size_t)u.dict_size + kChunk + kWinSlack;
     if (known != kUnknownSize && known + kWinSlack < ss->win_max) ss->win_max = (size_t)known + kWinSlack;
+    // positions inside the window are 32-bit: a dictionary beyond ~2 GiB gets a window it cannot
+    // slide in; such a stream decodes while it fits and is refused beyond (session_prepare)
+    if (ss->win_max > kMaxUnitBytes) ss->win_max = (size_t)kMaxUnitBytes;
     ss->win_cap = std::min<size_t>(ss->win_max, 2 * kChunk + kWinSlack);
-    ss->in_buf = std::min<size_t>(kInBuf, align_up(r->in.size() - ss->payload_off + 16, 256) + kArenaTailPad);
+    ss->in_buf = std::min<size_t>(kInBuf, align_up(r->src_len - ss->payload_off + 16, 256) + kArenaTailPad);
     ss->off_state = kCtlHead;
     ss->off_in = align_up(ss->off_state + state_bytes(ss->model_lc_lp), 256);
     if (hipMalloc(&ss->d_ctl, ss->off_in + ss->in_buf) != hipSuccess || hipMalloc(&ss->d_win, ss->win_cap) != hipSuccess) {
@@ -1280,7 +1303,7 @@ int session_prepare(xlz_reader *r, hipStream_t stream)
         if ((size_t)ss->pos + kChunk + kWinSlack > ss->win_cap) {
             // full size reached: only the last dictSize bytes can still be referenced (window.go:18-29);
             // win_max = 2 * dictSize + ... guarantees source and destination do not overlap
-            if ((size_t)ss->pos - keep < keep) return XLZ_ERR_DEVICE; // cannot happen (see win_max)
+            if ((size_t)ss->pos - keep < keep) return XLZ_ERR_UNSUPPORTED; // dictionary > 2 GiB on a stream > 4 GiB
             if (hipMemcpyAsync(ss->d_win, ss->d_win + (ss->pos - keep), keep, hipMemcpyDeviceToDevice, stream) != hipSuccess)
                 return XLZ_ERR_DEVICE;
             ss->rebase += (uint32_t)(ss->pos - keep);
@@ -1288,15 +1311,15 @@ int session_prepare(xlz_reader *r, hipStream_t stream)
         }
     }
     // ---- input window: [in_skip, in_loaded) of the payload is on the device
-    const uint64_t total = r->in.size() - ss->payload_off;
+    const uint64_t total = r->src_len - ss->payload_off;
     const uint64_t margin = u.kind == UNIT_LZMA2 ? 70000 : 4096;
     if (!ss->started || (ss->in_loaded < total && ss->in_loaded - ss->consumed < margin)) {
         ss->in_skip = ss->consumed & ~(uint64_t)255;
         const uint64_t end = std::min<uint64_t>(total, ss->in_skip + ss->in_buf - kArenaTailPad);
-        if (hipMemcpyAsync(ss->d_ctl + ss->off_in, r->in.data() + ss->payload_off + ss->in_skip, (size_t)(end - ss->in_skip),
+        if (hipMemcpyAsync(ss->d_ctl + ss->off_in, r->src + ss->payload_off + ss->in_skip, (size_t)(end - ss->in_skip),
                            hipMemcpyHostToDevice, stream) != hipSuccess ||
             hipMemsetAsync(ss->d_ctl + ss->off_in + (end - ss->in_skip), 0, kArenaTailPad, stream) != hipSuccess ||
-            hipStreamSynchronize(stream) != hipSuccess) // r->in is pageable: the copy has been staged when this returns
+            hipStreamSynchronize(stream) != hipSuccess) // the source is pageable: the copy has been staged when this returns
             return XLZ_ERR_DEVICE;
         ss->in_loaded = end;
     }
@@ -1327,6 +1350,13 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs)
     std::vector<Unit> units(n);
     for (size_t i = 0; i < n; i++) {
         int st = session_prepare(rs[i], ctx->stream);
+        if (st == XLZ_ERR_UNSUPPORTED && n == 1) { // this stream ends here; others are not affected
+            rs[i]->finished = true;
+            rs[i]->status = XLZ_ERR_UNSUPPORTED;
+            rs[i]->chunk.clear();
+            rs[i]->rd = 0;
+            return XLZ_OK;
+        }
         if (st != XLZ_OK) return st;
         units[i] = rs[i]->ss->unit;
         max_lc_lp = std::max(max_lc_lp, rs[i]->ss->model_lc_lp);
@@ -1372,6 +1402,7 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs)
         p.max_lc_lp = max_lc_lp;
         p.mlit = d_mlit;
         p.mlit_stride = 0;
+        p.prio_tab = ctx->prio_tab;
         if (launch_decode(p, ctx->num_cus, ctx->stream) == 0 &&
             hipMemcpyAsync(res.data(), d_res, n * sizeof(UnitResult), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
             hipStreamSynchronize(ctx->stream) == hipSuccess)
@@ -1385,7 +1416,8 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs)
             const uint32_t new_pos = (uint32_t)u.out_len;
             ss->started = true;
             ss->rebase = 0;
-            ss->consumed = u.in_consumed;
+            // (the device counts input modulo 2^32, relative arithmetic only; the window is < 4 GiB)
+            ss->consumed = ss->in_skip + (uint32_t)((uint32_t)u.in_consumed - (uint32_t)ss->in_skip);
             r->n_refills++;
             if ((u.aux & AUX_STALE) || u.status == ST_ERR_UNSUPPORTED) {
                 // a copy reached across an LZMA2 dictionary reset (the bytes of this refill are not exact),
@@ -1420,23 +1452,28 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs)
 int reader_whole(xlz_reader *r)
 {
     r->n_whole++;
+    if (r->src_len > kMaxUnitBytes || r->delivered > kMaxUnitBytes) { // the batch path holds a stream in one unit
+        r->finished = true;
+        r->status = XLZ_ERR_UNSUPPORTED;
+        return XLZ_OK;
+    }
     uint64_t cap = 0;
     bool known = false;
     if (r->desc.format == XLZ_FMT_LZMA_ALONE) {
-        uint64_t u = xlz_decode_unpack_size(r->in.data() + 5);
+        uint64_t u = xlz_decode_unpack_size(r->src + 5);
         if (u != kUnknownSize) known = true, cap = u;
     } else if (r->desc.format == XLZ_FMT_LZMA_RAW && r->desc.unpack_size != kUnknownSize) {
         known = true;
         cap = r->desc.unpack_size;
     }
-    if (!known) cap = std::max<uint64_t>(1u << 16, std::max<uint64_t>((uint64_t)r->in.size() * 6, r->delivered * 2));
+    if (!known) cap = std::max<uint64_t>(1u << 16, std::max<uint64_t>((uint64_t)r->src_len * 6, r->delivered * 2));
     std::vector<uint8_t> out;
     for (;;) {
         if (cap > kMaxUnitBytes) cap = kMaxUnitBytes;
         out.resize((size_t)cap);
         xlz_stream_desc d = r->desc;
-        d.in = r->in.data();
-        d.in_len = r->in.size();
+        d.in = r->src;
+        d.in_len = r->src_len;
         d.out = out.data();
         d.out_cap = out.size();
         xlz_result res;
@@ -1527,6 +1564,68 @@ void reader_release_device(xlz_reader *r)
 }
 
 } // namespace
+
+// Streams of >= 4 GiB (input or output) inside xlz_decode_batch: each is a session (the window slides,
+// the device counts positions relative to it, state.go:123-129's 64-bit bytesLeft is kept), all of
+// them stepped together, every refill copied straight into the caller's buffer.
+static int decode_oversize(xlz_ctx *ctx, const xlz_stream_desc *streams, xlz_result *results, const std::vector<size_t> &idx)
+{
+    std::vector<xlz_reader> rs(idx.size());
+    std::vector<uint64_t> produced(idx.size(), 0);
+    std::vector<xlz_reader *> active;
+    int st = XLZ_OK;
+    for (size_t k = 0; k < idx.size(); k++) {
+        xlz_reader &r = rs[k];
+        r.ctx = ctx;
+        r.desc = streams[idx[k]];
+        r.src = streams[idx[k]].in;
+        r.src_len = streams[idx[k]].in_len;
+        int so;
+        {
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            HIP_TRY(hipSetDevice(ctx->device));
+            so = session_open(&r);
+        }
+        if (so == XLZ_OK)
+            active.push_back(&r);
+        else if (so == XLZ_ERR_DEVICE)
+            st = so;
+        else
+            results[idx[k]].status = XLZ_ERR_UNSUPPORTED; // model too large for LDS AND >= 4 GiB
+    }
+    while (st == XLZ_OK && !active.empty()) {
+        st = sessions_step(ctx, active);
+        if (st != XLZ_OK) break;
+        std::vector<xlz_reader *> next;
+        for (xlz_reader *r : active) {
+            const size_t k = (size_t)(r - rs.data());
+            const xlz_stream_desc &d = streams[idx[k]];
+            xlz_result &res = results[idx[k]];
+            if (r->whole) { // (malformed LZMA2 reading across a dictionary reset: needs the whole-stream path)
+                res.status = XLZ_ERR_UNSUPPORTED;
+                res.out_len = produced[k];
+                continue;
+            }
+            const size_t room = d.out_cap > produced[k] ? (size_t)(d.out_cap - produced[k]) : 0;
+            const size_t take = std::min(room, r->chunk.size());
+            if (take) memcpy(d.out + produced[k], r->chunk.data(), take);
+            const bool overflow = take < r->chunk.size();
+            produced[k] += take;
+            r->chunk.clear();
+            if (overflow || r->finished) {
+                res.status = overflow ? XLZ_ERR_OUT_CAP : r->status;
+                res.out_len = produced[k];
+                res.in_consumed = r->ss->payload_off + r->ss->consumed;
+                res.reserved = 0;
+                continue;
+            }
+            next.push_back(r);
+        }
+        active.swap(next);
+    }
+    for (xlz_reader &r : rs) reader_release_device(&r);
+    return st;
+}
 
 // NewReader1, reader1.go:18-24
 extern "C" xlz_reader *xlz_new_reader1(xlz_ctx *ctx, const uint8_t *in, size_t in_len, int *err)
@@ -1729,6 +1828,8 @@ extern "C" int xlz_reader_reopen(xlz_reader *r, const uint8_t *in, size_t in_len
     }
     const int e = check_rc_init(in, in_len);
     r->in.assign(in, in + in_len);
+    r->src = r->in.data();
+    r->src_len = r->in.size();
     Session *ss = r->ss;
     ss->payload_off = 0;
     ss->in_skip = ss->in_loaded = ss->consumed = 0;

@@ -19,65 +19,12 @@
 #include <vector>
 
 #include "../../include/xlz.h"
+#include "xlz_check.h"
 
 namespace {
 
-uint32_t crc32_tab[8][256];
-uint64_t crc64_tab[4][256];
-std::once_flag crc_once;
-
-void crc_init()
-{
-    for (uint32_t i = 0; i < 256; i++) {
-        uint32_t c = i;
-        uint64_t d = i;
-        for (int k = 0; k < 8; k++) {
-            c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1)));
-            d = (d >> 1) ^ (0xC96C5795D7870F42ull & (0ull - (d & 1)));
-        }
-        crc32_tab[0][i] = c;
-        crc64_tab[0][i] = d;
-    }
-    for (uint32_t i = 0; i < 256; i++) {
-        for (int t = 1; t < 8; t++) crc32_tab[t][i] = (crc32_tab[t - 1][i] >> 8) ^ crc32_tab[0][crc32_tab[t - 1][i] & 0xFF];
-        for (int t = 1; t < 4; t++) crc64_tab[t][i] = (crc64_tab[t - 1][i] >> 8) ^ crc64_tab[0][crc64_tab[t - 1][i] & 0xFF];
-    }
-}
-
-uint32_t crc32(const uint8_t *p, size_t n)
-{
-    std::call_once(crc_once, crc_init);
-    uint32_t c = 0xFFFFFFFFu;
-    while (n >= 8) { // slicing-by-8
-        uint32_t a, b;
-        memcpy(&a, p, 4);
-        memcpy(&b, p + 4, 4);
-        a ^= c;
-        c = crc32_tab[7][a & 0xFF] ^ crc32_tab[6][(a >> 8) & 0xFF] ^ crc32_tab[5][(a >> 16) & 0xFF] ^ crc32_tab[4][a >> 24] ^
-            crc32_tab[3][b & 0xFF] ^ crc32_tab[2][(b >> 8) & 0xFF] ^ crc32_tab[1][(b >> 16) & 0xFF] ^ crc32_tab[0][b >> 24];
-        p += 8;
-        n -= 8;
-    }
-    while (n--) c = (c >> 8) ^ crc32_tab[0][(c ^ *p++) & 0xFF];
-    return ~c;
-}
-
-uint64_t crc64(const uint8_t *p, size_t n)
-{
-    std::call_once(crc_once, crc_init);
-    uint64_t c = ~0ull;
-    while (n >= 4) { // slicing-by-4
-        uint32_t a;
-        memcpy(&a, p, 4);
-        a ^= (uint32_t)c;
-        c = (c >> 32) ^ crc64_tab[3][a & 0xFF] ^ crc64_tab[2][(a >> 8) & 0xFF] ^ crc64_tab[1][(a >> 16) & 0xFF] ^
-            crc64_tab[0][a >> 24];
-        p += 4;
-        n -= 4;
-    }
-    while (n--) c = (c >> 8) ^ crc64_tab[0][(c ^ *p++) & 0xFF];
-    return ~c;
-}
+using xlzcheck::crc32;
+using xlzcheck::crc64;
 
 uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 
@@ -303,8 +250,12 @@ extern "C" int xlz_xz_decode(xlz_ctx *ctx, const uint8_t *file, size_t len, uint
                     bad[i] = crc32(p, (size_t)blk[i].uncomp_len) != le32(c);
                 else if (blk[i].check_type == 4)
                     bad[i] = crc64(p, (size_t)blk[i].uncomp_len) != ((uint64_t)le32(c) | (uint64_t)le32(c + 4) << 32);
-                else if (blk[i].check_type != 0)
-                    bad[i] = 2; // SHA-256 and reserved types: not verified here
+                else if (blk[i].check_type == 10) {
+                    uint8_t dg[32];
+                    xlzcheck::sha256(p, (size_t)blk[i].uncomp_len, dg);
+                    bad[i] = memcmp(dg, c, 32) != 0;
+                } else if (blk[i].check_type != 0)
+                    bad[i] = 2; // reserved check types: not verified
             }
         };
         std::vector<std::thread> th;

