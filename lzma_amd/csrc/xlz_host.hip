@@ -578,9 +578,8 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     }
     if (b->n_normal) { // the matched-literal half of every resident model (xlz_format.h)
         b->mlit_stride = num_matched_probs(b->max_lc_lp);
-        if (hipMalloc(&b->d_mlit, (size_t)decode_grid(b->max_lc_lp, ctx->num_cus) * b->mlit_stride * sizeof(uint16_t)) !=
-            hipSuccess)
-            return fail(XLZ_ERR_DEVICE);
+        const size_t slots = (size_t)decode_grid(b->max_lc_lp, ctx->num_cus);
+        if (hipMalloc(&b->d_mlit, slots * b->mlit_stride * sizeof(uint16_t)) != hipSuccess) return fail(XLZ_ERR_DEVICE);
     }
     {
         // pack the payloads into the context's pinned image (several host threads), one H2D copy
@@ -622,6 +621,7 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     return XLZ_OK;
 }
 
+
 extern "C" int xlz_batch_run(xlz_batch *b)
 {
     if (!b) return XLZ_ERR_BAD_ARG;
@@ -632,6 +632,7 @@ extern "C" int xlz_batch_run(xlz_batch *b)
     HIP_TRY(hipEventRecord(b->ev0, ctx->stream));
     const uint32_t nu = (uint32_t)b->units.size();
     LaunchParams p;
+    memset(&p, 0, sizeof p); // (ready, epochs, ...: off unless set below)
     p.in_arena = b->d_in;
     p.out_arena = b->d_out;
     p.units = b->d_units;
@@ -711,6 +712,7 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
         hipMemcpy(d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess &&
         hipMemsetAsync(ctx->queue, 0, 256, ctx->stream) == hipSuccess) {
         LaunchParams p;
+    memset(&p, 0, sizeof p); // (ready, epochs, ...: off unless set below)
         p.in_arena = b->d_in;
         p.out_arena = b->d_out;
         p.units = d_units;
@@ -737,6 +739,9 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
     return st;
 }
 
+void fold_streams(xlz_batch *b, size_t s0, size_t s1, std::vector<size_t> &redo);
+int finish_collect(xlz_batch *b, const std::vector<size_t> &redo);
+
 // Sync, fetch unit results, fold them into per-stream results.  An LZMA2 stream whose
 // units did not produce / consume exactly what its chunk headers announced is decoded
 // again as ONE unit: that pass follows the reference's framing byte for byte.
@@ -753,7 +758,15 @@ int collect(xlz_batch *b)
         HIP_TRY(hipMemcpy(ur.data(), b->d_results, ur.size() * sizeof(UnitResult), hipMemcpyDeviceToHost));
     b->final_results.assign(b->n, xlz_result{});
     std::vector<size_t> redo;
-    for (size_t i = 0; i < b->n; i++) {
+    fold_streams(b, 0, b->n, redo);
+    return finish_collect(b, redo);
+}
+
+// unit results -> per-stream results for streams [s0, s1); streams that need the exact re-run go to `redo`
+void fold_streams(xlz_batch *b, size_t s0, size_t s1, std::vector<size_t> &redo)
+{
+    const std::vector<UnitResult> &ur = b->unit_results;
+    for (size_t i = s0; i < s1; i++) {
         const StreamPlan &pl = b->plans[i];
         xlz_result &r = b->final_results[i];
         if (pl.host_status != 1) { // settled while parsing
@@ -803,6 +816,11 @@ int collect(xlz_batch *b)
             }
         }
     }
+}
+
+// the exact single-unit re-run of the streams in `redo` (malformed LZMA2 only), then the byte sums
+int finish_collect(xlz_batch *b, const std::vector<size_t> &redo)
+{
     for (int pass = 0; pass < 2 && !redo.empty(); pass++) {
         const bool big = pass == 1;
         std::vector<Unit> units;
@@ -931,6 +949,7 @@ namespace {
 // threads scatter the chunks that have arrived while the next ones are in flight.
 int download_all(xlz_batch *b, const xlz_stream_desc *streams, const xlz_result *results)
 {
+    const size_t s0 = 0, s1 = b->n;
     xlz_ctx *ctx = b->ctx;
     HostPipe &hp = ctx->pipe;
     struct Piece {
@@ -944,7 +963,7 @@ int download_all(xlz_batch *b, const xlz_stream_desc *streams, const xlz_result 
         std::vector<Piece> pieces;
     };
     std::vector<Chunk> chunks;
-    for (size_t i = 0; i < b->n; i++) {
+    for (size_t i = s0; i < s1; i++) {
         const StreamPlan &pl = b->plans[i];
         size_t len = (size_t)results[i].out_len;
         if (pl.host_status != 1 || len == 0) continue;
@@ -1057,12 +1076,26 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     if (!ctx || (!streams && n) || (!results && n)) return XLZ_ERR_BAD_ARG;
     for (size_t i = 0; i < n; i++)
         if (!streams[i].out && streams[i].out_cap) return XLZ_ERR_BAD_ARG;
+    // upload (pinned image, one copy) -> decode -> download (pinned ring, D2H overlapped with the scatter
+    // into the callers' buffers).  Splitting a call into sub-batches whose upload / decode / download
+    // overlap was built and measured in round 2 and is NOT here: on this stack a D2H copy enqueued on
+    // a second stream did not start before the running decode launch had finished, and a call of one
+    // wave round has nothing to overlap anyway.
+    const char *dbg = getenv("XLZ_DEBUG"); // debugging aid: log HIP failures and the phase times of this call
+    const auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (dbg) fprintf(stderr, "xlz_decode_batch: %-10s at %.1f ms\n", what,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
     xlz_batch *b = nullptr;
     int st = xlz_batch_create(ctx, streams, n, &b);
     if (st != XLZ_OK) return st;
+    lap("uploaded");
     st = xlz_batch_run(b);
     if (st == XLZ_OK) st = xlz_batch_results(b, results);
+    lap("decoded");
     if (st == XLZ_OK) st = download_all(b, streams, results);
+    lap("downloaded");
     std::vector<size_t> big; // streams of 4 GiB and more do not fit a unit's 32-bit counters: sessions
     for (size_t i = 0; i < n && st == XLZ_OK; i++)
         if (b->plans[i].oversize) big.push_back(i);
@@ -1391,6 +1424,7 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs)
     if (hipMemcpyAsync(d_units, units.data(), n * sizeof(Unit), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
         hipMemsetAsync(ctx->queue, 0, 256, ctx->stream) == hipSuccess) {
         LaunchParams p;
+    memset(&p, 0, sizeof p); // (ready, epochs, ...: off unless set below)
         memset(&p, 0, sizeof p);
         p.in_arena = nullptr; // units carry absolute device addresses
         p.out_arena = nullptr;

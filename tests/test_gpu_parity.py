@@ -487,3 +487,45 @@ def test_differential_fuzz_against_the_oracle(ctx):
     spec.loader.exec_module(mod)
     n, n_bad = mod.fuzz(ctx, budget=8.0, seed=20251004, per_round=96, verbose=False)
     assert n >= 96 and n_bad > 0
+
+
+def test_large_mixed_call_of_decode_batch(ctx):
+    """one xlz_decode_batch call with five wave rounds of work: 20 000 streams / 150 MiB of input, LZMA1
+    and multi-unit LZMA2 streams, ragged sizes, a truncated, a corrupted, an empty and an
+    out-of-room stream, plus a malformed LZMA2 stream that needs the exact re-run -- every result
+    equals the plaintext (the oracle for the bad ones), twice (the pinned pools are reused)."""
+    from lzma_amd import FMT_LZMA2_RAW
+    base = []
+    for i in range(80):
+        p = corpus.plain("R", 8000 + i, 6000 + 113 * i)                # incompressible: input-heavy
+        base.append((Stream(corpus.compress_alone(p, preset=0), FMT_LZMA_ALONE, out_cap=len(p)), p))
+    for i in range(30):
+        p = corpus.plain("TMZ"[i % 3], 8100 + i, 20_000 + 1000 * i)
+        base.append((Stream(corpus.compress_alone(p, preset=0, known_size=(i % 2 == 0)), FMT_LZMA_ALONE, out_cap=len(p)), p))
+    for i in range(10):
+        segs = [corpus.plain("TRZ"[(i + k) % 3], 8200 + 10 * i + k, 9_000) for k in range(4)]
+        base.append((Stream(corpus.lzma2_concat(segs, dict_size=1 << 16, preset=0), FMT_LZMA2_RAW, out_cap=36_000,
+                            dict_size=1 << 16), b"".join(segs)))
+    n = 20_000
+    streams = [base[i % len(base)][0] for i in range(n)]
+    want = [(base[i % len(base)][1], 0) for i in range(n)]
+    good = base[0][0].data
+    bad = bytearray(base[81][0].data)
+    bad[len(bad) // 2] ^= 0x20
+    specials = {7: Stream(good[: len(good) // 2], FMT_LZMA_ALONE, out_cap=60_000),
+                4000: Stream(bytes(bad), FMT_LZMA_ALONE, out_cap=40_000),
+                9555: Stream(b"", FMT_LZMA_ALONE, out_cap=10),
+                n - 1: Stream(good, FMT_LZMA_ALONE, out_cap=1000)}
+    from test_crafted_streams import crafted_lzma2
+    name, blob, ds, cap, _ = crafted_lzma2()[2]
+    specials[12345] = Stream(blob, FMT_LZMA2_RAW, out_cap=cap, dict_size=ds)
+    for k, s in specials.items():
+        streams[k] = s
+        w = oracle.lzma2_raw(s.data, s.dict_size, s.out_cap) if s.fmt == FMT_LZMA2_RAW else oracle.lzma1_alone(s.data, s.out_cap)
+        want[k] = (w[0], w[1])
+    assert sum(len(s.data) for s in streams) >= 64 << 20 and n >= 16384
+    for _ in range(2):
+        got = lzma_amd.decode_batch(ctx, streams)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g[1] == w[1], (i, g[1], w[1])
+            assert g[0] == w[0], i

@@ -165,6 +165,19 @@ def need_copy_done(inline=False):
 
 
 def finish_body():
+    if "smask" in VARIANT:  # experiment: store only the len bytes of the copy (not the scratch lanes behind them)
+        emit("""
+        s_sub_u32 s80, 64, s95
+        s_lshr_b64 exec, -1, s80
+        s_waitcnt vmcnt(0)
+        global_store_byte v48, v49, %[outp]
+        s_mov_b64 exec, -1
+        s_sub_u32 s80, s95, 1
+        v_readlane_b32 %[prev], v49, s80
+        v_readlane_b32 %[mb], v49, s95
+        s_mov_b32 s94, 0
+        """)
+        return
     emit("""
     s_waitcnt vmcnt(0)
     global_store_byte v48, v49, %[outp]
@@ -835,15 +848,18 @@ def sec_copy():
     """ % L("x3"))
     need_copy_done(inline=True)  # the new source may overlap the bytes the pending copy still has to store
     emit("v_add_u32 v48, %[pos], %[vlane]\nv_subrev_u32 v61, s93, v48")
-    if "cmask" in VARIANT:  # only lanes 0..len fetch (byte len is the next matchByte): fewer sectors touched
+    if "nocmask" in VARIANT:
+        emit("global_load_ubyte v49, v61, %[outp]")
+    else:
+        # only lanes 0..len fetch (byte len is the next matchByte): a 64-lane gather touches two or three
+        # 32-byte sectors of a window that is rarely in L2, a 7-byte one touches one (FETCH_SIZE per launch
+        # 43.7 -> 31.8 GB on the bench workload, throughput unchanged)
         emit("""
         s_sub_u32 s80, 63, s89
         s_lshr_b64 exec, -1, s80
         global_load_ubyte v49, v61, %[outp]
         s_mov_b64 exec, -1
         """)
-    else:
-        emit("global_load_ubyte v49, v61, %[outp]")
     emit("""
     s_mov_b32 s94, 1
     s_mov_b32 s95, s89
