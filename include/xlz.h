@@ -12,6 +12,10 @@
  * decode path in this library: without a usable HIP device every decode entry
  * point fails with XLZ_ERR_DEVICE.
  *
+ * The library reads ONE environment variable, a debugging aid: XLZ_DEBUG (any
+ * value) prints failed HIP calls and the phase times of xlz_decode_batch to
+ * stderr.  Nothing tunes the decode.
+ *
  * file:line citations are into the reference repository.
  */
 #ifndef XLZ_H

@@ -73,3 +73,19 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "xlz_oracle" not in text and "import oracle" not in text, f
+
+
+def test_xlz_so_override_loads_another_build(xlz_so, tmp_path):
+    """XLZ_SO (README: development aid for A/B measurements) makes the binding load the library it
+    names; checked in a child process with a copy of the built library."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    other = str(tmp_path / "libxlz_other.so")
+    shutil.copy(xlz_so, other)
+    code = "import lzma_amd._native as N; N.lib(); print(N.SO_PATH); print(N.lib().xlz_version().decode())"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=dict(os.environ, XLZ_SO=other))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split()[0] == other and "xlz" in r.stdout
