@@ -294,3 +294,67 @@ def lzma2_lzma_chunk(control, unc_size, payload, props=None):
     if control >= 0xC0:
         h += bytes([props])
     return h + payload
+
+
+# ---- random LZMA2 streams with every kind of chunk and reset (differential fuzzing) --------------
+def random_lzma2_stream(rnd, dict_size=4096, max_chunks=8, max_packets=120):
+    """A structurally valid LZMA2 stream made of random packets, cut into chunks with random control
+    bytes: stored chunks with and without dictionary reset, LZMA chunks that reset nothing / the
+    state / state + properties / everything.  Rep matches are free to reach behind a dictionary
+    reset (the bytes the reference's uncleared window still holds there).  -> (bytes, expected output
+    by the crafter's own window model)."""
+    lc, lp, pb = rnd.choice([(3, 0, 2), (0, 0, 0), (1, 1, 1), (0, 2, 0), (4, 0, 0)])
+    w = Window(dict_size)
+    e = None
+    out = bytearray()
+    first_lzma = True
+    for c in range(rnd.randint(1, max_chunks)):
+        kind = rnd.random()
+        if kind < 0.3:  # stored chunk
+            data = bytes(rnd.randrange(256) for _ in range(rnd.choice([1, 2, 7, 60, 300, 2000])))
+            reset = rnd.random() < 0.5 or c == 0
+            if reset:
+                w.reset()
+            for b in data:
+                w.put(b)
+            out += lzma2_stored(data, reset)
+            continue
+        if first_lzma:
+            control = 0xE0 if rnd.random() < 0.8 else 0xC0
+        else:
+            control = rnd.choice([0x80, 0x80, 0x80, 0xA0, 0xC0, 0xE0])
+        if control >= 0xC0:
+            lc, lp, pb = rnd.choice([(3, 0, 2), (0, 0, 0), (1, 1, 1), (0, 2, 0), (4, 0, 0)])
+        if control == 0xE0:
+            w.reset()
+        if e is None:
+            e = Encoder(lc, lp, pb, dict_size, window=w)
+        else:
+            e.new_chunk()
+            if control >= 0xC0:
+                e.renew(lc, lp, pb)
+            elif control == 0xA0:
+                e.reset_state()
+        first_lzma = False
+        start = len(w.total)
+        n = rnd.randint(1, max_packets)
+        for _ in range(n):
+            r = rnd.random()
+            fill = w.size if w.full else w.pos
+            if w.empty() or r < 0.4:
+                e.literal(rnd.randrange(256) if rnd.random() < 0.3 else rnd.choice(b"abcde "))
+            elif r < 0.6 and fill >= 1:
+                d = rnd.randint(1, min(fill, dict_size))
+                e.match(d, rnd.choice([2, 3, 4, 8, 9, 17, 18, 40, 64, 65, 273]))
+            elif r < 0.75:
+                e.short_rep()
+            else:
+                e.rep(rnd.randrange(4), rnd.choice([2, 3, 9, 16, 17, 70, 273]))
+            if len(w.total) - start > 60_000:
+                break
+        pay = e.payload()
+        if len(pay) > 65536 or len(w.total) == start:
+            break
+        out += lzma2_lzma_chunk(control, len(w.total) - start, pay, props_byte(lc, lp, pb))
+    out += b"\x00"
+    return bytes(out), bytes(w.total)

@@ -5,9 +5,12 @@ bytes, status and consumed input.
 usage: python tools/fuzz_gpu.py [seconds] [seed]"""
 import os, struct, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import random
 import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import corpus, lzma_amd, oracle
 from lzma_amd import Stream, FMT_LZMA_ALONE, FMT_LZMA2_RAW
+from lzma_craft import random_lzma2_stream  # packet-level crafter: LZMA2 streams with every chunk / reset kind
 
 def damage(rng, c):
     c = bytearray(c)
@@ -67,6 +70,19 @@ def fuzz(ctx, budget, seed, per_round=160, verbose=True):
               cap = max(cap, 0)
               streams.append(Stream(c, FMT_LZMA2_RAW, out_cap=cap, dict_size=d2))
               wants.append(oracle.lzma2_raw(c, d2, cap))
+      # crafted LZMA2 streams: random packets, random resets; rep matches may read the window bytes an
+      # EARLIER dictionary epoch left behind (window.go:135-140) -- the exact (epoch table) launch
+      for _ in range(per_round // 6):
+          r2 = random.Random(int(rng.integers(1, 1 << 62)))
+          d2 = r2.choice([4096, 4097, 8192, 65536])
+          c, expect = random_lzma2_stream(r2, d2)
+          cap = len(expect) + int(rng.choice([0, 0, 7, -1])) if len(expect) > 1 else len(expect)
+          if rng.random() < 0.2 and len(c) > 8:
+              c = bytearray(c)
+              c[int(rng.integers(0, len(c)))] ^= 1 << int(rng.integers(0, 8))
+              c = bytes(c)
+          streams.append(Stream(c, FMT_LZMA2_RAW, out_cap=max(cap, 0), dict_size=d2))
+          wants.append(oracle.lzma2_raw(c, d2, max(cap, 0)))
       got = lzma_amd.decode_batch(ctx, streams)
       for i, (g, w) in enumerate(zip(got, wants)):
           n_total += 1
