@@ -177,6 +177,36 @@ def test_crafted_streams_cpu_expectations():
         oracle.lzma1_alone(blob, cap)  # must not crash; statuses are compared on the GPU
 
 
+def test_random_crafted_lzma2_streams_cpu():
+    """random packets, random chunk kinds and resets (tools/fuzz_gpu.py uses the same generator on the
+    GPU): the crafter's window model and the oracle agree on every byte"""
+    from lzma_craft import random_lzma2_stream
+    for seed in range(150):
+        rnd = random.Random(seed)
+        ds = rnd.choice([4096, 4097, 8192, 65536])
+        blob, want = random_lzma2_stream(rnd, ds)
+        got = oracle.lzma2_raw(blob, ds, len(want) + 100)
+        assert got[1] == 0 and got[0] == want, seed
+
+
+@pytest.mark.gpu
+def test_random_crafted_lzma2_streams_gpu(ctx):
+    import lzma_amd
+    from lzma_amd import FMT_LZMA2_RAW, Stream
+    from lzma_craft import random_lzma2_stream
+    streams, wants = [], []
+    for seed in range(1000, 1400):
+        rnd = random.Random(seed)
+        ds = rnd.choice([4096, 4097, 8192, 65536])
+        blob, want = random_lzma2_stream(rnd, ds)
+        cap = len(want) + rnd.choice([0, 0, 9, -1])
+        streams.append(Stream(blob, FMT_LZMA2_RAW, out_cap=max(cap, 0), dict_size=ds))
+        wants.append(oracle.lzma2_raw(blob, ds, max(cap, 0)))
+    got = lzma_amd.decode_batch(ctx, streams)
+    for i, (g, w) in enumerate(zip(got, wants)):
+        assert g == w, i
+
+
 @pytest.mark.gpu
 def test_crafted_streams_on_gpu(ctx):
     import lzma_amd

@@ -553,10 +553,11 @@ def head_issue(first=False):
 LIT_BLOCKS = ["v50", "v51", "v52", "v53"]
 
 
-def literal_tail():
+def literal_tail(run_entry=None):
     """window.PutByte (:168), state (:171), then the next packet's head gather; the caller then
     applies the model update and requests the next literal blocks (which may be the very table
-    just updated, hence after the update's store).  v32 = the byte."""
+    just updated, hence after the update's store).  v32 = the byte.
+    run_entry: label to leave to when the new state is 0 (literal run, sec_literal_run)."""
     emit("""
     s_andn2_b32 %[prev], 0xff, s88
     v_mov_b32 v32, %[prev]
@@ -566,10 +567,12 @@ def literal_tail():
     """)
     wpos_advance("1")
     emit("v_readlane_b32 %[state], %[vlitnext], %[state]")  # stateUpdateLiteral as a 12-lane table
+    if run_entry:
+        emit("s_cmp_eq_u32 %%[state], 0\ns_cbranch_scc1 %s" % run_entry)
     head_issue()
 
 
-def plain_literal():
+def plain_literal(run_entry=None):
     """plain literal (:127-175) with its blocks in v50..v53 and base in v39; ends at pktl"""
     if "lit8" in VARIANT:
         walk8(LIT_BLOCKS)
@@ -577,7 +580,7 @@ def plain_literal():
         gather8(LIT_BLOCKS)
     else:
         walk_rec(8, LIT_BLOCKS)
-        literal_tail()
+        literal_tail(run_entry=run_entry)
     tree_update_rec(8, "v39")
     literal_context(prev_v="v32")
     emit("s_branch %s" % L("pktl"))
@@ -599,7 +602,78 @@ def sec_packet_after_literal():
     s_cbranch_scc1 %s
     """ % (L("x0"), H_IS_MATCH, L("x0")))
     hbit(H_IS_MATCH, L("match"), stage=2)
-    plain_literal()
+    plain_literal(run_entry=L("lrent") if "litrun" in VARIANT else None)
+
+
+IM0 = "v34"  # literal run: isMatch[state 0][posState], lane = posState
+
+
+def im0_update(bit):
+    """new value of isMatch[0][posState s90] inside IM0 (decompress.go:30 / :177)"""
+    emit("v_cmp_eq_u32 vcc, s90, %[vlane]")
+    if bit == 0:
+        emit("v_add_u32 v63, 0xfffff81f, %s\nv_ashrrev_i32 v63, 5, v63" % IM0)
+    else:
+        emit("v_ashrrev_i32 v63, 5, %s" % IM0)
+    emit("v_sub_u32 v63, %s, v63\nv_cndmask_b32 %s, %s, v63, vcc" % (IM0, IM0, IM0))
+
+
+def im0_writeback():
+    emit("v_cndmask_b32 v60, v38, v56, s[78:79]\nds_write_b16 v60, %s" % IM0)
+
+
+def sec_literal_run():
+    """Runs of literals (state 0: at least three literals since the last match, state.go:153-163).  The only
+    head probability such a packet needs is isMatch[0][posState]: the sixteen of them stay in a register
+    (lane = posState), so a literal of a run has no head gather, no head write-back and no wait for them.
+    Entered from the plain literal of sec_packet_after_literal when the state reaches 0; left to the
+    match path (label match2) at the first match, or to the exits."""
+    label("lrent")  # the finished literal's model update and the next literal's blocks are still to do
+    emit("ds_write_b16 v47, v40")       # the head of the packet that just ended goes back
+    emit("v_mov_b32 v47, v38")          # ... and no later exit writes it again (harmless slot)
+    emit("ds_read_u16 %s, v56" % IM0)   # isMatch[0][0..15] (P_IS_MATCH = 0), behind the write above
+    tree_update_rec(8, "v39")
+    literal_context(prev_v="v32")
+    label("lrun")
+    emit("s_waitcnt lgkmcnt(0)")
+    bounds(IM0)
+    emit("""
+    s_cmp_gt_u32 %%[arel], %%[arel_lim]
+    s_cbranch_scc1 %s
+    s_and_b32 s90, %%[wpos], %%[pos_mask]
+    s_cmp_ge_u32 %%[pos], %%[pos_lim]
+    s_cbranch_scc1 %s
+    v_readlane_b32 s80, v55, s90
+    v_cmp_gt_u32 vcc, s80, v29
+    s_cbranch_vccz %s
+    s_mov_b32 %%[range], s80
+    """ % (L("lrx0"), L("lrx0"), L("lrmatch")))
+    im0_update(0)
+    nchk()
+    walk_rec(8, LIT_BLOCKS)
+    emit("""
+    s_andn2_b32 %[prev], 0xff, s88
+    v_mov_b32 v32, %[prev]
+    v_mov_b32 v61, %[pos]
+    global_store_byte v61, v32, %[outp]
+    s_add_u32 %[pos], %[pos], 1
+    """)
+    wpos_advance("1")  # the state stays 0 (stateUpdateLiteral)
+    tree_update_rec(8, "v39")
+    literal_context(prev_v="v32")
+    emit("s_branch %s" % L("lrun"))
+    label("lrx0")  # a limit at a packet boundary: the register goes back, the ordinary exit does the rest
+    im0_writeback()
+    emit("s_branch %s" % L("x0"))
+    label("lrmatch")  # isMatch = 1: finish that decision here, gather the packet's head, join the match path
+    emit("v_subrev_u32 v29, s80, v29\ns_sub_u32 %[range], %[range], s80")
+    im0_update(1)
+    im0_writeback()
+    head_issue(first=True)
+    nchk()
+    emit("s_waitcnt lgkmcnt(0)")
+    bounds("v40")
+    emit("s_nop 0\nv_readlane_b32 s80, v55, %d\ns_branch %s" % (H_IS_REP, L("match2")))
 
 
 def sec_packet_general():
@@ -690,6 +764,7 @@ def sec_match():
     # ------------------------------------------------------------- match or rep
     label("match")
     hbit_one(H_IS_MATCH, next_head=H_IS_REP)
+    label("match2")  # (a literal run joins here with its own isMatch decision done)
     len_request(P_LEN)  # speculative (a rep match asks for its own trees): one LDS round trip earlier
     hbit(H_IS_REP, L("rep"), stage=2)
     # simple match (:215-668)
@@ -921,6 +996,8 @@ def gen():
     emit("v_sub_u32 v19, 8, %[vlane]\nv_sub_u32 v18, 7, %[vlane]\nv_cmp_gt_u32 s[76:77], 8, %[vlane]")
     if "lit8" in VARIANT:
         emit("v_cmp_eq_u32 s[78:79], 6, %[vlane]")  # gather8: lane 6 takes block 1
+    if "litrun" in VARIANT:
+        emit("v_cmp_gt_u32 s[78:79], 16, %[vlane]")  # the sixteen isMatch[0][posState] lanes
     # v21, lane = raw length 0..7: byte address of posSlot[min(len, 3)]; v20, lane = state:
     # stateUpdateMatch (state.go:165-171)
     emit("""
@@ -943,6 +1020,8 @@ def gen():
     sec_copy()
     sec_packet_general()
     sec_rep()
+    if "litrun" in VARIANT:
+        sec_literal_run()
     for f in deferred:
         f()
     sec_exits()
