@@ -306,8 +306,10 @@ def cpu_baseline(spec, comp, digests, threads, target_s):
         buf, n_out = outs[i]
         assert hashlib.sha256(buf.raw[:n_out]).digest() == digests[i]
     per_core = n_sample * osz / (1 << 20) / dt / min(threads, n_sample)
+    import shutil
     return {"value": round(n_sample * osz / GIB / dt, 4), "unit": "GiB/s", "cores": min(threads, n_sample), "kind": "port",
             "per_core_mib_s": round(per_core, 1),
+            "go_toolchain_on_this_box": bool(shutil.which("go") or shutil.which("gccgo")),  # probed every run
             "sample": "%d of the %d streams (%d MiB decoded) in %.2f s of decode wall time; C restatement of the Go "
                       "reference's algorithm (oracle/xlz_oracle.c, gcc -O2), one stream per thread on %d host CPUs "
                       "(%.0f MiB/s per core; the reference publishes 42.59 MiB/s on tar data and 16.47 MB/s on random "
