@@ -2,9 +2,10 @@
 // decode hot path ((*Reader1).decompress and the LZMA2 framing around it) through libxlz.so,
 // the MI355X decoder declared in include/xlz.h.  It keeps the reference's constructors, the
 // concrete *Reader1 / *Reader2 types with their Read / Reset / Reopen methods and the
-// io.ReadCloser of the sevenzip constructors; the device wants the compressed stream as one
-// buffer, so a constructor slurps its source first (the decoded side is streamed: a reader holds
-// one refill chunk, see include/xlz.h).
+// io.ReadCloser of the sevenzip constructors.  Both sides are streamed: a constructor reads the
+// first MiB of its source, Read pulls the next MiB whenever the decoder asks for input
+// (XLZ_NEED_INPUT -> xlz_reader_feed), and the decoded side arrives one refill chunk at a time
+// (include/xlz.h) -- a reader's memory does not depend on the stream's size.
 //
 // NOT COMPILED IN THIS REPOSITORY: the build image has no Go toolchain (go, gccgo: not found).
 // The same C entry points are exercised by a plain C caller (tests/c/reader_demo.c) and through
@@ -108,26 +109,66 @@ func context() (*C.xlz_ctx, error) {
 	return ctx, ctxErr
 }
 
-// handle owns an xlz_reader; freed by Close-then-finalizer or by the finalizer alone.
+const pieceSize = 1 << 20 // compressed bytes pulled from the source at a time
+
+// handle owns an xlz_reader; freed by Close-then-finalizer or by the finalizer alone.  src is the
+// rest of the compressed stream (nil once it has ended or when the whole stream was given).
 type handle struct {
-	h *C.xlz_reader
+	h   *C.xlz_reader
+	src io.Reader
 }
 
-func newHandle(h *C.xlz_reader) *handle {
-	r := &handle{h: h}
+func newHandle(h *C.xlz_reader, src io.Reader) *handle {
+	r := &handle{h: h, src: src}
+	if src != nil {
+		C.xlz_reader_expect_more(h)
+	}
 	runtime.SetFinalizer(r, func(r *handle) { C.xlz_reader_free(r.h) })
 	return r
+}
+
+// firstPiece reads up to pieceSize bytes; the returned reader is nil when the source ended inside them.
+func firstPiece(src io.Reader) ([]byte, io.Reader, error) {
+	buf := make([]byte, pieceSize)
+	n, err := io.ReadFull(src, buf)
+	if err == io.EOF || err == io.ErrUnexpectedEOF {
+		return buf[:n], nil, nil
+	}
+	if err != nil {
+		return nil, nil, err
+	}
+	return buf, src, nil
 }
 
 func (r *handle) read(p []byte) (int, error) {
 	if len(p) == 0 {
 		return 0, nil // the reference never returns from Read(p) with len(p) == 0 (SURVEY parity note 6)
 	}
-	var st C.int
-	// p is a Go slice of bytes (no pointers inside): passing &p[0] for the duration of the call is allowed
-	n := C.xlz_reader_read(r.h, (*C.uint8_t)(unsafe.Pointer(&p[0])), C.size_t(len(p)), &st)
-	runtime.KeepAlive(r)
-	return int(n), readError(st)
+	got := 0
+	for {
+		var st C.int
+		// p is a Go slice of bytes (no pointers inside): passing &p[got] for the duration of the call is allowed
+		n := C.xlz_reader_read(r.h, (*C.uint8_t)(unsafe.Pointer(&p[got])), C.size_t(len(p)-got), &st)
+		got += int(n)
+		if st != C.XLZ_NEED_INPUT {
+			runtime.KeepAlive(r)
+			return got, readError(st)
+		}
+		// the decoder has used up its input: the next piece of the source, or its end
+		piece := make([]byte, pieceSize)
+		k, err := io.ReadFull(r.src, piece)
+		if k > 0 {
+			C.xlz_reader_feed(r.h, (*C.uint8_t)(unsafe.Pointer(&piece[0])), C.size_t(k)) // copied by the library
+		}
+		if err == io.EOF || err == io.ErrUnexpectedEOF {
+			C.xlz_reader_feed_eof(r.h)
+		} else if err != nil {
+			return got, err // the source's own error, as the reference's ReadByte would surface it
+		}
+		if got == len(p) {
+			return got, nil
+		}
+	}
 }
 
 // Reader1 replaces lzma.Reader1 (reader1.go:10-16).
@@ -142,7 +183,8 @@ func (r *Reader1) Reset() {
 	runtime.KeepAlive(r)
 }
 
-// Reopen is (*Reader1).Reopen (reader1.go:166-176): a new raw stream on the same window and model.
+// Reopen is (*Reader1).Reopen (reader1.go:166-176): a new raw stream on the same window and model
+// (taken whole: xlz_reader_reopen has no streaming form).
 func (r *Reader1) Reopen(inStream io.ByteReader, unpackSize uint64) error {
 	data, err := slurp(inStream)
 	if err != nil {
@@ -224,7 +266,7 @@ func NewReader1(inStream io.ByteReader) (*Reader1, error) {
 	if err != nil {
 		return nil, err
 	}
-	data, err := slurp(inStream)
+	data, rest, err := firstPiece(asReader(inStream))
 	if err != nil {
 		return nil, err
 	}
@@ -235,7 +277,28 @@ func NewReader1(inStream io.ByteReader) (*Reader1, error) {
 	if h == nil {
 		return nil, reader1CtorError(st, len(data))
 	}
-	return &Reader1{newHandle(h)}, nil
+	return &Reader1{newHandle(h, rest)}, nil
+}
+
+// asReader: bufio.Reader, bytes.Reader ... are io.Readers already; a bare io.ByteReader is adapted.
+func asReader(br io.ByteReader) io.Reader {
+	if r, ok := br.(io.Reader); ok {
+		return r
+	}
+	return byteReaderAdapter{br}
+}
+
+type byteReaderAdapter struct{ br io.ByteReader }
+
+func (a byteReaderAdapter) Read(p []byte) (int, error) {
+	for i := range p {
+		b, err := a.br.ReadByte()
+		if err != nil {
+			return i, err
+		}
+		p[i] = b
+	}
+	return len(p), nil
 }
 
 // NewReader2 replaces lzma.NewReader2 (reader2.go:26-41).
@@ -244,7 +307,7 @@ func NewReader2(inStream io.Reader, dictSize int) (*Reader2, error) {
 	if err != nil {
 		return nil, err
 	}
-	data, err := io.ReadAll(inStream)
+	data, rest, err := firstPiece(inStream)
 	if err != nil {
 		return nil, err
 	}
@@ -263,7 +326,7 @@ func NewReader2(inStream io.Reader, dictSize int) (*Reader2, error) {
 		}
 		return nil, readError(st)
 	}
-	return &Reader2{newHandle(h)}, nil
+	return &Reader2{newHandle(h, rest)}, nil
 }
 
 // NewLZMADecompressorForSevenZip replaces the bodgit/sevenzip constructor of reader1.go:32-61.
@@ -289,7 +352,7 @@ func sevenzip(lzma2 bool, props []byte, unpackSize uint64, readers []io.ReadClos
 	if err != nil {
 		return nil, err
 	}
-	data, err := io.ReadAll(readers[0])
+	data, rest, err := firstPiece(readers[0])
 	if err != nil {
 		return nil, err
 	}
@@ -333,7 +396,7 @@ func sevenzip(lzma2 bool, props []byte, unpackSize uint64, readers []io.ReadClos
 		}
 		return nil, reader1CtorError(st, 13)
 	}
-	return &readCloser{handle: newHandle(h), c: readers[0]}, nil
+	return &readCloser{handle: newHandle(h, rest), c: readers[0]}, nil
 }
 
 // DecodeBatch is the new entry the reference has no analogue for: n independent .lzma

@@ -181,7 +181,21 @@ xlz_reader *xlz_new_lzma2_decompressor_for_sevenzip(xlz_ctx *ctx, const uint8_t 
 /* Read(p): returns bytes copied (>= 0).  *err: XLZ_OK while more may follow;
  * XLZ_EOF at end of stream; a negative status on error.                          */
 #define XLZ_EOF 100
+#define XLZ_NEED_INPUT 101 /* streaming input only: feed the next piece (or declare the end), read again */
 long xlz_reader_read(xlz_reader *r, uint8_t *p, size_t n, int *err);
+/* Streaming input: the reference's readers pull from an io.Reader as they go (reader1.go:18-24,
+ * decompress.go:35: one ReadByte per normalisation); the C ABI takes buffers, so the pull is turned
+ * around.  Construct the reader from the FIRST piece of the stream (at least the .lzma header / the
+ * first LZMA2 chunk header and the five range-coder bytes: the constructors check those), call
+ * xlz_reader_expect_more once, then: xlz_reader_read returns XLZ_NEED_INPUT whenever the decoder has
+ * used up its input -- feed the next piece (any size; >= 128 KiB keeps LZMA2 chunks whole) or
+ * declare the end, and read again.  The library keeps only the bytes the decoder has not consumed:
+ * with this, a reader's memory is bounded on BOTH sides.  Streams with lc+lp > 4 after the first
+ * piece, and malformed LZMA2 streams that read across a dictionary reset, end in XLZ_ERR_UNSUPPORTED
+ * in this mode (there is no whole stream to fall back to).                                       */
+int xlz_reader_expect_more(xlz_reader *r);
+int xlz_reader_feed(xlz_reader *r, const uint8_t *data, size_t n);
+int xlz_reader_feed_eof(xlz_reader *r);
 /* (*Reader1).Reset (reader1.go:161-164): the probability model, state and reps start over, the window
  * and the input position stay.  (*Reader1).Reopen (reader1.go:166-176): continue on a NEW raw LZMA
  * stream (no header) with the given unpack size (all-ones = unknown), same window and model; its

@@ -12,7 +12,7 @@ from . import _native as N
 from ._native import (EOF, ERR_BAD_ARG, ERR_CLOSED, ERR_DEVICE, ERR_HEADER_EOF,  # noqa: F401
                       ERR_INSUFFICIENT_PROPS, ERR_NEED_ONE_READER, ERR_OUT_CAP, ERR_PROPS,
                       ERR_RC_INIT, ERR_RESULT, ERR_UNEXPECTED_EOF, ERR_UNSUPPORTED,
-                      FMT_LZMA2_RAW, FMT_LZMA_ALONE, FMT_LZMA_RAW, OK, OK_INPUT_EOF, UNKNOWN_SIZE)
+                      FMT_LZMA2_RAW, FMT_LZMA_ALONE, FMT_LZMA_RAW, NEED_INPUT, OK, OK_INPUT_EOF, UNKNOWN_SIZE)
 
 
 class LzmaError(Exception):
@@ -280,15 +280,36 @@ class io_EOF:  # sentinel standing in for Go's io.EOF
 
 
 class _Reader:
-    def __init__(self, ctx, handle):
+    def __init__(self, ctx, handle, source=None, piece=1 << 20):
         self._ctx = ctx
         self._h = ctypes.c_void_p(handle)
+        self._src = source  # file-like object the rest of the compressed stream is pulled from (streaming input)
+        self._piece = piece
+        if source is not None:
+            st = N.lib().xlz_reader_expect_more(self._h)
+            if st != OK:
+                raise LzmaError(st, "xlz_reader_expect_more")
 
     def Read(self, n):
-        """Go's Read(p []byte): returns (bytes, err) with err None, io_EOF or LzmaError."""
+        """Go's Read(p []byte): returns (bytes, err) with err None, io_EOF or LzmaError.  With a
+        source (NewReader1 / NewReader2 on a file object) the compressed side is pulled piece by piece
+        as the decoder asks for it -- what the Go shim does with its io.Reader."""
         buf = ctypes.create_string_buffer(max(n, 1))
         err = ctypes.c_int()
-        got = N.lib().xlz_reader_read(self._h, ctypes.cast(buf, ctypes.c_void_p), n, ctypes.byref(err))
+        got = 0
+        while True:
+            k = N.lib().xlz_reader_read(self._h, ctypes.cast(ctypes.addressof(buf) + got, ctypes.c_void_p), n - got,
+                                        ctypes.byref(err))
+            got += k
+            if err.value != NEED_INPUT or self._src is None:
+                break
+            more = self._src.read(self._piece)
+            st = N.lib().xlz_reader_feed(self._h, more, len(more)) if more else N.lib().xlz_reader_feed_eof(self._h)
+            if st != OK:
+                return buf.raw[:got], LzmaError(st, "feeding the reader")
+            if got == n and n:
+                err.value = OK
+                break
         e = None
         if err.value == EOF:
             e = io_EOF
@@ -354,22 +375,33 @@ class ReadCloser(_Reader):
     _is_closer = True
 
 
-def NewReader1(ctx, data):
-    """NewReader1(inStream) (reader1.go:18-24): returns (reader, err)."""
-    err = ctypes.c_int()
-    h = N.lib().xlz_new_reader1(ctx._h, bytes(data), len(data), ctypes.byref(err))
-    if not h:
-        return None, LzmaError(err.value)
-    return Reader1(ctx, h), None
+def _head_and_source(data, piece):
+    """bytes -> (bytes, None); a file-like object -> (its first piece, the object or None at its end)"""
+    if hasattr(data, "read"):
+        head = data.read(piece)
+        return head, (data if len(head) == piece else None)
+    return bytes(data), None
 
 
-def NewReader2(ctx, data, dict_size):
-    """NewReader2(inStream, dictSize) (reader2.go:26-41): returns (reader, err)."""
+def NewReader1(ctx, data, piece=1 << 20):
+    """NewReader1(inStream) (reader1.go:18-24): returns (reader, err).  `data`: the compressed bytes, or a
+    file-like object that is then read `piece` bytes at a time as the decoder needs them."""
+    head, src = _head_and_source(data, piece)
     err = ctypes.c_int()
-    h = N.lib().xlz_new_reader2(ctx._h, bytes(data), len(data), dict_size, ctypes.byref(err))
+    h = N.lib().xlz_new_reader1(ctx._h, head, len(head), ctypes.byref(err))
     if not h:
         return None, LzmaError(err.value)
-    return Reader2(ctx, h), None
+    return Reader1(ctx, h, src, piece), None
+
+
+def NewReader2(ctx, data, dict_size, piece=1 << 20):
+    """NewReader2(inStream, dictSize) (reader2.go:26-41): returns (reader, err); `data` as for NewReader1."""
+    head, src = _head_and_source(data, piece)
+    err = ctypes.c_int()
+    h = N.lib().xlz_new_reader2(ctx._h, head, len(head), dict_size, ctypes.byref(err))
+    if not h:
+        return None, LzmaError(err.value)
+    return Reader2(ctx, h, src, piece), None
 
 
 def _sevenzip(fn, ctx, props, unpack_size, readers):

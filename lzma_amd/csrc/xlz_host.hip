@@ -1196,6 +1196,10 @@ struct xlz_reader {
     bool refill_pending = false;
     uint64_t n_refills = 0, n_whole = 0;
     bool pending_reset = false, pending_reopen = false; // (*Reader1).Reset / Reopen before the next refill
+    // streaming input (xlz_reader_expect_more / _feed / _feed_eof): `in` holds the bytes from stream
+    // offset in_base on; what the decoder has consumed is dropped at every feed
+    bool streaming = false, in_eof = false, need_input = false;
+    uint64_t in_base = 0;
 };
 
 // Background coalescer of readers (one per context).
@@ -1262,6 +1266,7 @@ int session_open(xlz_reader *r)
         u.kind = UNIT_LZMA2;
         u.dict_size = r->desc.dict_size < kLzmaDicMin ? 8u * 1024 * 1024 : r->desc.dict_size; // reader2.go:88-91
         u.unpack_size = kUnknownSize;
+        if (r->streaming && mx < 4) mx = 4; // later chunks may bring other properties: room for all that lc+lp <= 4 allows
         u.lc = (uint8_t)mx;
         ss->model_lc_lp = mx;
     } else {
@@ -1295,7 +1300,7 @@ int session_open(xlz_reader *r)
     // slide in; such a stream decodes while it fits and is refused beyond (session_prepare)
     if (ss->win_max > kMaxUnitBytes) ss->win_max = (size_t)kMaxUnitBytes;
     ss->win_cap = std::min<size_t>(ss->win_max, 2 * kChunk + kWinSlack);
-    ss->in_buf = std::min<size_t>(kInBuf, align_up(r->src_len - ss->payload_off + 16, 256) + kArenaTailPad);
+    ss->in_buf = r->streaming ? kInBuf : std::min<size_t>(kInBuf, align_up(r->src_len - ss->payload_off + 16, 256) + kArenaTailPad);
     ss->off_state = kCtlHead;
     ss->off_in = align_up(ss->off_state + state_bytes(ss->model_lc_lp), 256);
     if (hipMalloc(&ss->d_ctl, ss->off_in + ss->in_buf) != hipSuccess || hipMalloc(&ss->d_win, ss->win_cap) != hipSuccess) {
@@ -1344,12 +1349,14 @@ int session_prepare(xlz_reader *r, hipStream_t stream)
         }
     }
     // ---- input window: [in_skip, in_loaded) of the payload is on the device
-    const uint64_t total = r->src_len - ss->payload_off;
+    // (payload offsets; the host holds the stream from offset r->in_base on, all of it unless it is fed in pieces)
+    const uint64_t total = r->in_base + r->src_len - ss->payload_off; // payload bytes the host has seen so far
+    const bool more_coming = r->streaming && !r->in_eof;
     const uint64_t margin = u.kind == UNIT_LZMA2 ? 70000 : 4096;
     if (!ss->started || (ss->in_loaded < total && ss->in_loaded - ss->consumed < margin)) {
         ss->in_skip = ss->consumed & ~(uint64_t)255;
         const uint64_t end = std::min<uint64_t>(total, ss->in_skip + ss->in_buf - kArenaTailPad);
-        if (hipMemcpyAsync(ss->d_ctl + ss->off_in, r->src + ss->payload_off + ss->in_skip, (size_t)(end - ss->in_skip),
+        if (hipMemcpyAsync(ss->d_ctl + ss->off_in, r->src + (ss->payload_off + ss->in_skip - r->in_base), (size_t)(end - ss->in_skip),
                            hipMemcpyHostToDevice, stream) != hipSuccess ||
             hipMemsetAsync(ss->d_ctl + ss->off_in + (end - ss->in_skip), 0, kArenaTailPad, stream) != hipSuccess ||
             hipStreamSynchronize(stream) != hipSuccess) // the source is pageable: the copy has been staged when this returns
@@ -1364,7 +1371,8 @@ int session_prepare(xlz_reader *r, hipStream_t stream)
     u.pause_at = ss->pos + (uint32_t)kChunk;
     u.rebase = ss->rebase;
     u.state = (uint64_t)(ss->d_ctl + ss->off_state);
-    u.flags = UNIT_F_LAST | (ss->started ? UNIT_F_RESUME : 0u) | (ss->in_loaded < total ? UNIT_F_MORE_INPUT : 0u);
+    u.flags = UNIT_F_LAST | (ss->started ? UNIT_F_RESUME : 0u) |
+              ((ss->in_loaded < total || more_coming) ? UNIT_F_MORE_INPUT : 0u);
     if (ss->started && r->pending_reset) u.flags |= UNIT_F_RESET_MODEL; // before the first launch the model is fresh anyway
     if (ss->started && r->pending_reopen) u.flags |= UNIT_F_REOPEN;
     r->pending_reset = r->pending_reopen = false;
@@ -1453,6 +1461,14 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs)
             // (the device counts input modulo 2^32, relative arithmetic only; the window is < 4 GiB)
             ss->consumed = ss->in_skip + (uint32_t)((uint32_t)u.in_consumed - (uint32_t)ss->in_skip);
             r->n_refills++;
+            if (((u.aux & AUX_STALE) || u.status == ST_ERR_UNSUPPORTED) && r->streaming) {
+                // (no whole-stream fallback when the input is fed in pieces and dropped behind the decoder)
+                r->finished = true;
+                r->status = XLZ_ERR_UNSUPPORTED;
+                r->chunk.clear();
+                r->rd = 0;
+                continue;
+            }
             if ((u.aux & AUX_STALE) || u.status == ST_ERR_UNSUPPORTED) {
                 // a copy reached across an LZMA2 dictionary reset (the bytes of this refill are not exact),
                 // or the stream's real properties exceed what its headers announced: malformed streams
@@ -1472,6 +1488,9 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs)
             if (u.status != ST_PAUSED) {
                 r->finished = true;
                 r->status = u.status;
+            } else if ((u.aux & AUX_NEED_INPUT) && r->streaming && !r->in_eof &&
+                       ss->in_loaded >= r->in_base + r->src_len - ss->payload_off) {
+                r->need_input = true; // everything the host has is on the device and the wave wants more
             }
         }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) st = XLZ_ERR_DEVICE;
@@ -1805,6 +1824,10 @@ extern "C" long xlz_reader_read(xlz_reader *r, uint8_t *p, size_t n, int *err)
                 e = r->status >= 0 ? XLZ_EOF : r->status;
                 break;
             }
+            if (r->need_input) { // streaming input: the caller feeds (or declares the end) and reads again
+                e = XLZ_NEED_INPUT;
+                break;
+            }
             if ((e = reader_refill(r)) != XLZ_OK) break;
         }
         if (n == 0 && r->finished && r->rd == r->chunk.size()) e = r->status >= 0 ? XLZ_EOF : r->status;
@@ -1854,6 +1877,10 @@ extern "C" int xlz_reader_reopen(xlz_reader *r, const uint8_t *in, size_t in_len
     if (!r || (!in && in_len)) return XLZ_ERR_BAD_ARG;
     if (r->closed) return XLZ_ERR_CLOSED;
     if (r->desc.format == XLZ_FMT_LZMA2_RAW || r->whole) return XLZ_ERR_UNSUPPORTED;
+    if (r->streaming && !r->in_eof) return XLZ_ERR_UNSUPPORTED; // the current stream is still being fed
+    r->streaming = false; // the new stream is given whole
+    r->in_base = 0;
+    r->need_input = false;
     if (!r->ss) { // not started yet: open the session on the current stream's parameters first
         std::lock_guard<std::mutex> lock(r->ctx->mu);
         HIP_TRY(hipSetDevice(r->ctx->device));
@@ -1891,6 +1918,49 @@ extern "C" int xlz_reader_reopen(xlz_reader *r, const uint8_t *in, size_t in_len
     r->finished = false;
     r->status = XLZ_OK;
     return e == XLZ_ERR_RC_INIT ? XLZ_ERR_RESULT : e;
+}
+
+// Streaming input.  A reader made from the FIRST piece of a stream (at least the header and the five
+// range-coder bytes: the constructors check those) is told that more follows; xlz_reader_read then
+// returns XLZ_NEED_INPUT whenever the decoder has used up what it was given, and the caller feeds the
+// next piece or declares the end.  The host keeps only what the decoder has not consumed yet.
+extern "C" int xlz_reader_expect_more(xlz_reader *r)
+{
+    if (!r) return XLZ_ERR_BAD_ARG;
+    if (r->closed) return XLZ_ERR_CLOSED;
+    if (r->ss || r->whole) return XLZ_ERR_BAD_ARG; // before the first read
+    r->streaming = true;
+    return XLZ_OK;
+}
+
+extern "C" int xlz_reader_feed(xlz_reader *r, const uint8_t *data, size_t n)
+{
+    if (!r || (!data && n)) return XLZ_ERR_BAD_ARG;
+    if (r->closed) return XLZ_ERR_CLOSED;
+    if (!r->streaming || r->in_eof) return XLZ_ERR_BAD_ARG;
+    if (r->ss) { // drop what the decoder is done with (the device window restarts at consumed & ~255)
+        const uint64_t keep_from = r->ss->payload_off + (r->ss->consumed & ~(uint64_t)255);
+        if (keep_from > r->in_base) {
+            const size_t drop = (size_t)std::min<uint64_t>(keep_from - r->in_base, r->in.size());
+            r->in.erase(r->in.begin(), r->in.begin() + drop);
+            r->in_base += drop;
+        }
+    }
+    r->in.insert(r->in.end(), data, data + n);
+    r->src = r->in.data();
+    r->src_len = r->in.size();
+    r->need_input = false;
+    return XLZ_OK;
+}
+
+extern "C" int xlz_reader_feed_eof(xlz_reader *r)
+{
+    if (!r) return XLZ_ERR_BAD_ARG;
+    if (r->closed) return XLZ_ERR_CLOSED;
+    if (!r->streaming) return XLZ_ERR_BAD_ARG;
+    r->in_eof = true;
+    r->need_input = false;
+    return XLZ_OK;
 }
 
 extern "C" int xlz_reader_stats(const xlz_reader *r, uint64_t *refills, uint64_t *whole_decodes, uint64_t *in_uploaded)

@@ -37,8 +37,10 @@ def test_c_program_links_and_fails_loudly_without_a_gpu(demo):
 @pytest.mark.gpu
 def test_c_program_reads_the_reference_assets(demo, golden):
     exp, data = golden
-    for name, bufsz in (("a.lzma", 32768), ("a_eos.lzma", 7), ("a_lp1_lc2_pb1.lzma", 1), ("randomfile.dat.lzma", 4096)):
-        r = subprocess.run([demo, os.path.join(ROOT, "tests", "golden", name), str(bufsz)], capture_output=True, text=True)
+    for name, bufsz, piece in (("a.lzma", 32768, 262144), ("a_eos.lzma", 7, 64), ("a_lp1_lc2_pb1.lzma", 1, 262144),
+                               ("randomfile.dat.lzma", 4096, 100_000)):   # (a 1 MiB file pulled in 100 kB pieces)
+        r = subprocess.run([demo, os.path.join(ROOT, "tests", "golden", name), str(bufsz), str(piece)], capture_output=True,
+                           text=True)
         assert r.returncode == 0, (name, r.stdout, r.stderr)
         word, total, h = r.stdout.split()
         assert word == "EOF" and int(total) == exp[name]["out_len"]

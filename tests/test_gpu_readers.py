@@ -221,3 +221,71 @@ def test_stream_beyond_4_gib_through_the_batch_call(ctx):
     for o in range(0, size, 1 << 26):
         got.update(mv[o:o + (1 << 26)])
     assert got.digest() == h.digest()
+
+
+@pytest.mark.parametrize("kind", ["lzma1", "lzma2", "sevenzip"])
+def test_streaming_input_is_pulled_piece_by_piece(ctx, kind):
+    """xlz_reader_expect_more / _feed / _feed_eof (what the Go shim does with its io.Reader): the reader is
+    made from the first 300 KiB of a 30 MiB stream and pulls the rest as the decoder asks for it; the
+    library drops what has been consumed, so host memory stays bounded on the compressed side too."""
+    import io
+    import struct
+    p = corpus.plain("M", 6500, 30 << 20)
+    if kind == "lzma1":
+        blob = corpus.compress_alone(p, dict_size=1 << 20, preset=0)
+        r, err = lzma_amd.NewReader1(ctx, io.BytesIO(blob), piece=300_000)
+    elif kind == "lzma2":
+        blob = corpus.compress_raw_lzma2(p, dict_size=1 << 20, preset=0)
+        r, err = lzma_amd.NewReader2(ctx, io.BytesIO(blob), 1 << 20, piece=300_000)
+    else:
+        props, ds, blob = corpus.compress_raw_lzma1(p, dict_size=1 << 20, preset=0)
+        first = blob[:300_000]
+        r, err = lzma_amd.NewLZMADecompressorForSevenZip(ctx, bytes([props]) + struct.pack("<I", ds), len(p), [first])
+        assert err is None
+        from lzma_amd import _native as N
+        assert N.lib().xlz_reader_expect_more(r._h) == 0
+        r._src, r._piece = io.BytesIO(blob[300_000:]), 300_000
+    assert err is None
+    assert len(blob) > 8 << 20
+    gc.collect()
+    rss0 = _rss_mib()
+    h = hashlib.sha256()
+    total = 0
+    peak = rss0
+    while True:
+        b, e = r.Read(65536)
+        h.update(b)
+        total += len(b)
+        if total % (4 << 20) < 65536:
+            peak = max(peak, _rss_mib())
+        if e is not None:
+            break
+    assert e is lzma_amd.io_EOF and total == len(p) and h.digest() == hashlib.sha256(p).digest()
+    refills, whole, uploaded = r.stats()
+    assert whole == 0
+    assert peak - rss0 < 24, (rss0, peak)   # the 12-20 MiB of compressed input never sit in the reader
+
+
+def test_streaming_input_edge_cases(ctx):
+    """truncated source (clean EOF, parity note 4), a corrupted byte in a late piece, tiny pieces"""
+    import io
+    import oracle
+    p = corpus.plain("T", 6600, 3 << 20)
+    blob = corpus.compress_alone(p, preset=0)
+    r, err = lzma_amd.NewReader1(ctx, io.BytesIO(blob[: len(blob) * 2 // 3]), piece=70_000)
+    out, e = r.read_all(chunk=10_000)
+    want = oracle.lzma1_alone(blob[: len(blob) * 2 // 3], len(p))
+    assert e is None and want[1] == lzma_amd.OK_INPUT_EOF and out == want[0]
+    bad = bytearray(blob)
+    bad[len(bad) * 3 // 4] ^= 0x10
+    want = oracle.lzma1_alone(bytes(bad), len(p) + 100)
+    r, err = lzma_amd.NewReader1(ctx, io.BytesIO(bytes(bad)), piece=100_000)
+    out, e = r.read_all(chunk=33_333)
+    assert out == want[0] and ((e is None) == (want[1] >= 0))
+    r, err = lzma_amd.NewReader1(ctx, io.BytesIO(blob), piece=4099)   # pieces far smaller than the LZMA1 margin window
+    out, e = r.read_all(chunk=1 << 20)
+    assert e is None and out == p
+    c2 = corpus.compress_raw_lzma2(p, dict_size=1 << 16, preset=0)
+    r, err = lzma_amd.NewReader2(ctx, io.BytesIO(c2), 1 << 16, piece=20_000)  # pieces smaller than an LZMA2 chunk
+    out, e = r.read_all(chunk=50_000)
+    assert e is None and out == p
