@@ -158,8 +158,10 @@ void xlz_batch_destroy(xlz_batch *batch);
  * saved decoder state for about 1 MiB of output and stops.  Memory is bounded like the
  * reference's: one refill chunk on the host, 2 x dictSize + one chunk of window on the
  * device (less for streams of known size), a 4 MiB input window on the device.  The
- * stream is decoded exactly once, whatever its size or compression ratio.  Two rare
- * fallbacks decode the whole stream in one batch and skip what has been delivered:
+ * stream is decoded exactly once, whatever its size or compression ratio.  An LZMA2
+ * stream whose headers announce eight or more dictionary-reset units is served in runs
+ * of whole units (<= 64 MiB of output each) decoded unit-parallel by the batch engine.
+ * Two rare fallbacks decode the whole stream in one batch and skip what has been delivered:
  * models with lc+lp > 8 (HBM-resident model) and malformed LZMA2 streams whose copies
  * read window bytes of an earlier dictionary epoch.                                    */
 typedef struct xlz_reader xlz_reader;

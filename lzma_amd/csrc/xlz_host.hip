@@ -1200,6 +1200,11 @@ struct xlz_reader {
     // offset in_base on; what the decoder has consumed is dropped at every feed
     bool streaming = false, in_eof = false, need_input = false;
     uint64_t in_base = 0;
+    // unit-parallel LZMA2 (reader_parallel): the stream's dictionary-reset units, the next one to decode
+    std::vector<uint64_t> par_in, par_out; // prefix sums of the units' input / output bytes
+    size_t par_next = 0;
+    bool par = false, par_tried = false;
+    uint64_t n_par = 0;
 };
 
 // Background coalescer of readers (one per context).
@@ -1573,9 +1578,89 @@ void batcher_loop(Batcher *bt)
     }
 }
 
+// An LZMA2 stream made of many dictionary-reset units (multi-threaded encoders write those; BASELINE
+// config 4) read through NewReader2: a session would walk it with ONE wave.  When the whole stream is
+// at hand and its headers announce at least eight units, the reader instead decodes runs of whole
+// units -- up to kParBytes of output per refill -- through the batch path, where every unit has a
+// wave of its own, and serves them in order.  The slice of a run is a raw LZMA2 stream without its
+// end byte: "input ended" at exactly the announced sizes is its clean outcome.  Anything else (the
+// real decode leaves the headers: malformed streams) hands the reader to the whole-stream path.
+constexpr uint64_t kParBytes = 64u << 20;
+
+bool reader_parallel_plan(xlz_reader *r)
+{
+    r->par_tried = true;
+    std::vector<Lz2Unit> lu;
+    uint32_t mx = 0;
+    scan_lzma2(r->src, r->src_len, lu, mx);
+    if (lu.size() < 8 || mx > kMaxLcLpLds) return false;
+    r->par_in.assign(1, 0);
+    r->par_out.assign(1, 0);
+    for (const Lz2Unit &u : lu) {
+        if (u.in_start != r->par_in.back() || u.out_start != r->par_out.back()) return false;
+        r->par_in.push_back(u.in_start + (uint64_t)u.in_len);
+        r->par_out.push_back(u.out_start + u.expect_out);
+    }
+    return r->par_in.back() == r->src_len;
+}
+
+int reader_parallel_step(xlz_reader *r)
+{
+    const size_t nunits = r->par_in.size() - 1;
+    const size_t k0 = r->par_next;
+    size_t k1 = k0 + 1;
+    while (k1 < nunits && r->par_out[k1 + 1] - r->par_out[k0] <= kParBytes) k1++;
+    const bool last = k1 == nunits;
+    const uint64_t want_out = r->par_out[k1] - r->par_out[k0], in_len = r->par_in[k1] - r->par_in[k0];
+    if (want_out > kMaxUnitBytes || in_len > kMaxUnitBytes) { // (one enormous unit: a session's job)
+        r->par = false;
+        return XLZ_OK;
+    }
+    std::vector<uint8_t> out((size_t)want_out + (last ? 65536 : 0) + 1);
+    xlz_stream_desc d = r->desc;
+    d.in = r->src + r->par_in[k0];
+    d.in_len = (size_t)in_len;
+    d.out = out.data();
+    d.out_cap = out.size() - 1;
+    xlz_result res;
+    int st = xlz_decode_batch(r->ctx, &d, 1, &res);
+    if (st != XLZ_OK) return st;
+    r->n_par++;
+    const bool clean = last ? (res.status >= 0 && res.out_len == want_out)
+                            : (res.status == XLZ_ERR_UNEXPECTED_EOF && res.out_len == want_out && res.in_consumed == in_len);
+    if (!clean && !(last && k0 == 0)) { // off the headers: the whole-stream path settles bytes and status
+        r->par = false;
+        r->whole = true;
+        return XLZ_OK;
+    }
+    out.resize((size_t)res.out_len);
+    r->chunk.swap(out);
+    r->rd = 0;
+    r->delivered += res.out_len;
+    r->par_next = k1;
+    if (last) {
+        r->finished = true;
+        r->status = res.status;
+    }
+    return XLZ_OK;
+}
+
 // more decoded bytes into r->chunk (or the end of the stream into r->finished / r->status)
 int reader_refill(xlz_reader *r)
 {
+    if (r->desc.format == XLZ_FMT_LZMA2_RAW && !r->streaming && !r->whole && !r->ss && !r->par_tried)
+        r->par = reader_parallel_plan(r);
+    if (r->par) {
+        int st = reader_parallel_step(r);
+        if (st != XLZ_OK || r->par) return st;
+        if (r->whole && !r->finished) return reader_whole(r);
+        // (a single enormous unit: fall through to a session, which starts at the stream's start -- nothing was delivered yet
+        //  unless earlier runs were; then the whole-stream path is the one that can skip)
+        if (r->delivered) {
+            r->whole = true;
+            return reader_whole(r);
+        }
+    }
     if (!r->ss && !r->whole) {
         int st = XLZ_OK;
         {
@@ -1966,7 +2051,7 @@ extern "C" int xlz_reader_feed_eof(xlz_reader *r)
 extern "C" int xlz_reader_stats(const xlz_reader *r, uint64_t *refills, uint64_t *whole_decodes, uint64_t *in_uploaded)
 {
     if (!r) return XLZ_ERR_BAD_ARG;
-    if (refills) *refills = r->n_refills;
+    if (refills) *refills = r->n_refills + r->n_par;
     if (whole_decodes) *whole_decodes = r->n_whole;
     if (in_uploaded) *in_uploaded = r->ss ? r->ss->in_loaded : 0;
     return XLZ_OK;

@@ -289,3 +289,41 @@ def test_streaming_input_edge_cases(ctx):
     r, err = lzma_amd.NewReader2(ctx, io.BytesIO(c2), 1 << 16, piece=20_000)  # pieces smaller than an LZMA2 chunk
     out, e = r.read_all(chunk=50_000)
     assert e is None and out == p
+
+
+def test_reader2_decodes_dictionary_reset_units_in_parallel(ctx):
+    """NewReader2 on an LZMA2 stream of many dictionary-reset units (multi-threaded encoders, BASELINE
+    config 4): runs of whole units go through the batch path -- a wave per unit -- instead of one wave
+    walking the stream; 1500 units / 150 MiB arrive in a handful of refills, bounded by 64 MiB each."""
+    import time
+    segs = [corpus.plain("TMZ"[i % 3], 6700 + (i % 97), 100_000 + 13 * (i % 50)) for i in range(1500)]
+    blob = corpus.lzma2_concat(segs, dict_size=1 << 16, preset=0)
+    want = hashlib.sha256(b"".join(segs)).digest()
+    total_len = sum(map(len, segs))
+    del segs
+    t0 = time.time()
+    r, err = lzma_amd.NewReader2(ctx, blob, 1 << 16)
+    assert err is None
+    h = hashlib.sha256()
+    total = 0
+    while True:
+        b, e = r.Read(1 << 20)
+        h.update(b)
+        total += len(b)
+        if e is not None:
+            break
+    dt = time.time() - t0
+    assert e is lzma_amd.io_EOF and total == total_len and h.digest() == want
+    refills, whole, _ = r.stats()
+    assert whole == 0 and 2 <= refills <= 6, refills
+    assert dt < 20, dt            # (one wave would need ~30 s for 150 MiB)
+    # a stream that leaves its headers half way: the parallel runs hand over to the whole-stream path,
+    # bytes and error are the oracle's
+    import oracle
+    segs = [corpus.plain("T", 6800 + i, 30_000) for i in range(40)]
+    c = bytearray(corpus.lzma2_concat(segs, dict_size=1 << 16, preset=0))
+    c[len(c) * 7 // 10] ^= 0x08
+    w = oracle.lzma2_raw(bytes(c), 1 << 16, 40 * 30_000 + 1000)
+    r, err = lzma_amd.NewReader2(ctx, bytes(c), 1 << 16)
+    out, e = r.read_all(chunk=77_777)
+    assert out == w[0] and ((e is None) == (w[1] >= 0))
