@@ -1101,6 +1101,11 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
                     break;
                 }
                 phase = PH_CHUNK;
+                // The previous chunk (or the stream before a Reopen) may have ended inside a packet, after
+                // state / rep0 moved on (decompress.go:216,431,785-798 mutate before the next ReadByte can
+                // fail): the first literal then takes its matchByte at the rep0 of NOW, not the one loaded
+                // after the last copy.
+                if (d.state >= 7) reload_context(d, out, lane);
             }
             const int r = lzma_run(d, probs, mprobs, out, lane, hv, !big);
             if (r == RUN_PAUSE) {

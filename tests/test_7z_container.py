@@ -52,6 +52,13 @@ def test_number_encoding_round_trips_through_the_index():
     assert subs2 == [(len(fo[1][2][0]), zlib.crc32(fo[1][2][0])), (len(fo[3][2][0]), zlib.crc32(fo[3][2][0]))]
 
 
+def test_empty_archive():
+    start = struct.pack("<QQI", 0, 0, 0)
+    a = b"7z\xbc\xaf\x27\x1c" + bytes([0, 4]) + struct.pack("<I", zlib.crc32(start)) + start
+    folders, subs, total = lzma_amd.sevenzip_index(a)
+    assert folders == [] and subs == [] and total == 0
+
+
 def test_malformed_and_unsupported_archives_are_refused():
     fo, _ = _folders()
     a = archive(fo)

@@ -146,6 +146,77 @@ def crafted_lzma2():
     return out
 
 
+def crafted_lzma2_cut_chunks():
+    """(name, blob, dict_size, out_cap) -- a compressed chunk whose input ends INSIDE a packet, followed by
+    a chunk that resets nothing (0x80).  The reference mutates state and reps before the ReadByte that
+    fails (decompress.go:216 shifts the reps before the length is read, :431 moves the state before the
+    distance, :785-798 rotate the reps before the normalisation), returns io.EOF, and Reader2 starts the
+    next chunk on whatever was left: its first literal is a matched literal at the rep0 of that moment.
+    (Found by tools/fuzz_gpu.py seed 424242; tests/golden/fuzz_424242_45182.lzma2 is that input.)"""
+    out = []
+    ds = 1 << 16
+    for tail in range(6):
+        rnd = random.Random(500 + tail)
+        w = Window(ds)
+        e = Encoder(3, 0, 2, ds, window=w)
+        for i in range(2500):
+            e.literal(rnd.randrange(97, 105))
+        for _ in range(40):
+            e.match(rnd.randrange(1, 2400), rnd.choice([2, 5, 30]))
+            e.literal(rnd.randrange(97, 105))
+        # the packets the cut lands in: one kind per variant, repeated so that every cut of 1..14 bytes
+        # ends inside one of them
+        for _ in range(8):
+            if tail == 0:
+                e.match(rnd.randrange(1200, 2400), 9)      # distance with direct bits + align
+            elif tail == 1:
+                e.rep(1, 4)                                # reps rotated before the normalisation
+            elif tail == 2:
+                e.rep(2, 17)
+            elif tail == 3:
+                e.rep(3, 70)
+            elif tail == 4:
+                e.match(rnd.randrange(1, 100), 273)        # long length, short distance
+                e.short_rep()
+            else:
+                e.match(rnd.randrange(300, 2000), 3)
+                e.literal(rnd.randrange(256))              # matched literal
+        pay_a, n_a = e.payload(), len(w.total)
+        e.new_chunk()
+        for _ in range(60):
+            e.literal(rnd.randrange(97, 105))
+            e.rep(rnd.randrange(4), rnd.choice([2, 9]))
+            e.match(rnd.randrange(1, 2400), rnd.choice([2, 3, 8]))
+        pay_b, n_b = e.payload(), len(w.total) - n_a
+        chunk_b = lzma2_lzma_chunk(0x80, n_b, pay_b)
+        for cut in range(1, 15):
+            blob = lzma2_lzma_chunk(0xE0, n_a, pay_a[:-cut], props_byte(3, 0, 2)) + chunk_b + b"\x00"
+            out.append(("variant %d, chunk cut %d bytes short" % (tail, cut), blob, ds, n_a + n_b + 64))
+    return out
+
+
+def test_cut_chunks_carry_half_done_packets_cpu():
+    """the oracle on the cut chunks: the second chunk starts where the first stopped (less output than the
+    header promised is NOT an error in the reference), and what follows depends on the cut"""
+    seen = set()
+    for name, blob, ds, cap in crafted_lzma2_cut_chunks():
+        out, status, consumed = oracle.lzma2_raw(blob, ds, cap)
+        seen.add((status, len(out)))
+        assert consumed > 6, name
+    assert len(seen) > 20
+    blob, ds, cap = _fuzz_find()
+    out, status, consumed = oracle.lzma2_raw(blob, ds, cap)
+    assert (status, len(out), consumed) == (oracle.ERR_RESULT, 9942, 907)
+
+
+def _fuzz_find():
+    """the differential fuzzer's find: a bit flip made the chunk at offset 817 run out of input inside a
+    match (after the reps were shifted, before the distance was read)"""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_424242_45182.lzma2")
+    return open(path, "rb").read(), 8192, 10671
+
+
 def crafted_lzma2_framing():
     """first LZMA chunk behind stored chunks: Reader2.lzmaReader is still nil there, so an EOF inside
     rangeDec.Init is a constructor error (reader2.go:146-153)"""
@@ -215,11 +286,12 @@ def test_crafted_streams_on_gpu(ctx):
     got = lzma_amd.decode_batch(ctx, [Stream(b, FMT_LZMA_ALONE, out_cap=cap) for _, b, cap in c1])
     for (name, b, cap), g in zip(c1, got):
         assert g == oracle.lzma1_alone(b, cap), name
-    c2 = [(n, b, ds, cap) for n, b, ds, cap, _ in crafted_lzma2()] + crafted_lzma2_framing()
+    c2 = [(n, b, ds, cap) for n, b, ds, cap, _ in crafted_lzma2()] + crafted_lzma2_framing() + crafted_lzma2_cut_chunks()
     # alone, and inside a batch next to ordinary streams (the exact re-run must not disturb them)
     import corpus
     p = corpus.plain("T", 77, 50_000)
     extra = Stream(corpus.compress_raw_lzma2(p), FMT_LZMA2_RAW, out_cap=len(p), dict_size=1 << 16)
+    c2.append(("fuzz find 424242/45182",) + _fuzz_find())
     streams = [Stream(b, FMT_LZMA2_RAW, out_cap=cap, dict_size=ds) for _, b, ds, cap in c2]
     got = lzma_amd.decode_batch(ctx, streams + [extra])
     for (name, b, ds, cap), g in zip(c2, got):

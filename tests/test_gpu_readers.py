@@ -178,6 +178,47 @@ def test_reader1_reset_and_reopen(ctx):
         assert r.Reopen(b"\x01\0\0\0\0", 5).status == lzma_amd.ERR_RESULT  # first byte != 0: ErrResultError
 
 
+def test_reopen_after_input_that_ended_inside_a_packet(ctx):
+    """A stream whose input stops inside a packet is a clean io.EOF (decompress.go:35-38), with the reps
+    already shifted / the state already moved (decompress.go:216,431).  Reopen continues on exactly that:
+    the same bytes as the LZMA2 stream  E0(A, cut short) 80(B)  decoded by the oracle."""
+    import random
+    import struct
+    import oracle
+    from lzma_craft import Encoder, Window, lzma2_lzma_chunk, props_byte
+    ds = 1 << 16
+    rnd = random.Random(99)
+    w = Window(ds)
+    e = Encoder(3, 0, 2, ds, window=w)
+    for i in range(2000):
+        e.literal(rnd.randrange(97, 105))
+    for _ in range(30):
+        e.match(rnd.randrange(1000, 1900), 7)
+        e.rep(rnd.randrange(1, 4), 5)
+    pay_a, n_a = e.payload(), len(w.total)
+    e.new_chunk()
+    for _ in range(100):
+        e.literal(rnd.randrange(97, 105))
+        e.rep(rnd.randrange(4), 3)
+    pay_b, n_b = e.payload(), len(w.total) - n_a
+    differs = 0
+    for cut in range(1, 10):
+        framed = lzma2_lzma_chunk(0xE0, n_a, pay_a[:-cut], props_byte(3, 0, 2)) + lzma2_lzma_chunk(0x80, n_b, pay_b) + b"\x00"
+        want, status, _ = oracle.lzma2_raw(framed, ds, n_a + n_b)
+        r, err = lzma_amd.NewLZMADecompressorForSevenZip(ctx, bytes([props_byte(3, 0, 2)]) + struct.pack("<I", ds), n_a,
+                                                         [pay_a[:-cut]])
+        assert err is None
+        r.__class__ = lzma_amd.Reader1
+        out_a, e1 = r.read_all(chunk=500)
+        assert e1 is None and len(out_a) < n_a and out_a == want[:len(out_a)]
+        assert r.Reopen(pay_b, n_b) is None
+        out_b, e2 = r.read_all(chunk=4096)
+        assert out_b == want[len(out_a):], cut
+        assert (e2 is None) == (status in (oracle.OK, oracle.OK_INPUT_EOF)), cut
+        differs += out_a + out_b != bytes(w.total)[:len(out_a) + len(out_b)]
+    assert differs  # (the cut changed what B decodes to: the carried state matters)
+
+
 def test_stream_beyond_4_gib_through_the_batch_call(ctx):
     """VERDICT r1 missing #4: 4.25 GiB of output from ONE stream (long repeats, header size patched in:
     state.go:123-129 keeps bytesLeft in 64 bits) next to ordinary streams in the same
@@ -327,3 +368,19 @@ def test_reader2_decodes_dictionary_reset_units_in_parallel(ctx):
     r, err = lzma_amd.NewReader2(ctx, bytes(c), 1 << 16)
     out, e = r.read_all(chunk=77_777)
     assert out == w[0] and ((e is None) == (w[1] >= 0))
+
+
+def test_readers_on_models_beyond_lds(ctx):
+    """lc+lp > 8 (the reference accepts lc <= 8, lp <= 4): no session (the model does not fit LDS), the reader
+    takes the whole-stream path with its HBM-resident model; bytes and status are the oracle's"""
+    import oracle
+    p = corpus.plain("T", 6900, 30_000)
+    c = bytearray(corpus.compress_alone(p))
+    c[0] = corpus.props_byte(8, 4, 2)
+    want = oracle.lzma1_alone(bytes(c), 60_000)
+    r, err = lzma_amd.NewReader1(ctx, bytes(c))
+    assert err is None
+    out, e = r.read_all(chunk=999)
+    assert out == want[0] and ((e is None) == (want[1] >= 0))
+    _, whole, _ = r.stats()
+    assert whole == 1
