@@ -599,21 +599,26 @@ struct HeadVec {
 __device__ __forceinline__ HeadVec head_vectors(uint32_t lane)
 {
     HeadVec h;
-    const uint32_t base = lane == 0 ? P_IS_MATCH
-                          : lane == 1 ? P_IS_REP
-                          : lane == 2 ? P_IS_REP_G0
-                          : lane == 3 ? P_IS_REP_G1
-                          : lane == 4 ? P_IS_REP_G2
-                          : lane == 5 ? P_IS_REP0_LONG
-                          : lane == 6 ? P_LEN + LEN_CHOICE
-                          : lane == 7 ? P_LEN + LEN_CHOICE2
-                          : lane == 8 ? P_REP_LEN + LEN_CHOICE
-                          : lane == 9 ? P_REP_LEN + LEN_CHOICE2
-                                      : P_LEN + 2; // lanes 10..63: an unused slot (their v40 is stored too)
+#ifdef XLZ_HEAD_DPP // A/B build (tools/gen_fastpath.py --variant hdpp): head probability j at lane 16 (j / 4) + 4 (j % 4)
+    const uint32_t hj = (lane % 4 == 0 && lane < 40) ? (lane / 16) * 4 + (lane % 16) / 4 : 10u;
+#else
+    const uint32_t hj = lane;
+#endif
+    const uint32_t base = hj == 0 ? P_IS_MATCH
+                          : hj == 1 ? P_IS_REP
+                          : hj == 2 ? P_IS_REP_G0
+                          : hj == 3 ? P_IS_REP_G1
+                          : hj == 4 ? P_IS_REP_G2
+                          : hj == 5 ? P_IS_REP0_LONG
+                          : hj == 6 ? P_LEN + LEN_CHOICE
+                          : hj == 7 ? P_LEN + LEN_CHOICE2
+                          : hj == 8 ? P_REP_LEN + LEN_CHOICE
+                          : hj == 9 ? P_REP_LEN + LEN_CHOICE2
+                                    : P_LEN + 2; // the other lanes: an unused slot (their v40 is stored too)
     h.hc = base * 2;
     h.lit_next = upd_literal(lane < 12 ? lane : 0); // stateUpdateLiteral as a table: lane = old state
-    h.hms = (lane >= 1 && lane <= 4) ? 2u : 0u; // indexed by state
-    h.hm2 = (lane == 0 || lane == 5) ? 2u : 0u; // indexed by state2 = (state << 4) + posState
+    h.hms = (hj >= 1 && hj <= 4) ? 2u : 0u; // indexed by state
+    h.hm2 = (hj == 0 || hj == 5) ? 2u : 0u; // indexed by state2 = (state << 4) + posState
     return h;
 }
 
@@ -637,7 +642,7 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_
           [vin] "v"(d.vin), [vlane] "v"(lane), [vhc] "v"(hv.hc), [vhms] "v"(hv.hms), [vhm2] "v"(hv.hm2),
           [vlitnext] "v"(hv.lit_next), [vlpm] "v"(vlpm), [vpm] "v"(vpm)
         : "scc", "vcc", "memory", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
-          "s93", "s94", "s95", "s96", "s97", "s98", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46",
+          "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46",
           "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62",
           "v63");
     return exitc;

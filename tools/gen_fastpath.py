@@ -58,6 +58,20 @@ LEN_CHOICE, LEN_CHOICE2, LEN_LOW, LEN_MID, LEN_HIGH = 0, 1, 4, 132, 260
 H_IS_MATCH, H_IS_REP, H_G0, H_G1, H_G2, H_REP0_LONG, H_LEN_C, H_LEN_C2, H_REP_C, H_REP_C2 = range(10)
 
 VARIANT = set()  # experimental code paths switched on from the command line (A/B builds)
+
+
+def hdpp_lane(j):
+    return 16 * (j // 4) + 4 * (j % 4)
+
+
+def pend():
+    """the SGPR that says a match copy is still in flight.  cflag: its length s95 itself (>= 1)"""
+    return "s95" if "cflag" in VARIANT else "s94"
+
+
+def lgather():
+    return "lgather" in VARIANT or "lit8g" in VARIANT
+
 lines = []
 stubs = []
 finish_sites = []
@@ -71,7 +85,18 @@ def emit(s):
             lines.append(l)
 
 
+ALIGNED = ("pktl", "match", "mlit", "rep")  # reached by branches only (the code in front ends in s_branch)
+
+
 def label(name):
+    for v in VARIANT:  # A/B: alignN pads the hot loop heads to 2^N bytes, salignN the normalisation stubs
+        if v.startswith("align") and name in ALIGNED:
+            lines.append(".p2align %s" % v[5:])
+            for w in VARIANT:  # offN: the literal loop's head N dwords behind the boundary
+                if w.startswith("off") and name == "pktl":
+                    lines.extend(["s_nop 0"] * int(w[3:]))
+        if v.startswith("salign") and name in stubs:
+            lines.append(".p2align %s" % v[6:])
     lines.append(".L%s_%%=:" % name)
 
 
@@ -155,11 +180,11 @@ def need_copy_done(inline=False):
     uid[0] += 1
     k = "f%d" % uid[0]
     if inline:  # a copy is nearly always pending here: no branch out and back
-        emit("s_cmp_eq_u32 s94, 0\ns_cbranch_scc1 %s" % L(k + "b"))
+        emit("s_cmp_eq_u32 %s, 0\ns_cbranch_scc1 %s" % (pend(), L(k + "b")))
         finish_body()
         label(k + "b")
         return
-    emit("s_cmp_eq_u32 s94, 0\ns_cbranch_scc0 %s" % L(k))
+    emit("s_cmp_eq_u32 %s, 0\ns_cbranch_scc0 %s" % (pend(), L(k)))
     label(k + "b")
     finish_sites.append(k)
 
@@ -175,8 +200,8 @@ def finish_body():
         s_sub_u32 s80, s95, 1
         v_readlane_b32 %[prev], v49, s80
         v_readlane_b32 %[mb], v49, s95
-        s_mov_b32 s94, 0
-        """)
+        s_mov_b32 PEND, 0
+        """.replace("PEND", pend()))
         return
     emit("""
     s_waitcnt vmcnt(0)
@@ -184,8 +209,8 @@ def finish_body():
     s_sub_u32 s80, s95, 1
     v_readlane_b32 %[prev], v49, s80
     v_readlane_b32 %[mb], v49, s95
-    s_mov_b32 s94, 0
-    """)
+    s_mov_b32 PEND, 0
+    """.replace("PEND", pend()))
 
 
 def emit_finish_blocks():
@@ -199,6 +224,17 @@ def head_update(lane, bit):
     """new value of head probability `lane` (decompress.go:30 / :177), VALU only: the lanes of v40
     all compute it from their own value, lane `lane` keeps it.  v40 goes back to LDS in one
     store when the packet is over (head_issue / exit)."""
+    if "hdpp" in VARIANT:
+        # head probability j sits alone in DPP cell (row j / 4, bank j % 4), lane 16 (j / 4) + 4 (j % 4): the
+        # last subtract writes only that cell (row_mask / bank_mask) -- no lane compare, no select
+        j = (lane // 16) * 4 + (lane % 16) // 4
+        assert lane == hdpp_lane(j)
+        if bit == 0:
+            emit("v_add_u32 v63, 0xfffff81f, v40\nv_ashrrev_i32 v63, 5, v63")
+        else:
+            emit("v_ashrrev_i32 v63, 5, v40")
+        emit("v_sub_u32_dpp v40, v40, v63 quad_perm:[0,1,2,3] row_mask:0x%x bank_mask:0x%x" % (1 << (j // 4), 1 << (j % 4)))
+        return
     emit("v_cmp_eq_u32 vcc, %d, %%[vlane]" % lane)
     if bit == 0:
         emit("v_add_u32 v63, 0xfffff81f, v40\nv_ashrrev_i32 v63, 5, v63")
@@ -331,7 +367,7 @@ def fetch_level(k, blocks):
 def level_rec(k=None):
     """decision of a recorded level on the probability in s86 (parked in lane k of v54)"""
     emit("s_lshr_b32 s80, %[range], 11\ns_mul_i32 s80, s80, s86")
-    if k is not None:
+    if k is not None and not lgather():
         emit("v_writelane_b32 v54, s86, %d" % k)
     decide()
     emit("s_addc_u32 s88, s88, s88")
@@ -341,7 +377,10 @@ def walk_rec(nbits, blocks, entries=None):
     """walk() for the 8-level trees: also parks the probability of level k in lane k of v54.
     entries = label prefix: entered at level k >= 1 through <prefix>k with s88 set."""
     if not entries:
-        emit("s_mov_b32 s88, 1\nv_readlane_b32 s86, %s, 1" % blocks[0])
+        if "flim" in VARIANT and blocks is LIT_BLOCKS:  # (the packet head set s88 = 1 in a wait state)
+            emit("v_readlane_b32 s86, %s, 1" % blocks[0])
+        else:
+            emit("s_mov_b32 s88, 1\nv_readlane_b32 s86, %s, 1" % blocks[0])
     for k in range(nbits):
         if entries:
             if k == 0:
@@ -407,11 +446,50 @@ def gather8(blocks, dst="v54"):
     """ % (blocks[0], blocks[1], blocks[2], blocks[3], dst, dst, dst))
 
 
-def tree_update_rec(nb, base, store=True):
+def rec_gather_issue(base, masked):
+    """lgather: nothing was recorded during the walk: the eight probabilities it met are read back from LDS
+    with ONE 8-lane gather at the addresses the update stores to anyway (instead of eight v_writelane),
+    issued as soon as the walk is over so that the round trip hides behind the literal's tail.
+    masked: VCC = lanes whose level was decided in the matched table (their v54 is the HBM gather).
+    v60 = the addresses (kept for the store), data -> v54 (masked: v33)."""
+    emit("""
+    v_lshrrev_b32 v60, v19, s88
+    v_lshl_add_u32 v60, v60, 1, %s
+    """ % base)
+    if masked:
+        emit("v_cndmask_b32 v60, v60, v38, vcc")
+    emit("""
+    v_cndmask_b32 v60, v38, v60, s[76:77]
+    ds_read_u16 %s, v60
+    """ % ("v33" if masked else "v54"))
+
+
+def tree_update_rec(nb, base, store=True, issued=False, pending=0, filler=None):
     """model updates of a walk_rec in ONE vector operation, lane k = level k: slot = s88 >> (8-k),
     !bit = (s88 >> (7-k)) & 1, p = v54; lanes >= 8 store to the unused slot (v38).  The per-lane
     shift counts 8-k and 7-k are v19 / v18, the lanes-below-8 mask is s[76:77] (loop constants)."""
     assert nb == 8
+    if lgather():
+        if not issued:
+            rec_gather_issue(base, masked=not store)
+            pending = 0
+        emit("""
+        v_bfe_u32 v61, s88, v18, 1
+        v_mul_u32_u24 v61, 0x7e1, v61
+        """)
+        if filler:
+            filler()  # independent work of the caller in front of the wait
+        emit("s_waitcnt lgkmcnt(%d)" % pending)
+        if not store:
+            emit("v_cndmask_b32 v54, v33, v54, vcc")
+        emit("""
+        v_sub_u32 v61, v54, v61
+        v_ashrrev_i32 v61, 5, v61
+        v_sub_u32 v61, v54, v61
+        """)
+        if store:
+            emit("ds_write_b16 v60, v61")
+        return
     emit("""
     v_lshrrev_b32 v60, v19, s88
     v_bfe_u32 v61, s88, v18, 1
@@ -504,36 +582,87 @@ def wpos_advance(amount):
     """window.pos += amount with the wrap of window.go:38-41 out of line"""
     uid[0] += 1
     k = "w%d" % uid[0]
-    emit("s_add_u32 %%[wpos], %%[wpos], %s\ns_cmp_ge_u32 %%[wpos], %%[dict]\ns_cbranch_scc1 %s" % (amount, L(k)))
+    if "flim" in VARIANT:  # s96 = the next EVENT in window.pos terms: the dictionary's end or the output limit
+        emit("s_add_u32 %%[wpos], %%[wpos], %s\ns_cmp_ge_u32 %%[wpos], s96\ns_cbranch_scc1 %s" % (amount, L(k)))
+    else:
+        emit("s_add_u32 %%[wpos], %%[wpos], %s\ns_cmp_ge_u32 %%[wpos], %%[dict]\ns_cbranch_scc1 %s" % (amount, L(k)))
     label(k + "b")
     wstubs.append(k)
+
+
+def event_limit():
+    """s96 = min(dictSize, window.pos + (pos_lim - pos)), the sum saturated"""
+    emit("""
+    s_sub_u32 s80, %[pos_lim], %[pos]
+    s_add_u32 s80, s80, %[wpos]
+    s_cselect_b32 s80, -1, s80
+    s_min_u32 s96, s80, %[dict]
+    """)
+
+
+def packet_limits(head_lane):
+    """the limit tests of a packet head + the lane read of the first decision's bound (bounds("v40") was
+    just emitted).  flim: ONE test -- the output limit is folded into the window-wrap test of the packet
+    before (wpos_advance), which turns s99 into -1."""
+    if "flim" in VARIANT:
+        emit("""
+        s_cmp_gt_i32 %%[arel], s99
+        v_readlane_b32 s80, v55, %d
+        s_cbranch_scc1 %s
+        s_mov_b32 s88, 1
+        """ % (head_lane, L("x0")))
+        return
+    emit("""
+    s_cmp_gt_u32 %%[arel], %%[arel_lim]
+    s_cbranch_scc1 %s
+    v_readlane_b32 s80, v55, %d
+    s_cmp_ge_u32 %%[pos], %%[pos_lim]
+    s_cbranch_scc1 %s
+    """ % (L("x0"), head_lane, L("x0")))
 
 
 def emit_wstubs():
     for k in wstubs:
         label(k)
+        if "flim" in VARIANT:
+            # window.pos wrapped (window.go:38-41) and / or the output limit is reached: the latter makes the
+            # next packet head leave (its input test cannot pass against s99 = -1)
+            emit("""
+            s_cmp_ge_u32 %%[wpos], %%[dict]
+            s_cbranch_scc0 %s
+            s_sub_u32 %%[wpos], %%[wpos], %%[dict]
+            """ % L(k + "n"))
+            label(k + "n")
+            emit("s_cmp_ge_u32 %[pos], %[pos_lim]\ns_cselect_b32 s99, -1, s99")
+            event_limit()
+            emit("s_branch %s" % L(k + "b"))
+            continue
         emit("s_sub_u32 %%[wpos], %%[wpos], %%[dict]\ns_branch %s" % L(k + "b"))
 
 
-def literal_context(prev_v=None):
+def literal_context(prev_v=None, part=None):
     """literal table base -> v39 (decompress.go:56-57; byte address in LDS) and its four 64-prob
     blocks requested.  All on the VALU: the scalar port is the busy one.  prev_v = VGPR that
-    already holds prevByte."""
-    if prev_v is None:
-        emit("v_mov_b32 v55, %[prev]")
-        prev_v = "v55"
-    emit("""
-    v_and_b32 v57, %%[wpos], %%[vlpm]
-    v_lshlrev_b32 v57, %%[lc], v57
-    v_lshrrev_b32 v55, %%[lc8], %s
-    v_add_lshl_u32 v57, v57, v55, 9
-    v_add_u32 v39, %d, v57
-    v_add_u32 v59, v39, v56
-    ds_read_u16 v50, v59
-    ds_read_u16 v51, v59 offset:128
-    ds_read_u16 v52, v59 offset:256
-    ds_read_u16 v53, v59 offset:384
-    """ % (prev_v, P_LIT * 2))
+    already holds prevByte.  part: "addr" / "reads" emit only the address arithmetic / the requests."""
+    if part != "reads":
+        if prev_v is None:
+            emit("v_mov_b32 v55, %[prev]")
+            prev_v = "v55"
+        emit("""
+        v_and_b32 v57, %%[wpos], %%[vlpm]
+        v_lshlrev_b32 v57, %%[lc], v57
+        v_lshrrev_b32 v55, %%[lc8], %s
+        v_add_lshl_u32 v57, v57, v55, 9
+        v_add_u32 v39, %d, v57
+        v_add_u32 v59, v39, v56
+        """ % (prev_v, P_LIT * 2))
+    if part != "addr":
+        emit("""
+        ds_read_u16 v50, v59
+        ds_read_u16 v51, v59 offset:128
+        ds_read_u16 v52, v59 offset:256
+        ds_read_u16 v53, v59 offset:384
+        """)
 
 
 def head_issue(first=False):
@@ -574,15 +703,24 @@ def literal_tail(run_entry=None):
 
 def plain_literal(run_entry=None):
     """plain literal (:127-175) with its blocks in v50..v53 and base in v39; ends at pktl"""
-    if "lit8" in VARIANT:
+    if "lit8" in VARIANT or "lit8g" in VARIANT:
         walk8(LIT_BLOCKS)
+        if lgather():
+            rec_gather_issue("v39", masked=False)
         literal_tail()
-        gather8(LIT_BLOCKS)
+        if "lit8" in VARIANT:
+            gather8(LIT_BLOCKS)
     else:
         walk_rec(8, LIT_BLOCKS)
+        if lgather():
+            rec_gather_issue("v39", masked=False)
         literal_tail(run_entry=run_entry)
-    tree_update_rec(8, "v39")
-    literal_context(prev_v="v32")
+    if lgather():  # behind the gather: the head's write and its next gather
+        tree_update_rec(8, "v39", issued=True, pending=2, filler=lambda: literal_context(prev_v="v32", part="addr"))
+        literal_context(part="reads")
+    else:
+        tree_update_rec(8, "v39")
+        literal_context(prev_v="v32")
     emit("s_branch %s" % L("pktl"))
 
 
@@ -594,13 +732,7 @@ def sec_packet_after_literal():
     label("pktl")
     emit("s_waitcnt lgkmcnt(0)")
     bounds("v40")
-    emit("""
-    s_cmp_gt_u32 %%[arel], %%[arel_lim]
-    s_cbranch_scc1 %s
-    v_readlane_b32 s80, v55, %d
-    s_cmp_ge_u32 %%[pos], %%[pos_lim]
-    s_cbranch_scc1 %s
-    """ % (L("x0"), H_IS_MATCH, L("x0")))
+    packet_limits(H_IS_MATCH)
     hbit(H_IS_MATCH, L("match"), stage=2)
     plain_literal(run_entry=L("lrent") if "litrun" in VARIANT else None)
 
@@ -682,19 +814,21 @@ def sec_packet_general():
     label("pkt")
     emit("s_waitcnt lgkmcnt(0)")
     bounds("v40")
-    emit("""
-    s_cmp_gt_u32 %%[arel], %%[arel_lim]
-    s_cbranch_scc1 %s
-    v_readlane_b32 s80, v55, %d
-    s_cmp_ge_u32 %%[pos], %%[pos_lim]
-    s_cbranch_scc1 %s
-    """ % (L("x0"), H_IS_MATCH, L("x0")))
+    packet_limits(H_IS_MATCH)
     hbit(H_IS_MATCH, L("match"), stage=2)
     # ------------------------------------------------------------- literal (decompress.go:44-175)
-    need_copy_done()
-    emit("s_cmp_lg_u32 s97, 0\ns_cbranch_scc1 %s" % L("litready"))
-    literal_context()
-    emit("s_waitcnt lgkmcnt(0)")
+    if "cflag" in VARIANT:
+        # `pkt` is reached from a copy (pending; prevByte unknown, so no literal blocks yet) or from the loop's
+        # entry (nothing pending, blocks requested there): one flag says both
+        emit("s_cmp_eq_u32 s95, 0\ns_cbranch_scc1 %s" % L("litready"))
+        finish_body()
+        literal_context()
+        emit("s_waitcnt lgkmcnt(0)")
+    else:
+        need_copy_done()
+        emit("s_cmp_lg_u32 s97, 0\ns_cbranch_scc1 %s" % L("litready"))
+        literal_context()
+        emit("s_waitcnt lgkmcnt(0)")
     label("litready")
     emit("s_cmp_ge_u32 %%[state], 7\ns_cbranch_scc1 %s" % L("mlit"))
     plain_literal()
@@ -736,25 +870,38 @@ def sec_packet_general():
     for k in range(1, 8):
         label("mx%d" % k)
         emit("s_mov_b32 s98, %d\ns_branch %s" % (k, L("pw%d" % k)))
-    if "lit8" in VARIANT:
+    if "lit8" in VARIANT or "lit8g" in VARIANT:
         walk8(LIT_BLOCKS, entries="pw")
     else:
         walk_rec(8, LIT_BLOCKS, entries="pw")
     label("mlfin")
+    if lgather():
+        emit("v_cmp_gt_u32 vcc, s98, %[vlane]")
+        rec_gather_issue("v39", masked=True)
     literal_tail()
     if "lit8" in VARIANT:  # levels decided in the plain table: their probabilities, gathered; v54 keeps the matched ones
         gather8(LIT_BLOCKS, dst="v33")
         emit("v_cmp_gt_u32 vcc, s98, %[vlane]\nv_cndmask_b32 v54, v33, v54, vcc")
     # lanes < s98 -> matched table (HBM; the rest to its unused slot 0), lanes s98..7 -> plain table
     emit("v_cmp_gt_u32 vcc, s98, %[vlane]")
-    tree_update_rec(8, "v39", store=False)
-    emit("""
-    v_cndmask_b32 v57, 0, v57, vcc
-    global_store_short v57, v61, %[mptr]
-    v_cndmask_b32 v60, v60, v38, vcc
-    v_cndmask_b32 v60, v38, v60, s[76:77]
-    ds_write_b16 v60, v61
-    """)
+    if lgather():
+        tree_update_rec(8, "v39", store=False, issued=True, pending=2)
+    else:
+        tree_update_rec(8, "v39", store=False)
+    if lgather():  # (v60 is masked already)
+        emit("""
+        v_cndmask_b32 v57, 0, v57, vcc
+        global_store_short v57, v61, %[mptr]
+        ds_write_b16 v60, v61
+        """)
+    else:
+        emit("""
+        v_cndmask_b32 v57, 0, v57, vcc
+        global_store_short v57, v61, %[mptr]
+        v_cndmask_b32 v60, v60, v38, vcc
+        v_cndmask_b32 v60, v38, v60, s[76:77]
+        ds_write_b16 v60, v61
+        """)
     literal_context(prev_v="v32")
     emit("s_branch %s" % L("pktl"))
 
@@ -935,14 +1082,16 @@ def sec_copy():
         global_load_ubyte v49, v61, %[outp]
         s_mov_b64 exec, -1
         """)
+    if "cflag" not in VARIANT:
+        emit("s_mov_b32 s94, 1")
     emit("""
-    s_mov_b32 s94, 1
     s_mov_b32 s95, s89
     s_add_u32 %[pos], %[pos], s89
     """)
     wpos_advance("s89")
     head_issue()  # next packet's head gather; its literal blocks wait for the copy (prevByte)
-    emit("s_mov_b32 s97, 0")  # falls into the general packet head
+    if "cflag" not in VARIANT:
+        emit("s_mov_b32 s97, 0")  # falls into the general packet head
 
 
 def sec_exits():
@@ -974,7 +1123,7 @@ def sec_exits():
 def gen():
     # The gathers of packet n+1 are issued from the tail of packet n (software pipelining):
     # by the time the loop top has done its limit checks the probabilities have arrived.
-    emit("v_lshlrev_b32 v56, 1, %%[vlane]\ns_mov_b32 s94, 0\nv_mov_b32 v38, %d\nv_mov_b32 v29, %%[code]" % ((P_LEN + 2) * 2))
+    emit("v_lshlrev_b32 v56, 1, %%[vlane]\ns_mov_b32 PEND, 0\nv_mov_b32 v38, %d\nv_mov_b32 v29, %%[code]".replace("PEND", pend()) % ((P_LEN + 2) * 2))
     # per-lane constants of tree_update: v31 = floor(log2(lane)) + 1, v30 = lane (lane 0: never a slot)
     emit("v_cmp_eq_u32 vcc, 0, %[vlane]\nv_ffbh_u32 v31, %[vlane]\nv_sub_u32 v31, 32, v31\n"
          "v_cndmask_b32 v30, %[vlane], -1, vcc")
@@ -1009,9 +1158,15 @@ def gen():
     s_nop 1
     v_cndmask_b32 v20, v20, 7, vcc
     """ % (P_POS_SLOT * 2))
+    if "flim" in VARIANT:
+        emit("s_mov_b32 s99, %[arel_lim]")
+        event_limit()
     head_issue(first=True)
     literal_context()  # no copy is pending on entry: prevByte is valid
-    emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
+    if "cflag" in VARIANT:
+        emit("s_branch %s" % L("pkt"))
+    else:
+        emit("s_mov_b32 s97, 1\ns_branch %s" % L("pkt"))
     # Layout: the match path runs straight through -- match, distance, copy, next packet's head --
     # and everything rarer is out of line (length coder's mid / high trees: deferred blocks; rep
     # matches).  A taken branch costs about as much as a scalar instruction plus a fetch bubble.
@@ -1051,6 +1206,9 @@ if __name__ == "__main__":
         VARIANT.update(v for v in sys.argv[sys.argv.index("--variant") + 1].split(",") if v)
     if "--out" in sys.argv:
         OUT = sys.argv[sys.argv.index("--out") + 1]
+    if "hdpp" in VARIANT:  # (xlz_kernel.hip: head_vectors under XLZ_HEAD_DPP uses the same lanes)
+        (H_IS_MATCH, H_IS_REP, H_G0, H_G1, H_G2, H_REP0_LONG, H_LEN_C, H_LEN_C2, H_REP_C, H_REP_C2) = \
+            [hdpp_lane(j) for j in range(10)]
     text, final, n_nops = render()
     with open(OUT, "w") as f:
         f.write(text)

@@ -7,6 +7,7 @@ emits for gfx950 and, for R1, by a decoder that went wrong without it):
   R3  VALU writes VCC             -> VALU reads VCC (v_cndmask, v_addc, ...):      2
   R4  VALU writes SGPR / VCC      -> v_readlane / v_writelane lane select:         4
   R6  VALU writes SGPR            -> VMEM reads it:                                5
+  R7  VALU writes VGPR            -> DPP instruction reads it as src0:             2
 A wait state is any instruction in between; s_nop N counts N + 1.
 
 check(lines) walks the straight-line order and every branch edge (a taken branch counts as one
@@ -50,8 +51,11 @@ class Ins:
         self.vmem = self.m.startswith("global_") or self.m.startswith("buffer_") or self.m.startswith("flat_")
         self.lane = self.m in ("v_readlane_b32", "v_writelane_b32")
         self.rdlane = self.m in ("v_readlane_b32", "v_readfirstlane_b32")
+        self.dpp = self.m.endswith("_dpp")
         self.branch = self.m.startswith("s_cbranch") or self.m in ("s_branch", "s_setpc_b64")
         self.ws = 1
+        if self.m.startswith("."):  # an assembler directive (.p2align): no instruction, no wait state
+            self.ws = 0
         if self.m == "s_nop":
             self.ws = int(ops[0]) + 1
         regs = [reg_of(o) for o in ops]
@@ -83,6 +87,8 @@ def need(prod, cons, reg):
     if reg.startswith("v:"):
         if cons.rdlane and reg in cons.reads:
             n = 1
+        if cons.dpp and cons.reads and cons.reads[0] == reg:
+            n = 2
         return n
     # SGPR or VCC written by a VALU instruction
     if cons.lane and cons.lanesel == reg:
