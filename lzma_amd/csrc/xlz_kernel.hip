@@ -599,10 +599,11 @@ struct HeadVec {
 __device__ __forceinline__ HeadVec head_vectors(uint32_t lane)
 {
     HeadVec h;
-#ifdef XLZ_HEAD_DPP // A/B build (tools/gen_fastpath.py --variant hdpp): head probability j at lane 16 (j / 4) + 4 (j % 4)
-    const uint32_t hj = (lane % 4 == 0 && lane < 40) ? (lane / 16) * 4 + (lane % 16) / 4 : 10u;
-#else
+#ifdef XLZ_HEAD_PLAIN // A/B build (tools/gen_fastpath.py --without hdpp): head probability j at lane j
     const uint32_t hj = lane;
+#else // head probability j alone in DPP cell (row j / 4, bank j % 4): lane 16 (j / 4) + 4 (j % 4); its update is
+      // written with row_mask / bank_mask instead of a lane compare and a select
+    const uint32_t hj = (lane % 4 == 0 && lane < 40) ? (lane / 16) * 4 + (lane % 16) / 4 : 10u;
 #endif
     const uint32_t base = hj == 0 ? P_IS_MATCH
                           : hj == 1 ? P_IS_REP

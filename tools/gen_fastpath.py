@@ -57,7 +57,16 @@ LEN_CHOICE, LEN_CHOICE2, LEN_LOW, LEN_MID, LEN_HIGH = 0, 1, 4, 132, 260
 # head gather lanes (the per-lane address constants are built in xlz_kernel.hip: head_vectors)
 H_IS_MATCH, H_IS_REP, H_G0, H_G1, H_G2, H_REP0_LONG, H_LEN_C, H_LEN_C2, H_REP_C, H_REP_C2 = range(10)
 
-VARIANT = set()  # experimental code paths switched on from the command line (A/B builds)
+# Code paths that can be switched from the command line for A/B builds (--variant a,b adds, --without a,b removes).
+# The defaults are what round 2 measured as best:
+#   lgather  literal walks record nothing; the eight probabilities are read back with one LDS gather
+#   hdpp     head probabilities sit alone in DPP cells: their update needs no lane compare / select
+#   flim     the output limit is folded into the window-wrap test: one limit test per packet head
+#   cflag    one SGPR says "copy pending" and "literal blocks not requested yet"
+#   bralign  tools/layout.py: conditional branches in the lower half of a 16-byte block; stub32 / head32 /
+#            pktl64: normalisation stubs, out-of-line blocks and the literal loop on 32 / 32 / 64-byte boundaries
+DEFAULT_VARIANT = {"lgather", "hdpp", "flim", "cflag", "bralign", "stub32", "head32", "pktl64"}
+VARIANT = set(DEFAULT_VARIANT)
 
 
 def hdpp_lane(j):
@@ -89,6 +98,11 @@ ALIGNED = ("pktl", "match", "mlit", "rep")  # reached by branches only (the code
 
 
 def label(name):
+    if "bralign" in VARIANT and name == "pktl":  # tools/layout.py lays the stream out from here
+        lines.append(".p2align %d" % (6 if "pktl64" in VARIANT else 5 if "pktl32" in VARIANT else 4))
+    for v in VARIANT:
+        if v.startswith("shift") and name == "pktl":  # A/B: everything behind the loop's entry code moves by N dwords
+            lines.extend(["s_nop 0"] * int(v[5:]))
     for v in VARIANT:  # A/B: alignN pads the hot loop heads to 2^N bytes, salignN the normalisation stubs
         if v.startswith("align") and name in ALIGNED:
             lines.append(".p2align %s" % v[5:])
@@ -1120,7 +1134,15 @@ def sec_exits():
 
 
 
+def set_head_lanes():
+    """lane of each head probability (xlz_kernel.hip: head_vectors builds the gather addresses for the same lanes)"""
+    global H_IS_MATCH, H_IS_REP, H_G0, H_G1, H_G2, H_REP0_LONG, H_LEN_C, H_LEN_C2, H_REP_C, H_REP_C2
+    lanes = [hdpp_lane(j) for j in range(10)] if "hdpp" in VARIANT else list(range(10))
+    (H_IS_MATCH, H_IS_REP, H_G0, H_G1, H_G2, H_REP0_LONG, H_LEN_C, H_LEN_C2, H_REP_C, H_REP_C2) = lanes
+
+
 def gen():
+    set_head_lanes()
     # The gathers of packet n+1 are issued from the tail of packet n (software pipelining):
     # by the time the loop top has done its limit checks the probabilities have arrived.
     emit("v_lshlrev_b32 v56, 1, %%[vlane]\ns_mov_b32 PEND, 0\nv_mov_b32 v38, %d\nv_mov_b32 v29, %%[code]".replace("PEND", pend()) % ((P_LEN + 2) * 2))
@@ -1191,6 +1213,20 @@ def render():
     gen()
     final, n_nops = hazards.fix(lines, verbose=bool(os.environ.get("XLZ_GEN_VERBOSE")))
     assert not hazards.analyse(final)
+    if "bralign" in VARIANT:
+        import layout
+        good = tuple(int(x) for x in os.environ.get("XLZ_LAYOUT_GOOD", "0,4").split(","))  # (experiments)
+        targets = []
+        for v in VARIANT:  # (experiments) stubN: normalisation stubs on N-byte boundaries, headN: the out-of-line blocks
+            if v.startswith("stub"):
+                targets.append((r"\.Ln\d+_%=:$", int(v[4:])))
+            if v.startswith("head"):
+                targets.append((r"\.L(match|mlit|rep|lmc2|lmhi|lrc2|lrhi|g1|g2|g3|r0long|dist|direct)_%=:$", int(v[4:])))
+        final, promos, nops, dead = layout.align_branches(final, good=good, targets=targets)
+        assert not hazards.analyse(final)
+        n, bad = layout.report(final)
+        print("layout: %d conditional branches, %d re-encoded instructions, %d s_nop (+%d never executed), %d left in an upper half"
+              % (n, promos, nops, dead, bad))
     text = ["// GENERATED by tools/gen_fastpath.py -- do not edit.  %d instructions, %d normalisation stubs.\n"
             % (sum(1 for l in final if not l.endswith(":")), len(stubs)),
             "// Included inside lzma_fast_loop() in xlz_kernel.hip as the body of one asm volatile statement.\n"]
@@ -1201,14 +1237,14 @@ def render():
 
 
 if __name__ == "__main__":
-    # dev: --variant a,b selects experimental code paths (VARIANT), --out writes another .inc for an A/B build
+    # dev: --variant a,b / --without a,b select code paths (VARIANT), --out writes another .inc for an A/B build
+    # (a build without hdpp also needs -DXLZ_HEAD_PLAIN for xlz_kernel.hip)
     if "--variant" in sys.argv:
         VARIANT.update(v for v in sys.argv[sys.argv.index("--variant") + 1].split(",") if v)
     if "--out" in sys.argv:
         OUT = sys.argv[sys.argv.index("--out") + 1]
-    if "hdpp" in VARIANT:  # (xlz_kernel.hip: head_vectors under XLZ_HEAD_DPP uses the same lanes)
-        (H_IS_MATCH, H_IS_REP, H_G0, H_G1, H_G2, H_REP0_LONG, H_LEN_C, H_LEN_C2, H_REP_C, H_REP_C2) = \
-            [hdpp_lane(j) for j in range(10)]
+    if "--without" in sys.argv:
+        VARIANT.difference_update(sys.argv[sys.argv.index("--without") + 1].split(","))
     text, final, n_nops = render()
     with open(OUT, "w") as f:
         f.write(text)
