@@ -643,7 +643,7 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_
           [vin] "v"(d.vin), [vlane] "v"(lane), [vhc] "v"(hv.hc), [vhms] "v"(hv.hms), [vhm2] "v"(hv.hm2),
           [vlitnext] "v"(hv.lit_next), [vlpm] "v"(vlpm), [vpm] "v"(vpm)
         : "scc", "vcc", "memory", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
-          "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46",
+          "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46",
           "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62",
           "v63");
     return exitc;

@@ -63,9 +63,11 @@ H_IS_MATCH, H_IS_REP, H_G0, H_G1, H_G2, H_REP0_LONG, H_LEN_C, H_LEN_C2, H_REP_C,
 #   hdpp     head probabilities sit alone in DPP cells: their update needs no lane compare / select
 #   flim     the output limit is folded into the window-wrap test: one limit test per packet head
 #   cflag    one SGPR says "copy pending" and "literal blocks not requested yet"
+#   tuc      tree_update's per-lane shift counts are loop constants
+#   vperm    normalisation: code = code << 8 | byte as one v_perm_b32 (no scalar mask of the byte)
 #   bralign  tools/layout.py: conditional branches in the lower half of a 16-byte block; stub32 / head32 /
 #            pktl64: normalisation stubs, out-of-line blocks and the literal loop on 32 / 32 / 64-byte boundaries
-DEFAULT_VARIANT = {"lgather", "hdpp", "flim", "cflag", "bralign", "stub32", "head32", "pktl64"}
+DEFAULT_VARIANT = {"lgather", "hdpp", "flim", "cflag", "tuc", "vperm", "bralign", "stub32", "head32", "pktl64"}
 VARIANT = set(DEFAULT_VARIANT)
 
 
@@ -132,11 +134,20 @@ def decide():
     one subtract with borrow-out gives code - bound and VCC = (code < bound), an unsigned min
     selects the new code; the scalar side only keeps what steers control: the range and
     SCC = (code < bound) = !bit, which the caller uses next (s_addc that advances a tree slot)."""
+    if "order1" in VARIANT:  # round 1's order: the VCC reader right behind its writer (measured 1.7-2.9 % slower)
+        emit("""
+        s_sub_u32 s81, %[range], s80
+        v_subrev_co_u32 v28, vcc, s80, v29
+        s_cmp_lg_u32 vcc_lo, 0
+        v_min_u32 v29, v29, v28
+        s_cselect_b32 %[range], s80, s81
+        """)
+        return
     emit("""
     s_sub_u32 s81, %[range], s80
     v_subrev_co_u32 v28, vcc, s80, v29
-    s_cmp_lg_u32 vcc_lo, 0
     v_min_u32 v29, v29, v28
+    s_cmp_lg_u32 vcc_lo, 0
     s_cselect_b32 %[range], s80, s81
     """)
 
@@ -150,6 +161,20 @@ def nchk(prefix=None, pick=None, mid=None, late_test=False):
     front of them."""
     uid[0] += 1
     k = "n%d" % uid[0]
+    if "vnorm" in VARIANT and not mid:
+        # the test on the VALU (v17 = 1 << 24) and the branch on VCC: one scalar-port instruction less per decision
+        if prefix:
+            label(k + "b")
+            prefix()
+            emit("v_cmp_lt_u32 vcc, %[range], v17")
+            if pick:
+                pick()
+            emit("s_cbranch_vccnz %s" % L(k))
+        else:
+            emit("v_cmp_lt_u32 vcc, %%[range], v17\ns_cbranch_vccnz %s" % L(k))
+            label(k + "b")
+        stubs.append(k)
+        return
     if prefix:
         label(k + "b")
         prefix()
@@ -173,10 +198,11 @@ def nchk(prefix=None, pick=None, mid=None, late_test=False):
 def emit_stubs():
     for k in stubs:
         label(k)
+        if "vperm" in VARIANT:  # code = code << 8 | next byte in ONE byte permute (v13 = the selector), no scalar mask
+            emit("s_lshl_b32 %[range], %[range], 8\nv_perm_b32 v29, v29, %[cur], v13")
+        else:
+            emit("s_lshl_b32 %[range], %[range], 8\ns_and_b32 s80, %[cur], 0xff\nv_lshl_or_b32 v29, v29, 8, s80")
         emit("""
-        s_lshl_b32 %%[range], %%[range], 8
-        s_and_b32 s80, %%[cur], 0xff
-        v_lshl_or_b32 v29, v29, 8, s80
         s_lshr_b32 %%[cur], %%[cur], 8
         s_add_u32 %%[arel], %%[arel], 1
         s_and_b32 s80, %%[arel], 3
@@ -345,9 +371,11 @@ def tree_update(nb, blocks, base="v58"):
     slots are stored (a block register may overlap other tables and be stale there); the other
     lanes store to the unused slot whose address is in v38.  Single-block trees."""
     own = "v30"
+    if "tuc" in VARIANT and nb in (3, 4, 6):  # nb - level(lane) is a loop constant: v14 / v15 / v16
+        emit("v_lshrrev_b32 v61, %s, s88" % {3: "v14", 4: "v15", 6: "v16"}[nb])
+    else:
+        emit("v_sub_u32 v55, %s, v31\nv_lshrrev_b32 v61, v55, s88" % nb)
     emit("""
-    v_sub_u32 v55, %s, v31
-    v_lshrrev_b32 v61, v55, s88
     v_lshrrev_b32 v60, 1, v61
     v_cmp_eq_u32 vcc, v60, %s
     v_and_b32 v61, 1, v61
@@ -358,7 +386,7 @@ def tree_update(nb, blocks, base="v58"):
     v_add_u32 v60, %s, v56
     v_cndmask_b32 v60, v38, v60, vcc
     ds_write_b16 v60, v61
-    """ % (nb, own, blocks[0], blocks[0], base))
+    """ % (own, blocks[0], blocks[0], base))
     assert len(blocks) == 1
 
 
@@ -1163,6 +1191,12 @@ def gen():
     v_bfrev_b32 v23, v23
     v_lshrrev_b32 v23, 28, v23
     """)
+    if "tuc" in VARIANT:
+        emit("v_sub_u32 v14, 3, v31\nv_sub_u32 v15, 4, v31\nv_sub_u32 v16, 6, v31")
+    if "vnorm" in VARIANT:
+        emit("v_mov_b32 v17, 0x1000000")
+    if "vperm" in VARIANT:
+        emit("v_mov_b32 v13, 0x06050400")
     # constants of tree_update_rec
     emit("v_sub_u32 v19, 8, %[vlane]\nv_sub_u32 v18, 7, %[vlane]\nv_cmp_gt_u32 s[76:77], 8, %[vlane]")
     if "lit8" in VARIANT:
