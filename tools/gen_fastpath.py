@@ -64,10 +64,11 @@ H_IS_MATCH, H_IS_REP, H_G0, H_G1, H_G2, H_REP0_LONG, H_LEN_C, H_LEN_C2, H_REP_C,
 #   flim     the output limit is folded into the window-wrap test: one limit test per packet head
 #   cflag    one SGPR says "copy pending" and "literal blocks not requested yet"
 #   tuc      tree_update's per-lane shift counts are loop constants
+#   rlhoist  literal walk: the next level's probability is read in front of the normalisation branch
 #   vperm    normalisation: code = code << 8 | byte as one v_perm_b32 (no scalar mask of the byte)
 #   bralign  tools/layout.py: conditional branches in the lower half of a 16-byte block; stub32 / head32 /
 #            pktl64: normalisation stubs, out-of-line blocks and the literal loop on 32 / 32 / 64-byte boundaries
-DEFAULT_VARIANT = {"lgather", "hdpp", "flim", "cflag", "tuc", "vperm", "bralign", "stub32", "head32", "pktl64"}
+DEFAULT_VARIANT = {"lgather", "hdpp", "flim", "cflag", "tuc", "vperm", "rlhoist", "bralign", "stub32", "head32", "pktl64"}
 VARIANT = set(DEFAULT_VARIANT)
 
 
@@ -129,11 +130,22 @@ def bounds(src, dst="v55"):
     emit("v_lshrrev_b32 %s, 11, %%[range]\nv_mul_u32_u24 %s, %s, %s" % (dst, dst, dst, src))
 
 
-def decide():
+def decide(scalar_bound=False):
     """One decision against bound s80.  The CODE lives in v29 (wave-uniform) for the whole loop:
     one subtract with borrow-out gives code - bound and VCC = (code < bound), an unsigned min
     selects the new code; the scalar side only keeps what steers control: the range and
     SCC = (code < bound) = !bit, which the caller uses next (s_addc that advances a tree slot)."""
+    if "order3" in VARIANT and scalar_bound:
+        # the bound came from s_mul (no lane read two slots ahead that the VALU compare would have to keep its
+        # distance from): the scalar subtract moves behind the compare, the VCC reader one slot further away
+        emit("""
+        v_subrev_co_u32 v28, vcc, s80, v29
+        s_sub_u32 s81, %[range], s80
+        v_min_u32 v29, v29, v28
+        s_cmp_lg_u32 vcc_lo, 0
+        s_cselect_b32 %[range], s80, s81
+        """)
+        return
     if "order1" in VARIANT:  # round 1's order: the VCC reader right behind its writer (measured 1.7-2.9 % slower)
         emit("""
         s_sub_u32 s81, %[range], s80
@@ -411,13 +423,14 @@ def level_rec(k=None):
     emit("s_lshr_b32 s80, %[range], 11\ns_mul_i32 s80, s80, s86")
     if k is not None and not lgather():
         emit("v_writelane_b32 v54, s86, %d" % k)
-    decide()
+    decide(scalar_bound=True)
     emit("s_addc_u32 s88, s88, s88")
 
 
 def walk_rec(nbits, blocks, entries=None):
-    """walk() for the 8-level trees: also parks the probability of level k in lane k of v54.
-    entries = label prefix: entered at level k >= 1 through <prefix>k with s88 set."""
+    """walk() for the 8-level trees (scalar bound: the probability is read with v_readlane, the bound formed
+    with s_lshr / s_mul).  entries = label prefix: entered at level k >= 1 through <prefix>k with s88 set."""
+    hoist = "rlhoist" in VARIANT and (not entries or "pwhoist" in VARIANT)
     if not entries:
         if "flim" in VARIANT and blocks is LIT_BLOCKS:  # (the packet head set s88 = 1 in a wait state)
             emit("v_readlane_b32 s86, %s, 1" % blocks[0])
@@ -427,9 +440,27 @@ def walk_rec(nbits, blocks, entries=None):
         if entries:
             if k == 0:
                 continue
-            label("%s%d" % (entries, k))
-            fetch_level(k, blocks)
+            if hoist:
+                label("%sd%d" % (entries, k))  # level k with its probability already in s86
+            else:
+                label("%s%d" % (entries, k))
+                fetch_level(k, blocks)
         level_rec(k)
+        if hoist and k + 1 < nbits:
+            # the next level's probability is read in front of the normalisation branch: the lane read's result
+            # has the branch between it and its first use (s_mul)
+            uid[0] += 1
+            kk = "n%d" % uid[0]
+            if k + 1 == 7:  # (its block select uses SCC)
+                fetch_level(k + 1, blocks)
+                emit("s_lshr_b32 s81, %[range], 24")
+            else:
+                emit("s_lshr_b32 s81, %[range], 24")
+                fetch_level(k + 1, blocks)
+            emit("s_cbranch_scc0 %s" % L(kk))
+            label(kk + "b")  # (the stub changes neither the slot nor the probability read for it)
+            stubs.append(kk)
+            continue
         nchk()
         if k + 1 < nbits and not entries:
             fetch_level(k + 1, blocks)
@@ -911,7 +942,12 @@ def sec_packet_general():
     emit("s_mov_b32 s98, 8\ns_branch %s" % L("mlfin"))
     for k in range(1, 8):
         label("mx%d" % k)
-        emit("s_mov_b32 s98, %d\ns_branch %s" % (k, L("pw%d" % k)))
+        if "pwhoist" in VARIANT and "rlhoist" in VARIANT and "lit8" not in VARIANT and "lit8g" not in VARIANT:
+            emit("s_mov_b32 s98, %d" % k)  # the plain walk's levels expect their probability in s86
+            fetch_level(k, LIT_BLOCKS)
+            emit("s_branch %s" % L("pwd%d" % k))
+        else:
+            emit("s_mov_b32 s98, %d\ns_branch %s" % (k, L("pw%d" % k)))
     if "lit8" in VARIANT or "lit8g" in VARIANT:
         walk8(LIT_BLOCKS, entries="pw")
     else:
