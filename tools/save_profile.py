@@ -49,17 +49,17 @@ entry = {
         "valu_per_cu_cycle": round(mean("SQ_INSTS_VALU") / cu_cycles, 4),
         "branch_per_cu_cycle": round(mean("SQ_INSTS_BRANCH") / cu_cycles, 4),
         "lds_per_cu_cycle": round(mean("SQ_INSTS_LDS") / cu_cycles, 4),
-        # measured ceilings (tools/ubench/thr2.hip): 0.96 scalar-port instructions and 1.0 wave64 VALU
-        # instructions per CU cycle; SALU + branch share the scalar port (lane reads, counted as VALU
-        # here, take ~0.7 of a scalar slot each on top)
-        "scalar_port_utilisation": round((mean("SQ_INSTS_SALU") + mean("SQ_INSTS_BRANCH")) / cu_cycles / 0.96, 4),
-        "vector_pipe_utilisation": round(mean("SQ_INSTS_VALU") / cu_cycles / 1.0, 4),
+        # measured ceilings (tools/ubench/mix2.hip, 16 waves per CU): 0.97 SALU and 1.28 simple wave64 VALU
+        # instructions per CU cycle, both reachable at once by a strictly alternating stream.  Branches are not
+        # on the SALU port (SALU + branch exceeds 0.97 on incompressible data).
+        "salu_utilisation": round(mean("SQ_INSTS_SALU") / cu_cycles / 0.97, 4),
+        "valu_utilisation": round(mean("SQ_INSTS_VALU") / cu_cycles / 1.28, 4),
         "instructions_per_decoded_byte": round((mean("SQ_INSTS_SALU") + mean("SQ_INSTS_VALU") + mean("SQ_INSTS_BRANCH") +
                                                mean("SQ_INSTS_LDS") + mean("SQ_INSTS_VMEM")) /
                                               (line["config"]["streams_per_gpu"] * line["config"]["bytes_per_stream"]), 2),
         # SQ_WAVE_CYCLES counts in quad-cycles per wave: x4 / (slots x kernel cycles) = average slot occupancy
         "slot_occupancy": round(mean("SQ_WAVE_CYCLES") * 4 / (grid * kernel_ms / 1e3 * CLK), 4),
-        "budget": "one scalar-port instruction and one wave64 VALU instruction per CU cycle (tools/ubench/thr2.hip); "
+        "budget": "measured ceilings per CU cycle: 0.97 SALU, 1.28 VALU (tools/ubench/mix2.hip); "
                   "clock %.1f GHz, %d CUs, kernel_ms %.3f" % (CLK / 1e9, CUS, kernel_ms),
         "source": dest + "_pmc.csv",
     },
