@@ -8,7 +8,9 @@ hand invites typos; this script is the source, the .inc file is committed next t
 
 The loop decodes whole packets (decompress.go:13 ff.) while
     arel <= arel_lim   (>= 32 readable bytes left in the 256-byte input window)
-    pos  <  pos_lim    (>= 336 bytes of output room and of bytesLeft)
+    pos  <  pos_lim    (>= 336 bytes of output room and of bytesLeft; tested where window.pos is
+                        advanced, together with the dictionary wrap: reaching it makes the NEXT packet
+                        head leave through the input test, see wpos_advance / packet_limits)
 and leaves with an exit code:
     0  a limit was reached at a packet boundary (caller refills the window / re-checks)
     1  ErrResultError condition (bad distance, rep match on an empty window)
@@ -22,25 +24,31 @@ inside the loop.
 How the 64 lanes are used (the wave is the register file of ONE decoder):
   * head gather: one ds_read with per-lane addresses fetches the ten context-selected
     probabilities a packet can start with (isMatch, isRep, isRepG0-2, isRep0Long, the four
-    length `choice` bits) into v40; a decision takes its probability with v_readlane.
+    length `choice` bits) into v40, each alone in a DPP cell (lane 16 (j / 4) + 4 (j % 4)); a
+    decision takes its bound with v_readlane from the VALU product of all of them, the update
+    is written with row_mask / bank_mask.
   * tree blocks: one ds_read fetches 64 consecutive probabilities of a bit tree (lane j =
-    slot 64b + j).  A tree level is then eight scalar instructions plus
-    `v_readlane p, block, M`: the lane select IS the node index, so neither the decoded bit
-    nor an LDS address is ever formed.  Blocks are requested well before they are walked.
-  * the probabilities met on a walk are found again in the block registers (ds_bpermute, the
-    slots of all levels follow from the final slot) and updated together in one vector
-    operation (tree_update), lanes = levels.
+    slot 64b + j).  A tree level is then a handful of scalar instructions plus one
+    `v_readlane`: the lane select IS the node index, so neither the decoded bit nor an LDS
+    address is ever formed.  Blocks are requested well before they are walked.
+  * model updates need no record of the walk: single-block trees find the visited slots again in
+    the block register (tree_update, every lane looks at its own slot); the 8-level trees read the
+    eight probabilities back from LDS with one gather (rec_gather_issue / tree_update_rec).
   * match copy: one byte per lane; its completion (store + prevByte/matchByte) is deferred
     behind the next packet's decode.
+After generation tools/hazards.py inserts the wait states the assembler does not, and tools/layout.py
+places every conditional branch in the lower half of a 16-byte block (measured: DESIGN.md 3.2).
 
 Register conventions (fixed temporaries, declared as clobbers in xlz_kernel.hip):
-  s80 bound, s81 core temps   s82..s86 temps   s87 code - bound   s88 tree slot (1, then !bits)
+  s80 bound, s81 core temps   s82..s86 temps   s88 tree slot (1, then !bits)
   s89 LEN   s90 posState   s91 state2   s92 table base (bytes)   s93 dist
-  s94 copy pending   s95 its length
-  s97 literal blocks prefetched   s98 posSlot / nbits
+  s95 length of the pending copy (0: none)   s96 next event of window.pos (wrap or output limit)
+  s98 posSlot / nbits   s99 input limit (-1 once the output limit is reached)
+  v13 v_perm selector   v14..v16 tree_update shift counts   v18,v19 tree_update_rec shift counts
+  v20..v25 lane tables   v28 code - bound   v29 code   v30,v31 tree_update lane constants
   v35 align block   v36 posSlot block   v37 posDecoders block   v40 head probabilities
   v41,v42 len low/mid blocks   v43..v46 len high blocks   v47 head addresses
-  v48,v49 pending copy (destination, bytes)   v50..v53 literal blocks   v54 walk record
+  v48,v49 pending copy (destination, bytes)   v50..v53 literal blocks   v54 gathered walk
   v55 temp   v56 2*lane   v57 address temp   v58 walk base   v59 gather address
   v60..v63 temps
 """
