@@ -1174,6 +1174,7 @@ struct Session {
     uint64_t consumed = 0;      // input bytes the decoder has read
     bool started = false;
     size_t payload_off = 0;     // where the unit's input starts inside reader.in (header stripped)
+    uint64_t left = kUnknownSize; // bytes the stream can still produce (known unpack size), or unknown
 };
 
 struct xlz_reader {
@@ -1305,6 +1306,7 @@ int session_open(xlz_reader *r)
     // slide in; such a stream decodes while it fits and is refused beyond (session_prepare)
     if (ss->win_max > kMaxUnitBytes) ss->win_max = (size_t)kMaxUnitBytes;
     ss->win_cap = std::min<size_t>(ss->win_max, 2 * kChunk + kWinSlack);
+    ss->left = known;
     ss->in_buf = r->streaming ? kInBuf : std::min<size_t>(kInBuf, align_up(r->src_len - ss->payload_off + 16, 256) + kArenaTailPad);
     ss->off_state = kCtlHead;
     ss->off_in = align_up(ss->off_state + state_bytes(ss->model_lc_lp), 256);
@@ -1327,11 +1329,13 @@ int session_prepare(xlz_reader *r, hipStream_t stream)
 {
     Session *ss = r->ss;
     Unit &u = ss->unit;
-    // ---- output window
-    if ((size_t)ss->pos + kChunk + kWinSlack > ss->win_cap) {
+    // ---- output window: room for what this refill can produce (a stream of known size that ends inside the
+    // refill needs only its rest: its window was sized by that, session_open)
+    const size_t need = ss->left == kUnknownSize ? kChunk : (size_t)std::min<uint64_t>(kChunk, ss->left);
+    if ((size_t)ss->pos + need + kWinSlack > ss->win_cap) {
         const size_t keep = std::min<size_t>(ss->pos, u.dict_size);
         if (ss->win_cap < ss->win_max) { // grow (the history may still be shorter than the dictionary)
-            size_t want = std::min(ss->win_max, std::max(ss->win_cap * 2, (size_t)ss->pos + kChunk + kWinSlack));
+            size_t want = std::min(ss->win_max, std::max(ss->win_cap * 2, (size_t)ss->pos + need + kWinSlack));
             uint8_t *nw = nullptr;
             if (hipMalloc(&nw, want) != hipSuccess) return XLZ_ERR_DEVICE;
             if (hipMemcpyAsync(nw, ss->d_win, ss->pos, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
@@ -1343,7 +1347,7 @@ int session_prepare(xlz_reader *r, hipStream_t stream)
             ss->d_win = nw;
             ss->win_cap = want;
         }
-        if ((size_t)ss->pos + kChunk + kWinSlack > ss->win_cap) {
+        if ((size_t)ss->pos + need + kWinSlack > ss->win_cap) {
             // full size reached: only the last dictSize bytes can still be referenced (window.go:18-29);
             // win_max = 2 * dictSize + ... guarantees source and destination do not overlap
             if ((size_t)ss->pos - keep < keep) return XLZ_ERR_UNSUPPORTED; // dictionary > 2 GiB on a stream > 4 GiB
@@ -1490,6 +1494,7 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs)
                 st = XLZ_ERR_DEVICE;
             ss->pos = new_pos;
             r->delivered += fresh;
+            if (ss->left != kUnknownSize) ss->left -= std::min<uint64_t>(ss->left, fresh);
             if (u.status != ST_PAUSED) {
                 r->finished = true;
                 r->status = u.status;
@@ -1982,6 +1987,7 @@ extern "C" int xlz_reader_reopen(xlz_reader *r, const uint8_t *in, size_t in_len
     ss->unit.unpack_size = unpack_size;
     // a known size no longer bounds the window: the new stream appends to it
     ss->win_max = 2 * (size_t)ss->unit.dict_size + kChunk + kWinSlack;
+    ss->left = kUnknownSize; // (every refill gets room for a full kChunk again)
     if (ss->in_buf < kInBuf) { // the input window was sized for the first stream
         uint8_t *nc = nullptr;
         std::lock_guard<std::mutex> lock(r->ctx->mu);

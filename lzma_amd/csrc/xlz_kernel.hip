@@ -797,8 +797,10 @@ __device__ __forceinline__ void reload_context(Dec &d, const uint8_t *__restrict
         if (d.epochs) {
             const uint32_t sb = stale_byte(out, d, fill + d.dict_size - dist, !ok && !full && valid);
             b = (!ok && !full && valid) ? sb : b;
-        } else if (__builtin_amdgcn_readlane((int)(uint32_t)(!ok && !full), 1)) {
-            d.stale = 1; // matchByte would come from an earlier epoch (prevByte is 0 on an empty window)
+        } else if (d.state >= 7 && __builtin_amdgcn_readlane((int)(uint32_t)(!ok && !full), 1)) {
+            // matchByte would come from an earlier epoch (prevByte is 0 on an empty window).  Only a literal in a
+            // match state reads it (decompress.go:59), and every copy on the way to such a state loads its own.
+            d.stale = 1;
         }
     }
     d.prev_byte = (uint32_t)__builtin_amdgcn_readlane((int)b, 0);

@@ -334,6 +334,64 @@ def test_streaming_input_edge_cases(ctx):
     assert e is None and out == p
 
 
+def test_known_size_streams_refilled_more_than_once(ctx):
+    """a stream of known size gets a window of its size only (session_open): a refill that stops early --
+    input fed 64 bytes at a time, or simply a stream longer than one refill but shorter than
+    2 x dictSize + one refill -- must ask for room for the REST of the stream, not for a full refill
+    (found by tools/fuzz_readers.py: the reader reported XLZ_ERR_UNSUPPORTED after 83 bytes)."""
+    import io
+    p = corpus.plain("T", 6800, 1 << 20)
+    blob = corpus.compress_alone(p, dict_size=6144, lc=0, lp=1, pb=4, known_size=True, preset=0)
+    for piece in (64, 100, 300):
+        r, err = lzma_amd.NewReader1(ctx, io.BytesIO(blob), piece=piece)
+        assert err is None
+        out, e = r.read_all(chunk=5000)
+        assert e is None and out == p, piece
+    p = corpus.plain("M", 6801, 5 << 20)   # five refills, an 8 MiB dictionary: the window is 5 MiB + slack
+    blob = corpus.compress_alone(p, dict_size=8 << 20, known_size=True, preset=0)
+    r, err = lzma_amd.NewReader1(ctx, blob)
+    out, e = r.read_all(chunk=100_000)
+    assert e is None and out == p
+    r, err = lzma_amd.NewReader1(ctx, io.BytesIO(blob), piece=50_000)
+    out, e = r.read_all(chunk=1 << 20)
+    assert e is None and out == p
+
+
+def test_unused_match_byte_behind_a_dictionary_reset_is_not_a_stale_read(ctx):
+    """tools/fuzz_readers.py find (tests/golden/fuzz_reader_11_316.lzma2, a VALID crafted stream): stored
+    chunks that reset the dictionary, followed by a chunk that resets the state.  rep0 still points behind
+    the reset, but no literal in a match state follows, so nothing reads there: the session must decode
+    it itself (no whole-stream fallback), also when the input arrives in pieces (where there is none)."""
+    import io
+    import os
+    import oracle
+    blob = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_reader_11_316.lzma2"), "rb").read()
+    want = oracle.lzma2_raw(blob, 65536, 1 << 20)
+    assert want[1] == 0 and len(want[0]) == 7711
+    r, err = lzma_amd.NewReader2(ctx, blob, 65536)
+    out, e = r.read_all(chunk=5000)
+    assert e is None and out == want[0]
+    assert r.stats()[1] == 0
+    for piece in (500, 1000, 2000):
+        r, err = lzma_amd.NewReader2(ctx, io.BytesIO(blob), 65536, piece=piece)
+        out, e = r.read_all(chunk=3000)
+        assert e is None and out == want[0], piece
+
+
+def test_reader_fuzz_against_the_oracle(ctx):
+    """tools/fuzz_readers.py for a few seconds: the generators of the batch fuzzer, read through
+    NewReader1 / NewReader2 from bytes or from a file object in pieces of 64 B .. 1 MiB with random Read
+    sizes -- bytes delivered and the way the reader ends against the oracle."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_readers", os.path.join(root, "tools", "fuzz_readers.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, n_err = mod.fuzz(ctx, budget=10.0, seed=20251005, verbose=False)
+    assert n >= 20
+
+
 def test_reader2_decodes_dictionary_reset_units_in_parallel(ctx):
     """NewReader2 on an LZMA2 stream of many dictionary-reset units (multi-threaded encoders, BASELINE
     config 4): runs of whole units go through the batch path -- a wave per unit -- instead of one wave
