@@ -26,6 +26,27 @@ def test_committed_inc_is_generated_and_hazard_free():
     assert n_nops < 20  # instruction order, not s_nop, is what satisfies the wait states
 
 
+def test_committed_layout_keeps_conditional_branches_in_lower_halves():
+    """tools/layout.py: behind the alignment directive every conditional branch of the committed
+    loop sits at address mod 16 = 0 or 4 -- checked with the assembler's own instruction sizes -- and the pass
+    got there almost without executed padding."""
+    g = _load()
+    text, final, _ = g.render()
+    import layout
+    n, bad = layout.report(final)
+    assert n > 250 and bad == 0
+    start = next(i for i, l in enumerate(final) if l.startswith(".p2align"))
+    assert sum(1 for l in final[start:] if l.endswith("_e64") or "_e64 " in l) > 20   # re-encoded, not padded
+    # the pass itself, on a toy stream: one promotion moves the branch from offset 12 to 16
+    toy = [".p2align 4", "s_mov_b32 s80, 1", "v_add_u32 v1, v2, v3", "s_mov_b32 s81, 2", "s_cbranch_scc1 .Lx_%=", ".Lx_%=:"]
+    out, promos, nops, dead = layout.align_branches(toy)
+    assert promos == 1 and nops == 0 and "v_add_u32_e64 v1, v2, v3" in out
+    # nothing to re-encode: padding, behind an unconditional branch if there is one (never executed)
+    toy = [".p2align 4", "s_mov_b32 s80, 1", "s_branch .Ly_%=", ".Ly_%=:", "s_mov_b32 s81, 2", "s_cbranch_scc1 .Lx_%=", ".Lx_%=:"]
+    out, promos, nops, dead = layout.align_branches(toy)
+    assert (promos, nops, dead) == (0, 0, 1) and out[3] == "s_nop 0"
+
+
 def test_hazard_checker_sees_the_known_cases():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import hazards
