@@ -62,3 +62,43 @@ def test_lzma1_assets_and_every_truncation_of_one():
         blob = open(os.path.join(g, fn), "rb").read()
         for cut in range(13, len(blob), 7):
             assert lzma_pydec.lzma1_alone(blob[:cut]) == oracle.lzma1_alone(blob[:cut], 1 << 20), (fn, cut)
+
+
+def test_damaged_liblzma_streams_lzma1_and_lzma2():
+    """real compressor output (liblzma), small, with truncations and bit flips: the error paths of both
+    restatements -- distances beyond the window, rep matches on an empty window, markers with a non-zero
+    code, sizes that do not add up -- agree"""
+    import corpus
+    rnd = random.Random(77)
+    n_bad = 0
+    for k in range(140):
+        fam = "TRMZ"[k % 4]
+        p = corpus.plain(fam, 9000 + k, rnd.choice([1, 40, 700, 2500]))
+        lc = rnd.randrange(0, 5)
+        lp = rnd.randrange(0, 5 - lc)
+        pb = rnd.randrange(0, 5)
+        if k % 3:
+            blob = bytearray(corpus.compress_alone(p, dict_size=rnd.choice([4096, 5000, 65536]), lc=lc, lp=lp, pb=pb,
+                                                   known_size=bool(k % 2), preset=0))
+            if k % 5:
+                for _ in range(rnd.randrange(1, 3)):
+                    blob[rnd.randrange(13 if k % 7 else 0, len(blob))] ^= 1 << rnd.randrange(8)
+            if k % 11 == 0:
+                blob = blob[: rnd.randrange(1, len(blob))]
+            blob = bytes(blob)
+            want = oracle.lzma1_alone(blob, 1 << 22)
+            if want[1] == oracle.ERR_OUT_CAP:
+                continue
+            assert lzma_pydec.lzma1_alone(blob) == want, k
+        else:
+            ds = rnd.choice([4096, 65536])
+            blob = bytearray(corpus.lzma2_concat([p, p[: len(p) // 2] or p], dict_size=ds, lc=lc, lp=lp, pb=pb))
+            if k % 2:
+                blob[rnd.randrange(len(blob))] ^= 1 << rnd.randrange(8)
+            blob = bytes(blob)
+            want = oracle.lzma2_raw(blob, ds, 1 << 22)
+            if want[1] == oracle.ERR_OUT_CAP:
+                continue
+            assert lzma_pydec.lzma2_raw(blob, ds) == want, k
+        n_bad += want[1] < 0
+    assert n_bad > 15
