@@ -3,6 +3,10 @@ against the CPU oracle (dev tool, run on the GPU box).  Same stream generators a
 every stream is read through NewReader1 / NewReader2 -- from bytes or from a file object in pieces --
 with random Read sizes, and compared with the oracle on the bytes delivered and on how the reader ends
 (io.EOF, or the error the oracle's status names; constructor errors included).
+Two more modes take a share of the time: (b) `Reopen` -- a raw LZMA1 stream A cut at a random byte (clean io.EOF
+inside a packet), then (*Reader1).Reopen on a stream B that continues A's model and window, against the oracle
+on the LZMA2 stream E0(A cut) 80(B) that means the same (reader2.go:155-167); (c) eight readers at once on a
+context with xlz_ctx_enable_batching (their refills share launches), each against the oracle.
 usage: python tools/fuzz_readers.py [seconds] [seed]"""
 import io
 import os
@@ -72,13 +76,127 @@ def one_stream(rng):
     return 2, c, d2
 
 
+def reopen_case(ctx, rng):
+    """-> None or a failure text"""
+    import struct
+    from lzma_craft import Encoder, Window, lzma2_lzma_chunk, props_byte
+    r = random.Random(int(rng.integers(1, 1 << 62)))
+    lc, lp, pb = r.choice([(3, 0, 2), (0, 0, 0), (1, 1, 1), (0, 2, 0), (4, 0, 0)])
+    ds = r.choice([4096, 8192, 65536])
+    w = Window(ds)
+    e = Encoder(lc, lp, pb, ds, window=w)
+
+    def packets(n):
+        for _ in range(n):
+            x = r.random()
+            fill = w.size if w.full else w.pos
+            if w.empty() or x < 0.4:
+                e.literal(r.randrange(256) if r.random() < 0.3 else r.choice(b"abcde "))
+            elif x < 0.6:
+                e.match(r.randint(1, min(fill, ds)), r.choice([2, 3, 4, 8, 9, 17, 18, 40, 64, 65, 273]))
+            elif x < 0.75:
+                e.short_rep()
+            else:
+                e.rep(r.randrange(4), r.choice([2, 3, 9, 16, 17, 70, 273]))
+    packets(r.randint(20, 400))
+    pay_a, n_a = e.payload(), len(w.total)
+    e.new_chunk()
+    packets(r.randint(5, 200))
+    pay_b, n_b = e.payload(), len(w.total) - n_a
+    if n_b == 0 or len(pay_a) < 8:
+        return None
+    cut = r.choice([0, 0, 1, 2, 3, 5, 9, r.randrange(1, len(pay_a) - 5)])
+    pa = pay_a[: max(6, len(pay_a) - cut)]
+    framed = lzma2_lzma_chunk(0xE0, n_a, pa, props_byte(lc, lp, pb)) + lzma2_lzma_chunk(0x80, n_b, pay_b) + b"\x00"
+    want, status, _ = oracle.lzma2_raw(framed, ds, n_a + n_b + 1024)
+    rd, err = lzma_amd.NewLZMADecompressorForSevenZip(ctx, bytes([props_byte(lc, lp, pb)]) + struct.pack("<I", ds), n_a, [pa])
+    if rd is None:
+        return "constructor error %r" % getattr(err, "status", err)
+    rd.__class__ = lzma_amd.Reader1
+    out_a, e1 = rd.read_all(chunk=r.choice([1, 100, 4096, 70000]))
+    if e1 is not None and cut:
+        return None if status < 0 and out_a == want else "A (cut %d) ended with %r" % (cut, getattr(e1, "status", e1))
+    if e1 is not None:
+        return "A ended with %r" % getattr(e1, "status", e1)
+    if out_a != want[: len(out_a)]:
+        return "A's bytes differ"
+    e0 = rd.Reopen(pay_b, n_b)
+    if e0 is not None:
+        return "Reopen returned %r" % getattr(e0, "status", e0)
+    out_b, e2 = rd.read_all(chunk=r.choice([3, 500, 4096, 70000]))
+    if out_a + out_b != want:
+        return "after Reopen: reader %d + %d bytes, oracle %d (cut %d)" % (len(out_a), len(out_b), len(want), cut)
+    if (e2 is None) != (status >= 0):
+        return "after Reopen: ended with %r, oracle status %d" % (getattr(e2, "status", e2), status)
+    return None
+
+
+def concurrent_case(bctx, rng):
+    """eight readers on the batching context at once -> None or a failure text"""
+    import threading
+    jobs = []
+    while len(jobs) < 8:
+        fmt, c, ds = one_stream(rng)
+        want = oracle.lzma1_alone(c, CAP) if fmt == 1 else oracle.lzma2_raw(c, ds, CAP)
+        if want[1] != oracle.ERR_OUT_CAP:
+            jobs.append((fmt, c, ds, want, int(rng.choice([100, 4096, 65536, 1 << 20]))))
+    res = [None] * len(jobs)
+
+    def work(i):
+        fmt, c, ds, want, chunk = jobs[i]
+        try:
+            rd, err = lzma_amd.NewReader1(bctx, c) if fmt == 1 else lzma_amd.NewReader2(bctx, c, ds)
+            if rd is None:
+                res[i] = None if (want[1] < 0 and err.status == want[1] and not want[0]) else "constructor error %d" % err.status
+                return
+            out, e = rd.read_all(chunk=chunk)
+            if out != want[0]:
+                res[i] = "bytes differ: reader %d, oracle %d" % (len(out), len(want[0]))
+            elif (want[1] < 0) != isinstance(e, lzma_amd.LzmaError) or (want[1] < 0 and e.status != want[1]):
+                res[i] = "ended with %r, oracle status %d" % (getattr(e, "status", e), want[1])
+        except Exception as ex:  # noqa: BLE001
+            res[i] = "exception %r" % ex
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for i, f in enumerate(res):
+        if f:
+            return "reader %d of 8 (fmt %d, dict %d, len %d): %s" % (i, jobs[i][0], jobs[i][2], len(jobs[i][1]), f), jobs[i][1]
+    return None
+
+
 def fuzz(ctx, budget, seed, verbose=True):
     """-> (readers compared, readers that ended in an error); raises AssertionError on a mismatch"""
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     n_total = n_err = n_skipped = 0
     n_unsup = [0]
+    n_reopen = n_conc = 0
+    bctx = None
     while time.time() < t_end:
+        mode = rng.random()
+        if mode < 0.25:
+            f = reopen_case(ctx, rng)
+            n_total += 1
+            n_reopen += 1
+            if f:
+                print("MISMATCH reopen case: %s" % f, flush=True)
+                raise AssertionError("reader and oracle differ (Reopen: %s)" % f)
+            continue
+        if mode < 0.32:
+            if bctx is None:
+                bctx = lzma_amd.Context(0)
+                bctx.enable_batching(window_us=2000, max_streams=64)
+            f = concurrent_case(bctx, rng)
+            n_total += 8
+            n_conc += 8
+            if f:
+                os.makedirs("gpurun_out", exist_ok=True)
+                fn = "gpurun_out/fuzz_reader_fail_%d_%d.bin" % (seed, n_total)
+                open(fn, "wb").write(f[1])
+                print("MISMATCH concurrent readers: %s -> %s" % (f[0], fn), flush=True)
+                raise AssertionError("reader and oracle differ (%s), input saved as %s" % (f[0], fn))
+            continue
         fmt, c, ds = one_stream(rng)
         want = oracle.lzma1_alone(c, CAP) if fmt == 1 else oracle.lzma2_raw(c, ds, CAP)
         if want[1] == oracle.ERR_OUT_CAP:
@@ -135,8 +253,10 @@ def fuzz(ctx, budget, seed, verbose=True):
             print("MISMATCH %s: %s -> %s" % (what, fail, fn), flush=True)
             raise AssertionError("reader and oracle differ (%s), input saved as %s" % (fail, fn))
         if verbose and n_total % 50 == 0:
-            print("%d readers ok so far (%d ending in an error, %d skipped, %d fed readers at the documented limit)"
-                  % (n_total, n_err, n_skipped, n_unsup[0]), flush=True)
+            print("%d readers ok so far (%d ending in an error, %d skipped, %d fed readers at the documented limit, "
+                  "%d Reopen cases, %d concurrent)" % (n_total, n_err, n_skipped, n_unsup[0], n_reopen, n_conc), flush=True)
+    if bctx is not None:
+        bctx.close()
     return n_total, n_err
 
 
