@@ -151,3 +151,17 @@ def test_folders_through_the_sevenzip_constructors(ctx):
         out += b
         assert r.Close() is None
     assert out == want
+
+
+@pytest.mark.gpu
+def test_container_fuzz_with_decode(ctx):
+    """tools/fuzz_containers.py for a few seconds: mutated .xz files against liblzma (stream by stream), mutated
+    .7z archives against their plaintext whenever a verified decode succeeds"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_containers", os.path.join(root, "tools", "fuzz_containers.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, n_ok, _ = mod.fuzz(ctx, 6.0, 20251006, verbose=False)
+    assert n > 200 and n_ok > 10

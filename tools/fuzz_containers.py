@@ -1,0 +1,119 @@
+"""Mutation fuzz of the container front-ends WITH decode (dev tool, run on the GPU box): .xz files against
+liblzma (Python's lzma module), hand-built .7z archives against their own plaintext.
+  .xz: whatever liblzma decodes, xlz_xz_decode must decode to the same bytes; where liblzma refuses the file,
+       xlz_xz_decode (verify on) must refuse it too or -- the containers are checked less strictly than liblzma
+       does in places (reserved header bits, padding) -- decode it to what liblzma's block decoder would give;
+       that second case is only counted.
+  .7z: a decode with verification on that succeeds has passed every CRC the archive carries: its bytes must be
+       the original files'.
+usage: python tools/fuzz_containers.py [seconds] [seed]"""
+import lzma
+import os
+import random
+import struct
+import sys
+import time
+import zlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import corpus
+import lzma_amd
+from fuzz_parsers import _mutate
+from sevenzip_craft import archive, copy_folder, lzma2_folder, lzma_folder
+
+def strict_xz(b):
+    """liblzma, stream by stream (lzma.decompress ignores whatever follows the first stream once that one is
+    good, and knows no stream padding): every stream must decode, padding is 4-byte groups of zeros"""
+    out, data = [], b
+    if not data:
+        return None
+    while data:
+        d = lzma.LZMADecompressor(format=lzma.FORMAT_XZ)
+        try:
+            out.append(d.decompress(data))
+        except lzma.LZMAError:
+            return None
+        if not d.eof:
+            return None
+        data = d.unused_data
+        k = 0
+        while data[k:k + 4] == b"\0\0\0\0":
+            k += 4
+        data = data[k:]
+    return b"".join(out)
+
+
+LIMIT = 64 << 20  # never allocate more than this for an output the (mutated) index announces
+
+
+def fuzz(ctx, seconds, seed, verbose=True):
+    rnd = random.Random(seed)
+    plains = [corpus.plain("TRMZ"[i % 4], 4000 + i, n) for i, n in enumerate((1, 300, 5000, 70000, 300000))]
+    xzs = []
+    for p in plains:
+        for chk in (lzma.CHECK_NONE, lzma.CHECK_CRC32, lzma.CHECK_CRC64, lzma.CHECK_SHA256):
+            xzs.append(lzma.compress(p, format=lzma.FORMAT_XZ, check=chk, preset=rnd.choice([0, 1, 6])))
+    xzs.append(xzs[5] + xzs[10])
+    xzs.append(xzs[2] + b"\0" * 4 + xzs[14] + xzs[7])
+    szs = []
+    for combo in ([0], [0, 1], [1, 2, 3]):
+        fo, want = [], b""
+        for c in combo:
+            parts = plains[: 1 + c]
+            data = b"".join(parts)
+            rec, packed = (lzma_folder, lzma2_folder, copy_folder, lzma_folder)[c](data)
+            fo.append((rec, packed, parts))
+            want += data
+        for fc in (True, False):
+            a = archive(fo, folder_crc=fc)
+            szs.append((a, 32 + struct.unpack("<Q", a[12:20])[0], want))
+    t_end = time.time() + seconds
+    n = n_ok = n_lenient = 0
+    while time.time() < t_end:
+        n += 1
+        if rnd.random() < 0.6:
+            b = bytes(_mutate(rnd, rnd.choice(xzs))) if rnd.random() < 0.85 else rnd.choice(xzs)
+            ref = strict_xz(b)
+            try:
+                _, total = lzma_amd.xz_index(b)
+                if total > LIMIT:
+                    continue
+                got = lzma_amd.xz_decode(ctx, b, verify=True)
+            except lzma_amd.LzmaError:
+                got = None
+            if ref is not None:
+                assert got == ref, "xz: liblzma decodes %d bytes, xlz %s" % (len(ref), None if got is None else len(got))
+                n_ok += 1
+            elif got is not None:
+                n_lenient += 1
+        else:
+            a, hs, want = rnd.choice(szs)
+            b = _mutate(rnd, a, tail_from=hs if rnd.random() < 0.5 else 32)
+            if len(b) > max(hs, 32) and rnd.random() < 0.7:
+                b[28:32] = struct.pack("<I", zlib.crc32(bytes(b[hs:])) & 0xFFFFFFFF)
+                b[8:12] = struct.pack("<I", zlib.crc32(bytes(b[12:32])) & 0xFFFFFFFF)
+            b = bytes(b)
+            try:
+                _, _, total = lzma_amd.sevenzip_index(b, ctx)
+                if total > LIMIT:
+                    continue
+                got = lzma_amd.sevenzip_decode(ctx, b, verify=True)
+            except lzma_amd.LzmaError:
+                continue
+            # every folder (or file) of these archives carries a CRC: what passed them is the plaintext, unless the
+            # mutation dropped folders / files from the header itself
+            if len(got) == len(want):
+                assert got == want, "7z: verified decode differs from the plaintext"
+            n_ok += 1
+        if verbose and n % 200 == 0:
+            print("%d inputs, %d decoded and equal, %d xz files liblzma refuses but xlz decodes" % (n, n_ok, n_lenient), flush=True)
+    return n, n_ok, n_lenient
+
+
+if __name__ == "__main__":
+    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    print("container fuzz ok: %d inputs, %d decoded and equal, %d lenient" % fuzz(lzma_amd.Context(0), secs, seed))
