@@ -182,6 +182,8 @@ extern "C" int xlz_xz_index(const uint8_t *file, size_t len, xlz_xz_block *block
             const uint64_t comp = rec.first - hdr - chk;
             if (csz != ~0ull && csz != comp) return XLZ_ERR_RESULT;
             if (usz != ~0ull && usz != rec.second) return XLZ_ERR_RESULT;
+            for (uint64_t k = comp; k < ((comp + 3) & ~3ull); k++) // Block Padding: null bytes (liblzma refuses others)
+                if (file[pos + hdr + k] != 0) return XLZ_ERR_RESULT;
             if (nb < max_blocks) {
                 xlz_xz_block &b = blocks[nb];
                 b.comp_off = pos + hdr;

@@ -123,6 +123,37 @@ def test_index_whose_record_sizes_wrap_64_bits_is_refused():
             lzma_amd.xz_index(crafted)
 
 
+def test_every_structural_bit_flip_is_refused_where_liblzma_refuses():
+    """single-bit flips in the stream header, the block header, the block padding, the index and the footer
+    of one file per check type: wherever liblzma (stream by stream) refuses the file, xlz_xz_index refuses it
+    too -- no GPU needed, the parse is host code"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from fuzz_containers import strict_xz
+    p = bytes((i * 7 + i // 13) % 251 for i in range(3001))   # 3001: the LZMA2 payload needs block padding
+    for chk in (lzma.CHECK_NONE, lzma.CHECK_CRC32, lzma.CHECK_CRC64, lzma.CHECK_SHA256):
+        x = lzma.compress(p, format=lzma.FORMAT_XZ, check=chk, preset=0)
+        n = len(x)
+        blocks, _ = lzma_amd.xz_index(x)
+        b0 = blocks[0]
+        pad = range(b0["comp_off"] + b0["comp_len"], b0["check_off"])
+        index_len = (int.from_bytes(x[n - 8:n - 4], "little") + 1) * 4
+        structural = list(range(0, b0["comp_off"])) + list(pad) + list(range(n - 12 - index_len, n))
+        refused = 0
+        for i in structural:
+            for bit in range(8):
+                y = bytearray(x)
+                y[i] ^= 1 << bit
+                y = bytes(y)
+                if strict_xz(y) is None:
+                    refused += 1
+                    with pytest.raises(LzmaError):
+                        lzma_amd.xz_index(y)
+        assert refused > 8 * (len(structural) - 8)
+    assert len(pad) > 0
+
+
 @pytest.mark.gpu
 def test_whole_files_decode_as_one_batch(ctx):
     for f, p in (_three_streams(), _multi_block(), _multi_block(65536)):
