@@ -60,6 +60,13 @@ def test_hazard_checker_sees_the_known_cases():
     # R3: VCC written by v_cmp, read by v_cndmask
     assert hazards.analyse(["v_cmp_eq_u32 vcc, 0, v1", "v_cndmask_b32 v2, v3, v4, vcc"])
     assert not hazards.analyse(["v_cmp_eq_u32 vcc, 0, v1", "s_nop 1", "v_cndmask_b32 v2, v3, v4, vcc"])
+    # R7: a DPP instruction reads (as src0) a VGPR the VALU wrote one slot earlier
+    dpp = "v_sub_u32_dpp v40, v40, v63 quad_perm:[0,1,2,3] row_mask:0x1 bank_mask:0x2"
+    assert hazards.analyse(["v_add_u32 v40, v1, v2", "s_mov_b32 s80, 1", dpp])
+    assert not hazards.analyse(["v_add_u32 v40, v1, v2", "s_mov_b32 s80, 1", "s_mov_b32 s81, 1", dpp])
+    assert not hazards.analyse(["v_add_u32 v63, v1, v2", dpp])   # src1 is read without DPP: no extra wait state
+    # an assembler directive between producer and consumer is not a wait state
+    assert hazards.analyse(["v_mul_u32_u24 v55, v55, v40", ".p2align 4", "v_readlane_b32 s80, v55, 3"])
     # across a branch: the consumer is the first instruction at the target
     bad = ["v_readlane_b32 s80, v55, 3", "s_cbranch_scc0 .Lx", "s_nop 3", ".Lx:", "v_add_u32 v1, s80, v1"]
     assert hazards.analyse(bad)
