@@ -111,11 +111,14 @@ def _len(rc, L, ps):
     return 16 + _tree(rc, L[3], 0, 8)
 
 
-def _run(rc, st, w, left):
+def _run(rc, st, w, left, stop_at=None):
     """decompress.go:13 ff. until the chunk's end; 'end' / 'marker' / 'err'; raises _Eof where a ReadByte fails.
-    left: bytesLeft (None = undefined)."""
+    left: bytesLeft (None = undefined).  stop_at: return 'stop' in front of the packet that starts at that output
+    position (tests that compare the decoder's state in mid-stream)."""
     defined = left is not None
     while True:
+        if stop_at is not None and len(w.total) >= stop_at:
+            return "stop", left
         if defined and left == 0 and rc.code == 0:
             return "end", left
         ps = w.pos & ((1 << st.pb) - 1)

@@ -1,0 +1,158 @@
+"""CPU: the COMMITTED fast loop (lzma_amd/csrc/xlz_fastpath.inc as tools/gen_fastpath.py renders it) executed
+instruction by instruction by tools/gcn_emu.py on real LZMA1 streams -- head gather, tree walks on lane selects, the
+LDS gather of the literal walk, DPP head updates, matched literals through the HBM table, deferred match copies, the
+direct-bit branch table, normalisation stubs, the folded limit tests -- against the oracle: every decoded byte, and
+range / code / state / reps where the loop hands back to the checked path.  The C++ around the loop (lzma_run: window
+refills, the copies the loop leaves to its caller, the end of the stream) is restated here in a few lines of Python.
+
+This is the part of the product no other CPU test reaches (there is no GPU in CI); on the GPU box the same loop runs
+for real in the -m gpu tests."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import corpus
+import lzma_pydec
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+P_LEN, P_LIT = 820, 1852
+K_IN_WINDOW, K_FAST_INPUT, K_FAST_OUTPUT = 256, 32, 336
+
+
+def _render(add=(), remove=()):
+    spec = importlib.util.spec_from_file_location("gen_fastpath_emu", os.path.join(ROOT, "tools", "gen_fastpath.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    g.VARIANT.update(add)
+    g.VARIANT.difference_update(remove)
+    _, final, _ = g.render()
+    import layout
+    return final, layout.sizes(final), layout
+
+
+@pytest.fixture(scope="module")
+def program():
+    return _render()
+
+
+def _head_vectors(lane, dpp=True):
+    """xlz_kernel.hip: head_vectors (DPP cells; dpp=False: the XLZ_HEAD_PLAIN build, head probability j at lane j)"""
+    base_of = [0, 192, 204, 216, 228, 240, P_LEN + 0, P_LEN + 1, 1336 + 0, 1336 + 1]
+    hc, hms, hm2, litnext = [], [], [], []
+    for l in range(64):
+        if dpp:
+            hj = (l // 16) * 4 + (l % 16) // 4 if (l % 4 == 0 and l < 40) else 10
+        else:
+            hj = min(l, 10)
+        base = base_of[hj] if hj < 10 else P_LEN + 2
+        hc.append(base * 2)
+        hms.append(2 if 1 <= hj <= 4 else 0)
+        hm2.append(2 if hj in (0, 5) else 0)
+        s = l if l < 12 else 0
+        litnext.append(0 if s < 4 else (s - 3 if s < 10 else s - 6))
+    return [np.array(x, dtype=np.uint32) for x in (hc, hms, hm2, litnext)]
+
+
+def run_fast_loop(program, payload, lc, lp, pb, dict_size, size, expect, dpp=True):
+    """-> (bytes decoded by the emulated loop, machine, number of loop entries, exits by code)"""
+    from gcn_emu import Machine
+    final, sizes, layout = program
+    m = Machine(final, sizes, layout.SGPR_OPS, layout.VGPR_OPS, layout.SGPR64_OPS)
+    n_probs = P_LIT + (0x100 << (lc + lp))
+    m.lds[0:2 * n_probs:2] = 0x00
+    m.lds[1:2 * n_probs:2] = 0x04          # every probability 1024 (state.go:79-121)
+    out = bytearray(size + 1024)
+    mp = bytearray(b"\x00\x04" * (0x200 << (lc + lp)))
+    m.mem["outp"], m.mem["mptr"] = out, mp
+    lane = np.arange(64, dtype=np.uint32)
+    hc, hms, hm2, litnext = _head_vectors(lane, dpp)
+    m.v.update(vlane=lane, vhc=hc, vhms=hms, vhm2=hm2, vlitnext=litnext,
+               vlpm=np.full(64, (1 << lp) - 1, dtype=np.uint32), vpm=np.full(64, (1 << pb) - 1, dtype=np.uint32))
+    s = m.s
+    s.update(range=0xFFFFFFFF, code=int.from_bytes(payload[1:5], "big"), state=0, rep0=0, rep1=0, rep2=0, rep3=0,
+             pos=0, wpos=0, prev=0, mb=0, exitc=0, lenout=0, dict=dict_size, dictm1=dict_size - 1,
+             pos_mask=(1 << pb) - 1, lc=lc, lc8=8 - lc, wbase=0)
+    assert payload[0] == 0
+    p = 5                                   # input position (rc.Init took five bytes, range_decoder.go:27-46)
+    data = payload + b"\0" * 512
+    entries, exits = 0, {0: 0, 1: 0, 2: 0, 3: 0}
+    while True:
+        in_left = len(payload) - p
+        if in_left < K_FAST_INPUT or size - s["pos"] < K_FAST_OUTPUT:
+            break                           # the checked path takes over here (lzma_run)
+        win0, arel = p & ~3, p & 3
+        m.v["vin"] = np.frombuffer(data[win0:win0 + 256], dtype="<u4").astype(np.uint32)
+        s["cur"] = int(m.v["vin"][0]) >> (8 * arel)
+        s["arel"] = arel
+        s["arel_lim"] = min(K_IN_WINDOW - K_FAST_INPUT, arel + (in_left - K_FAST_INPUT))
+        s["pos_lim"] = s["pos"] + (size - s["pos"] - K_FAST_OUTPUT) + 1
+        pos0 = s["pos"]
+        m.run()
+        entries += 1
+        ec = s["exitc"]
+        exits[ec] += 1
+        p = win0 + s["arel"]
+        assert bytes(out[pos0:s["pos"]]) == expect[pos0:s["pos"]], "bytes differ behind position %d" % pos0
+        if ec == 3:                         # a copy the loop leaves to its caller (wave_copy)
+            n, dist = s["lenout"], s["rep0"] + 1
+            for i in range(n):
+                out[s["pos"] + i] = out[s["pos"] + i - dist] if s["pos"] + i >= dist else 0
+            s["pos"] += n
+            s["wpos"] = (s["wpos"] + n) % dict_size
+            s["prev"] = out[s["pos"] - 1]
+            s["mb"] = out[s["pos"] - dist] if s["pos"] >= dist else 0
+        elif ec != 0:
+            break
+    return bytes(out[:s["pos"]]), m, entries, exits, p
+
+
+def _reference_state_at(payload, lc, lp, pb, dict_size, size, stop):
+    """the Python restatement, stopped in front of the packet that starts at output position `stop`"""
+    st = lzma_pydec._State(lc, lp, pb)
+    w = lzma_pydec.Window(dict_size)
+    rc = lzma_pydec._Rc(payload, 0, len(payload))
+    assert rc.init()
+    res, _ = lzma_pydec._run(rc, st, w, size, stop_at=stop)
+    assert res == "stop" and len(w.total) == stop
+    return rc, st
+
+
+@pytest.mark.parametrize("family,n,lc,lp,pb,ds", [("T", 6000, 3, 0, 2, 1 << 16), ("R", 1500, 3, 0, 2, 1 << 16),
+                                                  ("M", 5000, 0, 2, 0, 4096), ("Z", 9000, 1, 1, 1, 4096),
+                                                  ("T", 5000, 4, 0, 4, 5000)])
+def test_committed_loop_decodes_real_streams_on_the_emulator(program, family, n, lc, lp, pb, ds):
+    p = corpus.plain(family, 4242 + n, n)
+    blob = corpus.compress_alone(p, dict_size=ds, lc=lc, lp=lp, pb=pb, known_size=True, preset=6 if family == "T" else 0)
+    assert oracle.lzma1_alone(blob, n)[0] == p
+    payload = blob[13:]
+    out, m, entries, exits, in_pos = run_fast_loop(program, payload, lc, lp, pb, ds, n, p)
+    assert out == p[:len(out)]
+    # the loop ran until the checked path's margins: nearly everything was decoded by it, over many entries
+    assert len(out) > n - 336 - 300 or len(payload) - in_pos < 64, (len(out), n, in_pos, len(payload))
+    assert exits[1] == 0 and exits[2] == 0 and entries >= 1
+    rc, st = _reference_state_at(payload, lc, lp, pb, ds, n, len(out))
+    s = m.s
+    assert (s["range"], s["code"], s["state"]) == (rc.range, rc.code, st.state)
+    assert [s["rep0"], s["rep1"], s["rep2"], s["rep3"]] == st.reps
+    assert in_pos == rc.p
+
+
+@pytest.mark.parametrize("add,remove", [((), ("lgather",)), ((), ("hdpp",)), ((), ("flim", "cflag")), ((), ("rlhoist", "vperm", "tuc")),
+                                        (("lit8g",), ()), (("order3", "pwhoist"), ()), (("order1",), ("bralign",)),
+                                        (("litrun",), ("flim",))])
+def test_generator_switches_still_decode(add, remove):
+    """the code paths kept in the generator as measured alternatives (profiles/r02/layout_scan.md)
+    are not dead code: each of them decodes a stream correctly on the emulator"""
+    lc, lp, pb, ds, n = 3, 0, 2, 1 << 16, 2600
+    p = corpus.plain("T", 99, n)
+    blob = corpus.compress_alone(p, dict_size=ds, lc=lc, lp=lp, pb=pb, known_size=True, preset=6)
+    out, m, entries, exits, in_pos = run_fast_loop(_render(add, remove), blob[13:], lc, lp, pb, ds, n, p, dpp="hdpp" not in remove)
+    assert out == p[:len(out)] and len(out) > n - 700 and exits[1] == 0
+    rc, st = _reference_state_at(blob[13:], lc, lp, pb, ds, n, len(out))
+    assert (m.s["range"], m.s["code"], m.s["state"], m.s["rep0"]) == (rc.range, rc.code, st.state, st.reps[0])
