@@ -156,3 +156,30 @@ def test_generator_switches_still_decode(add, remove):
     assert out == p[:len(out)] and len(out) > n - 700 and exits[1] == 0
     rc, st = _reference_state_at(blob[13:], lc, lp, pb, ds, n, len(out))
     assert (m.s["range"], m.s["code"], m.s["state"], m.s["rep0"]) == (rc.range, rc.code, st.state, st.reps[0])
+
+
+def test_end_marker_and_error_exits(program):
+    """exit 2 (distance 0xFFFFFFFF: the end marker, decompress.go:633-645) on a stream of unknown size, and exit 1
+    (a distance the window does not hold, :651-653) on corrupted streams: same position and bytes as the oracle"""
+    lc, lp, pb, ds, n = 3, 0, 2, 1 << 16, 3000
+    p = corpus.plain("T", 5, n)
+    blob = corpus.compress_alone(p, dict_size=ds, known_size=False, preset=6)       # ends with the marker
+    assert blob[5:13] == b"\xff" * 8
+    # (64 bytes behind the stream: with fewer than 32 left the kernel hands over to the checked path)
+    out, m, entries, exits, in_pos = run_fast_loop(program, blob[13:] + b"\0" * 64, lc, lp, pb, ds, n + 4096, p + b"\0" * 4096)
+    assert in_pos == len(blob) - 13
+    assert out == p and exits[2] == 1 and m.s["code"] == 0 and m.s["rep0"] == 0xFFFFFFFF
+    caught = 0
+    for k in range(40):
+        bad = bytearray(blob)
+        bad[13 + 200 + 37 * k] ^= 1 << (k % 8)
+        bad = bytes(bad)
+        want, status, _ = oracle.lzma1_alone(bad, n + 4096)
+        if status != oracle.ERR_RESULT or len(want) > n - 400:
+            continue
+        out, m, entries, exits, in_pos = run_fast_loop(program, bad[13:] + b"\0" * 64, lc, lp, pb, ds, n + 4096, want + b"\0" * 8192)
+        assert exits[1] + exits[2] == 1 and out == want, k
+        caught += 1
+        if caught == 4:
+            break
+    assert caught >= 2
