@@ -59,11 +59,12 @@ def _head_vectors(lane, dpp=True):
     return [np.array(x, dtype=np.uint32) for x in (hc, hms, hm2, litnext)]
 
 
-def run_fast_loop(program, payload, lc, lp, pb, dict_size, size, expect, dpp=True):
+def run_fast_loop(program, payload, lc, lp, pb, dict_size, size, expect, dpp=True, strict_waits=False):
     """-> (bytes decoded by the emulated loop, machine, number of loop entries, exits by code)"""
     from gcn_emu import Machine
     final, sizes, layout = program
     m = Machine(final, sizes, layout.SGPR_OPS, layout.VGPR_OPS, layout.SGPR64_OPS)
+    m.strict_waits = strict_waits
     n_probs = P_LIT + (0x100 << (lc + lp))
     m.lds[0:2 * n_probs:2] = 0x00
     m.lds[1:2 * n_probs:2] = 0x04          # every probability 1024 (state.go:79-121)
@@ -183,3 +184,18 @@ def test_end_marker_and_error_exits(program):
         if caught == 4:
             break
     assert caught >= 2
+
+
+def test_every_load_is_waited_for_and_may_complete_as_late_as_its_wait(program):
+    """the emulator's strict mode: the result of an LDS read or a global load is not in its register before the
+    s_waitcnt that covers it (lgkmcnt / vmcnt counted as the hardware counts them, LDS in order), reading or
+    overwriting it earlier is an error, and global loads read memory AT the wait -- the latest the hardware could.
+    The committed loop decodes the same bytes as with loads that complete at issue: its s_waitcnt counts (the
+    lgkmcnt(2) behind the literal walk's gather among them) are sufficient, and the deferred match copy does not
+    depend on when its load lands."""
+    for fam, n, lc, lp, pb, ds in (("T", 4000, 3, 0, 2, 1 << 16), ("M", 3000, 0, 2, 0, 4096)):
+        p = corpus.plain(fam, 777 + n, n)
+        blob = corpus.compress_alone(p, dict_size=ds, lc=lc, lp=lp, pb=pb, known_size=True, preset=6)
+        out, m, entries, exits, in_pos = run_fast_loop(program, blob[13:], lc, lp, pb, ds, n, p, strict_waits=True)
+        assert out == p[:len(out)] and len(out) > n - 700
+        assert not m.pending and not m.vm                      # every exit has waited for what it started

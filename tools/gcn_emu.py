@@ -52,6 +52,15 @@ class Machine:
         self.mem = {}  # name of a 64-bit base operand -> bytearray
         self.sgpr_ops, self.vgpr_ops, self.sgpr64_ops = set(sgpr_ops), set(vgpr_ops), set(sgpr64_ops)
         self.n_exec = 0
+        # strict_waits: the result of an LDS read / a global load is NOT in its register until the s_waitcnt that
+        # covers it (lgkmcnt counts LDS reads and writes, completing in order; vmcnt the global loads); reading or
+        # overwriting such a register earlier raises.  Global loads then read memory at the WAIT, the latest moment
+        # the hardware could (the default reads at issue, the earliest): a loop that is right under both orders does
+        # not depend on when its loads complete.
+        self.strict_waits = False
+        self.lgkm = []   # pending LDS operations, oldest first: None (a write) or (register, value)
+        self.vm = []     # pending global loads: (register, addresses, buffer, width, exec mask)
+        self.pending = {}  # register -> loads into it still in flight
         # program
         self.ins, self.addr, self.labels = [], [], {}
         off = 0
@@ -113,6 +122,11 @@ class Machine:
             raise NotImplementedError(text)
         return (fn, ops, mods, text)
 
+    def _landed(self, reg):
+        self.pending[reg] -= 1
+        if not self.pending[reg]:
+            del self.pending[reg]
+
     def rs(self, o):  # scalar read (32 bit)
         k = o[0]
         if k == "s":
@@ -149,10 +163,14 @@ class Machine:
     def rv(self, o):  # vector read -> uint64 array (values < 2^32)
         k = o[0]
         if k == "v":
+            if o[1] in self.pending:
+                raise Halt("`%s` reads %s before the s_waitcnt that covers its load" % (self.ins[self.pc][3], o[1]))
             return self.v[o[1]].astype(np.uint64)
         return np.full(64, self.rs(o), dtype=np.uint64)
 
     def wv(self, o, val, mask=None):
+        if o[1] in self.pending:
+            raise Halt("`%s` overwrites %s while a load into it is in flight" % (self.ins[self.pc][3], o[1]))
         val = (np.asarray(val, dtype=np.uint64) & np.uint64(M32)).astype(np.uint32)
         em = self._mask_arr(self.exec) if mask is None else (mask & self._mask_arr(self.exec))
         if o[1] not in self.v:
@@ -190,7 +208,27 @@ class Machine:
     def i_s_nop(self, o, m):
         return None
 
-    i_s_waitcnt = i_s_nop
+    def i_s_waitcnt(self, o, m):
+        if not self.strict_waits:
+            return None
+        text = self.ins[self.pc][3]
+        mm = re.search(r"lgkmcnt\((\d+)\)", text)
+        if mm:
+            while len(self.lgkm) > int(mm.group(1)):
+                op = self.lgkm.pop(0)
+                if op is not None:
+                    self._landed(op[0])
+                    self.v[op[0]] = np.where(op[2], op[1], self.v.get(op[0], np.zeros(64, dtype=np.uint32)))
+        mm = re.search(r"vmcnt\((\d+)\)", text)
+        if mm:
+            while len(self.vm) > int(mm.group(1)):
+                reg, a, buf, width, em = self.vm.pop(0)
+                val = np.zeros(64, dtype=np.uint32)
+                for i in np.nonzero(em)[0]:
+                    val[i] = buf[a[i]] | ((buf[a[i] + 1] << 8) if width == 2 else 0)
+                self._landed(reg)
+                self.v[reg] = np.where(em, val, self.v.get(reg, np.zeros(64, dtype=np.uint32)))
+        return None
 
     def i_s_mov_b32(self, o, m):
         self.s[o[0][1]] = self.rs(o[1])
@@ -430,6 +468,8 @@ class Machine:
         self.wv(o[0], np.where(sel, self.rv(o[2]), self.rv(o[1])))
 
     def i_v_readlane_b32(self, o, m):
+        if o[1][1] in self.pending:
+            raise Halt("`%s` reads %s before the s_waitcnt that covers its load" % (self.ins[self.pc][3], o[1][1]))
         self.s[o[0][1]] = int(self.v[o[1][1]][self.rs(o[2]) & 63])
 
     def i_v_writelane_b32(self, o, m):
@@ -450,7 +490,13 @@ class Machine:
     # ---- LDS / memory -----------------------------------------------------------------------------
     def i_ds_read_u16(self, o, mods):
         a = (self.rv(o[1]) + np.uint64(mods.get("offset", 0))).astype(np.int64)
-        self.wv(o[0], self.lds[a].astype(np.uint64) | (self.lds[a + 1].astype(np.uint64) << np.uint64(8)))
+        val = self.lds[a].astype(np.uint64) | (self.lds[a + 1].astype(np.uint64) << np.uint64(8))
+        if self.strict_waits:  # (LDS operations execute in order: the VALUE is that of issue time, its arrival is late)
+            # (a second LDS read into a register whose first is still in flight is fine: they land in order)
+            self.lgkm.append((o[0][1], val.astype(np.uint32), self._mask_arr(self.exec)))
+            self.pending[o[0][1]] = self.pending.get(o[0][1], 0) + 1
+            return None
+        self.wv(o[0], val)
 
     def i_ds_bpermute_b32(self, o, mods):
         idx = ((self.rv(o[1]) >> np.uint64(2)) & np.uint64(63)).astype(np.int64)
@@ -460,6 +506,8 @@ class Machine:
         a = (self.rv(o[0]) + np.uint64(mods.get("offset", 0))).astype(np.int64)
         d = self.rv(o[1])
         em = self._mask_arr(self.exec)
+        if self.strict_waits:
+            self.lgkm.append(None)
         for i in np.nonzero(em)[0]:  # lane order: a later lane wins on equal addresses (all write the same there)
             self.lds[a[i]] = int(d[i]) & 0xFF
             self.lds[a[i] + 1] = (int(d[i]) >> 8) & 0xFF
@@ -467,7 +515,16 @@ class Machine:
     def _gaddr(self, o_addr, o_base):
         return self.rv(o_addr).astype(np.int64), self.mem[o_base[1]]
 
+    def _late_load(self, o, width):
+        a, buf = self._gaddr(o[1], o[2])
+        if o[0][1] in self.pending:
+            raise Halt("`%s`: a second load into %s while one is in flight" % (self.ins[self.pc][3], o[0][1]))
+        self.vm.append((o[0][1], a, buf, width, self._mask_arr(self.exec)))
+        self.pending[o[0][1]] = self.pending.get(o[0][1], 0) + 1
+
     def i_global_load_ubyte(self, o, mods):
+        if self.strict_waits:
+            return self._late_load(o, 1)
         a, buf = self._gaddr(o[1], o[2])
         em = self._mask_arr(self.exec)
         val = np.zeros(64, dtype=np.uint64)
@@ -476,6 +533,8 @@ class Machine:
         self.wv(o[0], val)
 
     def i_global_load_ushort(self, o, mods):
+        if self.strict_waits:
+            return self._late_load(o, 2)
         a, buf = self._gaddr(o[1], o[2])
         em = self._mask_arr(self.exec)
         val = np.zeros(64, dtype=np.uint64)
