@@ -59,7 +59,7 @@ def _head_vectors(lane, dpp=True):
     return [np.array(x, dtype=np.uint32) for x in (hc, hms, hm2, litnext)]
 
 
-def run_fast_loop(program, payload, lc, lp, pb, dict_size, size, expect, dpp=True, strict_waits=False):
+def run_fast_loop(program, payload, lc, lp, pb, dict_size, size, expect, dpp=True, strict_waits=False, base=0):
     """-> (bytes decoded by the emulated loop, machine, number of loop entries, exits by code)"""
     from gcn_emu import Machine
     final, sizes, layout = program
@@ -69,6 +69,7 @@ def run_fast_loop(program, payload, lc, lp, pb, dict_size, size, expect, dpp=Tru
     m.lds[0:2 * n_probs:2] = 0x00
     m.lds[1:2 * n_probs:2] = 0x04          # every probability 1024 (state.go:79-121)
     out = bytearray(size + 1024)
+    out[:base] = expect[:base]              # (base > 0: an LZMA2 unit whose dictionary epoch starts at `base`)
     mp = bytearray(b"\x00\x04" * (0x200 << (lc + lp)))
     m.mem["outp"], m.mem["mptr"] = out, mp
     lane = np.arange(64, dtype=np.uint32)
@@ -77,8 +78,8 @@ def run_fast_loop(program, payload, lc, lp, pb, dict_size, size, expect, dpp=Tru
                vlpm=np.full(64, (1 << lp) - 1, dtype=np.uint32), vpm=np.full(64, (1 << pb) - 1, dtype=np.uint32))
     s = m.s
     s.update(range=0xFFFFFFFF, code=int.from_bytes(payload[1:5], "big"), state=0, rep0=0, rep1=0, rep2=0, rep3=0,
-             pos=0, wpos=0, prev=0, mb=0, exitc=0, lenout=0, dict=dict_size, dictm1=dict_size - 1,
-             pos_mask=(1 << pb) - 1, lc=lc, lc8=8 - lc, wbase=0)
+             pos=base, wpos=0, prev=0, mb=0, exitc=0, lenout=0, dict=dict_size, dictm1=dict_size - 1,
+             pos_mask=(1 << pb) - 1, lc=lc, lc8=8 - lc, wbase=base)
     assert payload[0] == 0
     p = 5                                   # input position (rc.Init took five bytes, range_decoder.go:27-46)
     data = payload + b"\0" * 512
@@ -103,14 +104,14 @@ def run_fast_loop(program, payload, lc, lp, pb, dict_size, size, expect, dpp=Tru
         if ec == 3:                         # a copy the loop leaves to its caller (wave_copy)
             n, dist = s["lenout"], s["rep0"] + 1
             for i in range(n):
-                out[s["pos"] + i] = out[s["pos"] + i - dist] if s["pos"] + i >= dist else 0
+                out[s["pos"] + i] = out[s["pos"] + i - dist] if s["pos"] + i >= dist + base else 0
             s["pos"] += n
             s["wpos"] = (s["wpos"] + n) % dict_size
             s["prev"] = out[s["pos"] - 1]
-            s["mb"] = out[s["pos"] - dist] if s["pos"] >= dist else 0
+            s["mb"] = out[s["pos"] - dist] if s["pos"] >= dist + base else 0
         elif ec != 0:
             break
-    return bytes(out[:s["pos"]]), m, entries, exits, p
+    return bytes(out[base:s["pos"]]) if base else bytes(out[:s["pos"]]), m, entries, exits, p
 
 
 def _reference_state_at(payload, lc, lp, pb, dict_size, size, stop):
@@ -199,3 +200,17 @@ def test_every_load_is_waited_for_and_may_complete_as_late_as_its_wait(program):
         out, m, entries, exits, in_pos = run_fast_loop(program, blob[13:], lc, lp, pb, ds, n, p, strict_waits=True)
         assert out == p[:len(out)] and len(out) > n - 700
         assert not m.pending and not m.vm                      # every exit has waited for what it started
+
+
+def test_dictionary_epoch_that_starts_inside_the_output(program):
+    """an LZMA2 unit behind a dictionary reset: positions are absolute in the output, the window starts at wbase
+    (distance checks, the `window full` test and the copies' source test all use pos - wbase); 70 000 bytes in
+    front make the absolute positions differ from the window's in more than the low bits"""
+    lc, lp, pb, ds, n, base = 3, 0, 2, 4096, 7000, 70_000
+    p = corpus.plain("M", 31, n)
+    blob = corpus.compress_alone(p, dict_size=ds, known_size=True, preset=0)
+    junk = corpus.plain("R", 32, base)
+    out, m, entries, exits, in_pos = run_fast_loop(program, blob[13:], lc, lp, pb, ds, base + n, junk + p, base=base)
+    assert out == p[:len(out)] and len(out) > n - 700 and exits[1] == 0
+    rc, st = _reference_state_at(blob[13:], lc, lp, pb, ds, n, len(out))
+    assert (m.s["range"], m.s["code"], m.s["state"], m.s["rep0"]) == (rc.range, rc.code, st.state, st.reps[0])
