@@ -142,12 +142,13 @@ def test_committed_loop_decodes_real_streams_on_the_emulator(program, family, n,
     s = m.s
     assert (s["range"], s["code"], s["state"]) == (rc.range, rc.code, st.state)
     assert [s["rep0"], s["rep1"], s["rep2"], s["rep3"]] == st.reps
-    assert in_pos == rc.p
+    assert in_pos == rc.p and s["prev"] == p[len(out) - 1]
 
 
 @pytest.mark.parametrize("add,remove", [((), ("lgather",)), ((), ("hdpp",)), ((), ("flim", "cflag")), ((), ("rlhoist", "vperm", "tuc")),
                                         (("lit8g",), ()), (("order3", "pwhoist"), ()), (("order1",), ("bralign",)),
-                                        (("litrun",), ("flim",))])
+                                        (("litrun",), ("flim",)), (("slot0",), ()), (("slot0", "lit8g"), ("cflag",)),
+                                        (("vprev",), ()), (("vprev", "slot0"), ())])
 def test_generator_switches_still_decode(add, remove):
     """the code paths kept in the generator as measured alternatives (profiles/r02/layout_scan.md)
     are not dead code: each of them decodes a stream correctly on the emulator"""

@@ -271,6 +271,8 @@ def finish_body():
     v_readlane_b32 %[mb], v49, s95
     s_mov_b32 PEND, 0
     """.replace("PEND", pend()))
+    if "vprev" in VARIANT:  # prevByte lives in v32 (literal_tail): keep it current behind a copy too
+        emit("v_mov_b32 v32, %[prev]")
 
 
 def emit_finish_blocks():
@@ -368,10 +370,10 @@ def walk(nbits, blocks, early_exit=None, filler="s_nop 0"):
     assert nbits <= 6
     level_prefix(0, blocks)
     emit(filler)
-    emit("v_readlane_b32 s80, v55, 1\ns_mov_b32 s88, 1")
+    emit("v_readlane_b32 s80, v55, 1\n" + slot_init())
     for k in range(nbits):
         decide()
-        emit("s_addc_u32 s88, s88, s88")  # J = 2J + SCC = 2J + !bit
+        slot_step(k)  # J = 2J + SCC = 2J + !bit
         if k + 1 < nbits:
             nchk(prefix=lambda: level_prefix(k + 1, blocks), pick=lambda: level_pick(k + 1))
             if early_exit:
@@ -426,13 +428,26 @@ def fetch_level(k, blocks):
              "s_cselect_b32 s86, s84, s86" % (blocks[2], blocks[3]))
 
 
+def slot_step(k):
+    """tree slot J = 2J + SCC (SCC = !bit).  slot0: the first level of a walk knows J = 1, so it writes 3 or 2
+    directly and nobody has to set s88 = 1 first (one scalar instruction less per tree walk)"""
+    if "slot0" in VARIANT and k == 0:
+        emit("s_cselect_b32 s88, 3, 2")
+    else:
+        emit("s_addc_u32 s88, s88, s88")
+
+
+def slot_init():
+    return "" if "slot0" in VARIANT else "s_mov_b32 s88, 1"
+
+
 def level_rec(k=None):
     """decision of a recorded level on the probability in s86 (parked in lane k of v54)"""
     emit("s_lshr_b32 s80, %[range], 11\ns_mul_i32 s80, s80, s86")
     if k is not None and not lgather():
         emit("v_writelane_b32 v54, s86, %d" % k)
     decide(scalar_bound=True)
-    emit("s_addc_u32 s88, s88, s88")
+    slot_step(k)
 
 
 def walk_rec(nbits, blocks, entries=None):
@@ -443,7 +458,7 @@ def walk_rec(nbits, blocks, entries=None):
         if "flim" in VARIANT and blocks is LIT_BLOCKS:  # (the packet head set s88 = 1 in a wait state)
             emit("v_readlane_b32 s86, %s, 1" % blocks[0])
         else:
-            emit("s_mov_b32 s88, 1\nv_readlane_b32 s86, %s, 1" % blocks[0])
+            emit(slot_init() + "\nv_readlane_b32 s86, %s, 1" % blocks[0])
     for k in range(nbits):
         if entries:
             if k == 0:
@@ -690,8 +705,8 @@ def packet_limits(head_lane):
         s_cmp_gt_i32 %%[arel], s99
         v_readlane_b32 s80, v55, %d
         s_cbranch_scc1 %s
-        s_mov_b32 s88, 1
         """ % (head_lane, L("x0")))
+        emit(slot_init())  # (a wait state between the lane read and the compare that uses its result)
         return
     emit("""
     s_cmp_gt_u32 %%[arel], %%[arel_lim]
@@ -726,6 +741,8 @@ def literal_context(prev_v=None, part=None):
     blocks requested.  All on the VALU: the scalar port is the busy one.  prev_v = VGPR that
     already holds prevByte.  part: "addr" / "reads" emit only the address arithmetic / the requests."""
     if part != "reads":
+        if prev_v is None and "vprev" in VARIANT:
+            prev_v = "v32"
         if prev_v is None:
             emit("v_mov_b32 v55, %[prev]")
             prev_v = "v55"
@@ -768,9 +785,13 @@ def literal_tail(run_entry=None):
     applies the model update and requests the next literal blocks (which may be the very table
     just updated, hence after the update's store).  v32 = the byte.
     run_entry: label to leave to when the new state is 0 (literal run, sec_literal_run)."""
+    if "vprev" in VARIANT:
+        # the byte (the complement of the slot's low eight bits) is formed on the VALU; the scalar copy of prevByte
+        # is only brought up to date where the loop is left (sec_exits): one scalar instruction less per literal
+        emit("v_not_b32 v32, s88\nv_and_b32 v32, 0xff, v32")
+    else:
+        emit("s_andn2_b32 %[prev], 0xff, s88\nv_mov_b32 v32, %[prev]")
     emit("""
-    s_andn2_b32 %[prev], 0xff, s88
-    v_mov_b32 v32, %[prev]
     v_mov_b32 v61, %[pos]
     global_store_byte v61, v32, %[outp]
     s_add_u32 %[pos], %[pos], 1
@@ -937,10 +958,10 @@ def sec_packet_general():
     # matched levels: the eight candidate probabilities are lanes 0..7 of v54, so the bound of
     # level k is lane k of the VALU product (no record needed: v54 itself is the record)
     bounds("v54")
-    emit("s_mov_b32 s88, 1\nv_readlane_b32 s80, v55, 0\ns_nop 0")
+    emit(slot_init() + "\nv_readlane_b32 s80, v55, 0\ns_nop 0")
     for k in range(8):
         decide()
-        emit("s_addc_u32 s88, s88, s88")
+        slot_step(k)
         if k < 7:
             nchk(prefix=lambda: bounds("v54"), pick=head_pick(k + 1))
         else:
@@ -1196,6 +1217,8 @@ def sec_exits():
     label("fin")
     emit("v_readfirstlane_b32 %[code], v29")
     need_copy_done()
+    if "vprev" in VARIANT:
+        emit("v_readfirstlane_b32 %[prev], v32")
     emit("s_waitcnt lgkmcnt(0)\nds_write_b16 v47, v40\ns_waitcnt lgkmcnt(0)\ns_branch %s" % L("end"))
     emit_stubs()
     emit_wstubs()
@@ -1262,6 +1285,8 @@ def gen():
         emit("s_mov_b32 s99, %[arel_lim]")
         event_limit()
     head_issue(first=True)
+    if "vprev" in VARIANT:
+        emit("v_mov_b32 v32, %[prev]")
     literal_context()  # no copy is pending on entry: prevByte is valid
     if "cflag" in VARIANT:
         emit("s_branch %s" % L("pkt"))
