@@ -148,7 +148,7 @@ def test_committed_loop_decodes_real_streams_on_the_emulator(program, family, n,
 @pytest.mark.parametrize("add,remove", [((), ("lgather",)), ((), ("hdpp",)), ((), ("flim", "cflag")), ((), ("rlhoist", "vperm", "tuc")),
                                         (("lit8g",), ()), (("order3", "pwhoist"), ()), (("order1",), ("bralign",)),
                                         (("litrun",), ("flim",)), (("slot0",), ()), (("slot0", "lit8g"), ("cflag",)),
-                                        (("vprev",), ()), (("vprev", "slot0"), ())])
+                                        (("vprev",), ()), (("rmov",), ()), (("vprev", "slot0", "rmov"), ())])
 def test_generator_switches_still_decode(add, remove):
     """the code paths kept in the generator as measured alternatives (profiles/r02/layout_scan.md)
     are not dead code: each of them decodes a stream correctly on the emulator"""

@@ -138,7 +138,7 @@ def bounds(src, dst="v55"):
     emit("v_lshrrev_b32 %s, 11, %%[range]\nv_mul_u32_u24 %s, %s, %s" % (dst, dst, dst, src))
 
 
-def decide(scalar_bound=False):
+def decide(scalar_bound=False, rin="%[range]"):
     """One decision against bound s80.  The CODE lives in v29 (wave-uniform) for the whole loop:
     one subtract with borrow-out gives code - bound and VCC = (code < bound), an unsigned min
     selects the new code; the scalar side only keeps what steers control: the range and
@@ -148,31 +148,31 @@ def decide(scalar_bound=False):
         # distance from): the scalar subtract moves behind the compare, the VCC reader one slot further away
         emit("""
         v_subrev_co_u32 v28, vcc, s80, v29
-        s_sub_u32 s81, %[range], s80
+        s_sub_u32 s81, RIN, s80
         v_min_u32 v29, v29, v28
         s_cmp_lg_u32 vcc_lo, 0
         s_cselect_b32 %[range], s80, s81
-        """)
+        """.replace("RIN", rin))
         return
     if "order1" in VARIANT:  # round 1's order: the VCC reader right behind its writer (measured 1.7-2.9 % slower)
         emit("""
-        s_sub_u32 s81, %[range], s80
+        s_sub_u32 s81, RIN, s80
         v_subrev_co_u32 v28, vcc, s80, v29
         s_cmp_lg_u32 vcc_lo, 0
         v_min_u32 v29, v29, v28
         s_cselect_b32 %[range], s80, s81
-        """)
+        """.replace("RIN", rin))
         return
     emit("""
-    s_sub_u32 s81, %[range], s80
+    s_sub_u32 s81, RIN, s80
     v_subrev_co_u32 v28, vcc, s80, v29
     v_min_u32 v29, v29, v28
     s_cmp_lg_u32 vcc_lo, 0
     s_cselect_b32 %[range], s80, s81
-    """)
+    """.replace("RIN", rin))
 
 
-def nchk(prefix=None, pick=None, mid=None, late_test=False):
+def nchk(prefix=None, pick=None, mid=None, late_test=False, rreg=None):
     """normalisation test; the stub is emitted out of line at the end of the block.
     prefix / pick: functions that emit the first instructions of the NEXT decision -- the
     range-only VALU product (bounds) and the lane read of its bound.  They are hoisted in front of
@@ -207,21 +207,27 @@ def nchk(prefix=None, pick=None, mid=None, late_test=False):
                 pick()
         emit("s_cbranch_scc0 %s" % L(k))
     else:
-        emit("s_lshr_b32 s80, %[range], 24")
+        emit("s_lshr_b32 s80, %s, 24" % (rreg or "%[range]"))
         if mid:  # VALU instructions of the caller between test and branch (SCC is kept)
             emit(mid)
         emit("s_cbranch_scc0 %s" % L(k))
         label(k + "b")
+        if rreg:
+            stub_reg[k] = rreg
     stubs.append(k)
+
+
+stub_reg = {}  # stub -> the SGPR that holds the range at its site (rmov), default %[range]
 
 
 def emit_stubs():
     for k in stubs:
         label(k)
+        rr = stub_reg.get(k, "%[range]")
         if "vperm" in VARIANT:  # code = code << 8 | next byte in ONE byte permute (v13 = the selector), no scalar mask
-            emit("s_lshl_b32 %[range], %[range], 8\nv_perm_b32 v29, v29, %[cur], v13")
+            emit("s_lshl_b32 %s, %s, 8\nv_perm_b32 v29, v29, %%[cur], v13" % (rr, rr))
         else:
-            emit("s_lshl_b32 %[range], %[range], 8\ns_and_b32 s80, %[cur], 0xff\nv_lshl_or_b32 v29, v29, 8, s80")
+            emit("s_lshl_b32 %s, %s, 8\ns_and_b32 s80, %%[cur], 0xff\nv_lshl_or_b32 v29, v29, 8, s80" % (rr, rr))
         emit("""
         s_lshr_b32 %%[cur], %%[cur], 8
         s_add_u32 %%[arel], %%[arel], 1
@@ -309,7 +315,7 @@ def head_pick(lane):
     return lambda: emit("v_readlane_b32 s80, v55, %d" % lane)
 
 
-def hbit(lane, one, stage=0, next_head=None):
+def hbit(lane, one, stage=0, next_head=None, breg="s80", keep=False):
     """One decision on head probability `lane` (already in v40), both outcomes specialised: VCC of
     the compare is branched on directly.  Bit 0 falls through; bit 1 goes to label `one`, where
     the caller emits hbit_one(lane) first.
@@ -319,21 +325,20 @@ def hbit(lane, one, stage=0, next_head=None):
     if stage < 1:
         bounds("v40")
     if stage < 2:
-        emit("v_readlane_b32 s80, v55, %d" % lane)
-    emit("""
-    v_cmp_gt_u32 vcc, s80, v29
-    s_cbranch_vccz %s
-    s_mov_b32 %%[range], s80
-    """ % one)
+        emit("v_readlane_b32 %s, v55, %d" % (breg, lane))
+    emit("v_cmp_gt_u32 vcc, %s, v29\ns_cbranch_vccz %s" % (breg, one))
+    if not keep:  # keep (rmov): the new range stays in `breg`; the literal's first level reads it there
+        emit("s_mov_b32 %%[range], %s" % breg)
     head_update(lane, 0)
     if next_head is not None:
+        assert not keep
         nchk(prefix=lambda: bounds("v40"), pick=head_pick(next_head))
     else:
-        nchk()
+        nchk(rreg=breg if keep else None)
 
 
-def hbit_one(lane, next_head=None):
-    emit("v_subrev_u32 v29, s80, v29\ns_sub_u32 %[range], %[range], s80")
+def hbit_one(lane, next_head=None, breg="s80"):
+    emit("v_subrev_u32 v29, %s, v29\ns_sub_u32 %%[range], %%[range], %s" % (breg, breg))
     head_update(lane, 1)
     if next_head is not None:
         nchk(prefix=lambda: bounds("v40"), pick=head_pick(next_head))
@@ -437,20 +442,25 @@ def slot_step(k):
         emit("s_addc_u32 s88, s88, s88")
 
 
+def ismatch_reg():
+    """the SGPR the isMatch bound is read into (rmov keeps it there as the literal's range)"""
+    return "s82" if "rmov" in VARIANT else "s80"
+
+
 def slot_init():
     return "" if "slot0" in VARIANT else "s_mov_b32 s88, 1"
 
 
-def level_rec(k=None):
+def level_rec(k=None, rin="%[range]"):
     """decision of a recorded level on the probability in s86 (parked in lane k of v54)"""
-    emit("s_lshr_b32 s80, %[range], 11\ns_mul_i32 s80, s80, s86")
+    emit("s_lshr_b32 s80, %s, 11\ns_mul_i32 s80, s80, s86" % rin)
     if k is not None and not lgather():
         emit("v_writelane_b32 v54, s86, %d" % k)
-    decide(scalar_bound=True)
+    decide(scalar_bound=True, rin=rin)
     slot_step(k)
 
 
-def walk_rec(nbits, blocks, entries=None):
+def walk_rec(nbits, blocks, entries=None, range0=None):
     """walk() for the 8-level trees (scalar bound: the probability is read with v_readlane, the bound formed
     with s_lshr / s_mul).  entries = label prefix: entered at level k >= 1 through <prefix>k with s88 set."""
     hoist = "rlhoist" in VARIANT and (not entries or "pwhoist" in VARIANT)
@@ -468,7 +478,7 @@ def walk_rec(nbits, blocks, entries=None):
             else:
                 label("%s%d" % (entries, k))
                 fetch_level(k, blocks)
-        level_rec(k)
+        level_rec(k, rin=range0) if (k == 0 and range0) else level_rec(k)
         if hoist and k + 1 < nbits:
             # the next level's probability is read in front of the normalisation branch: the lane read's result
             # has the branch between it and its first use (s_mul)
@@ -696,25 +706,25 @@ def event_limit():
     """)
 
 
-def packet_limits(head_lane):
+def packet_limits(head_lane, breg="s80"):
     """the limit tests of a packet head + the lane read of the first decision's bound (bounds("v40") was
     just emitted).  flim: ONE test -- the output limit is folded into the window-wrap test of the packet
     before (wpos_advance), which turns s99 into -1."""
     if "flim" in VARIANT:
         emit("""
         s_cmp_gt_i32 %%[arel], s99
-        v_readlane_b32 s80, v55, %d
+        v_readlane_b32 %s, v55, %d
         s_cbranch_scc1 %s
-        """ % (head_lane, L("x0")))
+        """ % (breg, head_lane, L("x0")))
         emit(slot_init())  # (a wait state between the lane read and the compare that uses its result)
         return
     emit("""
     s_cmp_gt_u32 %%[arel], %%[arel_lim]
     s_cbranch_scc1 %s
-    v_readlane_b32 s80, v55, %d
+    v_readlane_b32 %s, v55, %d
     s_cmp_ge_u32 %%[pos], %%[pos_lim]
     s_cbranch_scc1 %s
-    """ % (L("x0"), head_lane, L("x0")))
+    """ % (L("x0"), breg, head_lane, L("x0")))
 
 
 def emit_wstubs():
@@ -803,7 +813,7 @@ def literal_tail(run_entry=None):
     head_issue()
 
 
-def plain_literal(run_entry=None):
+def plain_literal(run_entry=None, range0=None):
     """plain literal (:127-175) with its blocks in v50..v53 and base in v39; ends at pktl"""
     if "lit8" in VARIANT or "lit8g" in VARIANT:
         walk8(LIT_BLOCKS)
@@ -813,7 +823,7 @@ def plain_literal(run_entry=None):
         if "lit8" in VARIANT:
             gather8(LIT_BLOCKS)
     else:
-        walk_rec(8, LIT_BLOCKS)
+        walk_rec(8, LIT_BLOCKS, range0=range0)
         if lgather():
             rec_gather_issue("v39", masked=False)
         literal_tail(run_entry=run_entry)
@@ -834,6 +844,14 @@ def sec_packet_after_literal():
     label("pktl")
     emit("s_waitcnt lgkmcnt(0)")
     bounds("v40")
+    if "rmov" in VARIANT:
+        # the isMatch bound is read into s82 and STAYS there as the new range when the bit is 0: the literal's first
+        # level takes it from s82 and writes %[range] itself -- no s_mov per literal (lit8 forms read %[range]: excluded)
+        assert "lit8" not in VARIANT and "lit8g" not in VARIANT and "litrun" not in VARIANT
+        packet_limits(H_IS_MATCH, breg="s82")
+        hbit(H_IS_MATCH, L("match"), stage=2, breg="s82", keep=True)
+        plain_literal(range0="s82")
+        return
     packet_limits(H_IS_MATCH)
     hbit(H_IS_MATCH, L("match"), stage=2)
     plain_literal(run_entry=L("lrent") if "litrun" in VARIANT else None)
@@ -916,8 +934,8 @@ def sec_packet_general():
     label("pkt")
     emit("s_waitcnt lgkmcnt(0)")
     bounds("v40")
-    packet_limits(H_IS_MATCH)
-    hbit(H_IS_MATCH, L("match"), stage=2)
+    packet_limits(H_IS_MATCH, breg=ismatch_reg())
+    hbit(H_IS_MATCH, L("match"), stage=2, breg=ismatch_reg())
     # ------------------------------------------------------------- literal (decompress.go:44-175)
     if "cflag" in VARIANT:
         # `pkt` is reached from a copy (pending; prevByte unknown, so no literal blocks yet) or from the loop's
@@ -1017,7 +1035,7 @@ def sec_match():
     """simple match up to the validity test of the new distance; falls into sec_copy"""
     # ------------------------------------------------------------- match or rep
     label("match")
-    hbit_one(H_IS_MATCH, next_head=H_IS_REP)
+    hbit_one(H_IS_MATCH, next_head=H_IS_REP, breg=ismatch_reg())
     label("match2")  # (a literal run joins here with its own isMatch decision done)
     len_request(P_LEN)  # speculative (a rep match asks for its own trees): one LDS round trip earlier
     hbit(H_IS_REP, L("rep"), stage=2)
