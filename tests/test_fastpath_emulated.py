@@ -148,7 +148,8 @@ def test_committed_loop_decodes_real_streams_on_the_emulator(program, family, n,
 @pytest.mark.parametrize("add,remove", [((), ("lgather",)), ((), ("hdpp",)), ((), ("flim", "cflag")), ((), ("rlhoist", "vperm", "tuc")),
                                         (("lit8g",), ()), (("order3", "pwhoist"), ()), (("order1",), ("bralign",)),
                                         (("litrun",), ("flim",)), (("slot0",), ()), (("slot0", "lit8g"), ("cflag",)),
-                                        (("vprev",), ()), (("rmov",), ()), (("vprev", "slot0", "rmov"), ())])
+                                        (("vprev",), ()), (("rmov",), ()), (("nopos",), ()),
+                                        (("vprev", "slot0", "rmov", "nopos"), ())])
 def test_generator_switches_still_decode(add, remove):
     """the code paths kept in the generator as measured alternatives (profiles/r02/layout_scan.md)
     are not dead code: each of them decodes a stream correctly on the emulator"""
@@ -215,3 +216,20 @@ def test_dictionary_epoch_that_starts_inside_the_output(program):
     assert out == p[:len(out)] and len(out) > n - 700 and exits[1] == 0
     rc, st = _reference_state_at(blob[13:], lc, lp, pb, ds, n, len(out))
     assert (m.s["range"], m.s["code"], m.s["state"], m.s["rep0"]) == (rc.range, rc.code, st.state, st.reps[0])
+
+
+def test_prepared_variants_on_a_window_that_wraps(program):
+    """slot0 + vprev + rmov + nopos (switched off, to be measured next round) on the two
+    configurations the switch test does not reach: a 4 KiB dictionary that wraps several times (nopos keeps the
+    window's fill as max(window.pos, 0 or dictSize)) and an epoch that starts 70 000 bytes into the output, with
+    late-landing loads"""
+    prog = _render(("slot0", "vprev", "rmov", "nopos"), ())
+    for fam, n, lc, lp, pb, ds, base in (("Z", 9000, 1, 1, 1, 4096, 0), ("M", 7000, 3, 0, 2, 4096, 70_000)):
+        p = corpus.plain(fam, 4242 + n, n)
+        blob = corpus.compress_alone(p, dict_size=ds, lc=lc, lp=lp, pb=pb, known_size=True, preset=0)
+        junk = corpus.plain("R", 32, base) if base else b""
+        out, m, entries, exits, in_pos = run_fast_loop(prog, blob[13:], lc, lp, pb, ds, base + n, junk + p, strict_waits=True, base=base)
+        assert out == p[:len(out)] and exits[1] == 0 and entries > 5
+        rc, st = _reference_state_at(blob[13:], lc, lp, pb, ds, n, len(out))
+        assert (m.s["range"], m.s["code"], m.s["state"], m.s["prev"]) == (rc.range, rc.code, st.state, p[len(out) - 1])
+        assert [m.s["rep0"], m.s["rep1"], m.s["rep2"], m.s["rep3"]] == st.reps

@@ -291,6 +291,14 @@ class Machine:
         self.scc = int(a < b)
         self.s[o[0][1]] = min(a, b)
 
+    def i_s_max_u32(self, o, m):
+        a, b = self.rs(o[1]), self.rs(o[2])
+        self.scc = int(a > b)
+        self.s[o[0][1]] = max(a, b)
+
+    def i_s_or_b32(self, o, m):
+        self._logic(o, self.rs(o[1]) | self.rs(o[2]))
+
     def i_s_mul_i32(self, o, m):
         self.s[o[0][1]] = (self.rs(o[1]) * self.rs(o[2])) & M32
 

@@ -696,14 +696,25 @@ def wpos_advance(amount):
     wstubs.append(k)
 
 
-def event_limit():
+def event_limit(pos="%[pos]"):
     """s96 = min(dictSize, window.pos + (pos_lim - pos)), the sum saturated"""
     emit("""
-    s_sub_u32 s80, %[pos_lim], %[pos]
+    s_sub_u32 s80, %[pos_lim], POS
     s_add_u32 s80, s80, %[wpos]
     s_cselect_b32 s80, -1, s80
     s_min_u32 s96, s80, %[dict]
-    """)
+    """.replace("POS", pos))
+
+
+def nopos():
+    """nopos: the output position lives in v17 (wave-uniform) inside the loop -- the addresses of stores and copies
+    are vector operands anyway -- and %[pos] is written back where the loop is left.  What the scalar side needs is
+    how full the window is: window.pos while it has not wrapped, dictSize from then on (s94 = 0 / dictSize, the
+    fill is max(window.pos, s94)).  One scalar instruction less per packet."""
+    if "nopos" in VARIANT:
+        assert "flim" in VARIANT and "cflag" in VARIANT and "vnorm" not in VARIANT and "litrun" not in VARIANT
+        return True
+    return False
 
 
 def packet_limits(head_lane, breg="s80"):
@@ -738,9 +749,15 @@ def emit_wstubs():
             s_cbranch_scc0 %s
             s_sub_u32 %%[wpos], %%[wpos], %%[dict]
             """ % L(k + "n"))
+            if nopos():
+                emit("s_mov_b32 s94, %[dict]")  # the window is full from here on
             label(k + "n")
-            emit("s_cmp_ge_u32 %[pos], %[pos_lim]\ns_cselect_b32 s99, -1, s99")
-            event_limit()
+            if nopos():
+                emit("v_readfirstlane_b32 s81, v17\ns_cmp_ge_u32 s81, %[pos_lim]\ns_cselect_b32 s99, -1, s99")
+                event_limit(pos="s81")
+            else:
+                emit("s_cmp_ge_u32 %[pos], %[pos_lim]\ns_cselect_b32 s99, -1, s99")
+                event_limit()
             emit("s_branch %s" % L(k + "b"))
             continue
         emit("s_sub_u32 %%[wpos], %%[wpos], %%[dict]\ns_branch %s" % L(k + "b"))
@@ -801,11 +818,14 @@ def literal_tail(run_entry=None):
         emit("v_not_b32 v32, s88\nv_and_b32 v32, 0xff, v32")
     else:
         emit("s_andn2_b32 %[prev], 0xff, s88\nv_mov_b32 v32, %[prev]")
-    emit("""
-    v_mov_b32 v61, %[pos]
-    global_store_byte v61, v32, %[outp]
-    s_add_u32 %[pos], %[pos], 1
-    """)
+    if nopos():
+        emit("global_store_byte v17, v32, %[outp]\nv_add_u32 v17, 1, v17")
+    else:
+        emit("""
+        v_mov_b32 v61, %[pos]
+        global_store_byte v61, v32, %[outp]
+        s_add_u32 %[pos], %[pos], 1
+        """)
     wpos_advance("1")
     emit("v_readlane_b32 %[state], %[vlitnext], %[state]")  # stateUpdateLiteral as a 12-lane table
     if run_entry:
@@ -1121,8 +1141,8 @@ def sec_match():
     # while the window is not full window.pos = pos - wbase < dictSize, so both say
     # rep0 <= min(pos - wbase, dictSize - 1).  The end marker (rep0 = 0xFFFFFFFF) fails it too
     # and is told apart out of line.
+    emit("s_max_u32 s80, %[wpos], s94" if nopos() else "s_sub_u32 s80, %[pos], %[wbase]")
     emit("""
-    s_sub_u32 s80, %%[pos], %%[wbase]
     s_min_u32 s80, s80, %%[dictm1]
     s_cmp_le_u32 %%[rep0], s80
     s_cbranch_scc0 %s
@@ -1135,7 +1155,10 @@ def sec_rep():
     # ------------------------------------------------------------- rep match (:685-1123)
     label("rep")
     hbit_one(H_IS_REP, next_head=H_G0)
-    emit("s_cmp_eq_u32 %%[pos], %%[wbase]\ns_cbranch_scc1 %s" % L("x1"))
+    if nopos():
+        emit("s_or_b32 s81, %%[wpos], s94\ns_cbranch_scc0 %s" % L("x1"))  # nothing in the window: pos == wbase
+    else:
+        emit("s_cmp_eq_u32 %%[pos], %%[wbase]\ns_cbranch_scc1 %s" % L("x1"))
     hbit(H_G0, L("g1"), stage=2, next_head=H_REP0_LONG)
     hbit(H_REP0_LONG, L("r0long"), stage=2)
     emit("""
@@ -1189,12 +1212,12 @@ def sec_copy():
     s_min_u32 s80, s93, 64
     s_cmp_lt_u32 s89, s80
     s_cselect_b32 s80, s93, -1
-    s_sub_u32 s81, %%[pos], %%[wbase]
+    FILL
     s_cmp_le_u32 s80, s81
     s_cbranch_scc0 %s
-    """ % L("x3"))
+    """.replace("FILL", "s_max_u32 s81, %%[wpos], s94" if nopos() else "s_sub_u32 s81, %%[pos], %%[wbase]") % L("x3"))
     need_copy_done(inline=True)  # the new source may overlap the bytes the pending copy still has to store
-    emit("v_add_u32 v48, %[pos], %[vlane]\nv_subrev_u32 v61, s93, v48")
+    emit("v_add_u32 v48, %s, %%[vlane]\nv_subrev_u32 v61, s93, v48" % ("v17" if nopos() else "%[pos]"))
     if "nocmask" in VARIANT:
         emit("global_load_ubyte v49, v61, %[outp]")
     else:
@@ -1209,10 +1232,8 @@ def sec_copy():
         """)
     if "cflag" not in VARIANT:
         emit("s_mov_b32 s94, 1")
-    emit("""
-    s_mov_b32 s95, s89
-    s_add_u32 %[pos], %[pos], s89
-    """)
+    emit("s_mov_b32 s95, s89")
+    emit("v_add_u32 v17, s89, v17" if nopos() else "s_add_u32 %[pos], %[pos], s89")
     wpos_advance("s89")
     head_issue()  # next packet's head gather; its literal blocks wait for the copy (prevByte)
     if "cflag" not in VARIANT:
@@ -1237,6 +1258,8 @@ def sec_exits():
     need_copy_done()
     if "vprev" in VARIANT:
         emit("v_readfirstlane_b32 %[prev], v32")
+    if nopos():
+        emit("v_readfirstlane_b32 %[pos], v17")
     emit("s_waitcnt lgkmcnt(0)\nds_write_b16 v47, v40\ns_waitcnt lgkmcnt(0)\ns_branch %s" % L("end"))
     emit_stubs()
     emit_wstubs()
@@ -1302,6 +1325,13 @@ def gen():
     if "flim" in VARIANT:
         emit("s_mov_b32 s99, %[arel_lim]")
         event_limit()
+    if nopos():
+        emit("""
+        v_mov_b32 v17, %[pos]
+        s_sub_u32 s80, %[pos], %[wbase]
+        s_cmp_ge_u32 s80, %[dict]
+        s_cselect_b32 s94, %[dict], 0
+        """)
     head_issue(first=True)
     if "vprev" in VARIANT:
         emit("v_mov_b32 v32, %[prev]")
