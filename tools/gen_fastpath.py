@@ -422,9 +422,12 @@ def tree_update(nb, blocks, base="v58"):
 # data), so these trees keep a record: the probability of level k is parked in lane k of v54
 # (v_writelane) and ONE vector operation, lanes = levels, updates them.
 
-def fetch_level(k, blocks):
-    """probability of tree slot s88 at level k (0-based) of an 8-level tree -> s86"""
-    if k <= 5:
+def fetch_level(k, blocks, merged=False):
+    """probability of tree slot s88 at level k (0-based) of an 8-level tree -> s86.  merged (l7blk): v62 already
+    holds the one of the two last-level blocks this walk can reach (its first decision chose it)"""
+    if k == 7 and merged:
+        emit("v_readlane_b32 s86, v62, s88")
+    elif k <= 5:
         emit("v_readlane_b32 s86, %s, s88" % blocks[0])
     elif k == 6:
         emit("v_readlane_b32 s86, %s, s88" % blocks[1])
@@ -479,24 +482,30 @@ def walk_rec(nbits, blocks, entries=None, range0=None):
                 label("%s%d" % (entries, k))
                 fetch_level(k, blocks)
         level_rec(k, rin=range0) if (k == 0 and range0) else level_rec(k)
+        merged = "l7blk" in VARIANT and not entries and nbits == 8
+        if merged and k == 0:
+            # slots 128..255 of the last level lie in blocks[2] (first decided bit 1) or blocks[3] (bit 0: the slot's
+            # complemented bit 6 is set), and VCC still holds level 0's borrow = that complemented bit in every lane:
+            # one select now replaces two lane reads + a bit test + a scalar select at level 7
+            emit("v_cndmask_b32 v62, %s, %s, vcc" % (blocks[2], blocks[3]))
         if hoist and k + 1 < nbits:
             # the next level's probability is read in front of the normalisation branch: the lane read's result
             # has the branch between it and its first use (s_mul)
             uid[0] += 1
             kk = "n%d" % uid[0]
-            if k + 1 == 7:  # (its block select uses SCC)
+            if k + 1 == 7 and not merged:  # (its block select uses SCC)
                 fetch_level(k + 1, blocks)
                 emit("s_lshr_b32 s81, %[range], 24")
             else:
                 emit("s_lshr_b32 s81, %[range], 24")
-                fetch_level(k + 1, blocks)
+                fetch_level(k + 1, blocks, merged)
             emit("s_cbranch_scc0 %s" % L(kk))
             label(kk + "b")  # (the stub changes neither the slot nor the probability read for it)
             stubs.append(kk)
             continue
         nchk()
         if k + 1 < nbits and not entries:
-            fetch_level(k + 1, blocks)
+            fetch_level(k + 1, blocks, merged)
 
 
 def walk8(blocks, entries=None):
