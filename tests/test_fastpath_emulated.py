@@ -162,9 +162,12 @@ def test_generator_switches_still_decode(add, remove):
     assert (m.s["range"], m.s["code"], m.s["state"], m.s["rep0"]) == (rc.range, rc.code, st.state, st.reps[0])
 
 
-def test_end_marker_and_error_exits(program):
+@pytest.mark.parametrize("variants", [(), ("slot0", "vprev", "rmov", "nopos", "l7blk")])
+def test_end_marker_and_error_exits(program, variants):
     """exit 2 (distance 0xFFFFFFFF: the end marker, decompress.go:633-645) on a stream of unknown size, and exit 1
     (a distance the window does not hold, :651-653) on corrupted streams: same position and bytes as the oracle"""
+    if variants:
+        program = _render(variants, ())
     lc, lp, pb, ds, n = 3, 0, 2, 1 << 16, 3000
     p = corpus.plain("T", 5, n)
     blob = corpus.compress_alone(p, dict_size=ds, known_size=False, preset=6)       # ends with the marker
