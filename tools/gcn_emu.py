@@ -276,6 +276,11 @@ class Machine:
     def i_s_lshr_b32(self, o, m):
         self._logic(o, self.rs(o[1]) >> (self.rs(o[2]) & 31))
 
+    def i_s_ashr_i32(self, o, m):
+        a = self.rs(o[1])
+        a = a - (1 << 32) if a >> 31 else a
+        self._logic(o, a >> (self.rs(o[2]) & 31))
+
     def i_s_lshr_b64(self, o, m):
         r = self.rs64(o[1]) >> (self.rs(o[2]) & 63)
         self.ws64(o[0], r)

@@ -228,6 +228,19 @@ def emit_stubs():
             emit("s_lshl_b32 %s, %s, 8\nv_perm_b32 v29, v29, %%[cur], v13" % (rr, rr))
         else:
             emit("s_lshl_b32 %s, %s, 8\ns_and_b32 s80, %%[cur], 0xff\nv_lshl_or_b32 v29, v29, 8, s80" % (rr, rr))
+        if "warel" in VARIANT:
+            # the input position as (word s90, bytes left in it after this one s91): the countdown's borrow IS the
+            # "word used up" test -- one scalar instruction less per input byte; %[arel] is rebuilt where the loop is left
+            emit("""
+            s_lshr_b32 %%[cur], %%[cur], 8
+            s_sub_u32 s91, s91, 1
+            s_cbranch_scc0 %s
+            s_add_u32 s90, s90, 1
+            s_mov_b32 s91, 3
+            v_readlane_b32 %%[cur], %%[vin], s90
+            s_branch %s
+            """ % (L(k + "b"), L(k + "b")))
+            continue
         emit("""
         s_lshr_b32 %%[cur], %%[cur], 8
         s_add_u32 %%[arel], %%[arel], 1
@@ -732,10 +745,10 @@ def packet_limits(head_lane, breg="s80"):
     before (wpos_advance), which turns s99 into -1."""
     if "flim" in VARIANT:
         emit("""
-        s_cmp_gt_i32 %%[arel], s99
+        s_cmp_gt_i32 AREL, s99
         v_readlane_b32 %s, v55, %d
         s_cbranch_scc1 %s
-        """ % (breg, head_lane, L("x0")))
+        """.replace("AREL", "s90" if "warel" in VARIANT else "%%[arel]") % (breg, head_lane, L("x0")))
         emit(slot_init())  # (a wait state between the lane read and the compare that uses its result)
         return
     emit("""
@@ -1269,6 +1282,8 @@ def sec_exits():
         emit("v_readfirstlane_b32 %[prev], v32")
     if nopos():
         emit("v_readfirstlane_b32 %[pos], v17")
+    if "warel" in VARIANT:
+        emit("s_sub_u32 s80, 3, s91\ns_lshl2_add_u32 %[arel], s90, s80")
     emit("s_waitcnt lgkmcnt(0)\nds_write_b16 v47, v40\ns_waitcnt lgkmcnt(0)\ns_branch %s" % L("end"))
     emit_stubs()
     emit_wstubs()
@@ -1332,7 +1347,18 @@ def gen():
     v_cndmask_b32 v20, v20, 7, vcc
     """ % (P_POS_SLOT * 2))
     if "flim" in VARIANT:
-        emit("s_mov_b32 s99, %[arel_lim]")
+        if "warel" in VARIANT:
+            # word-granular input limit: a packet may start up to 3 bytes later than arel_lim says (>= 29 of the 32
+            # bytes of slack remain; a packet reads at most 20, types.go:38)
+            assert "litrun" not in VARIANT
+            emit("""
+            s_ashr_i32 s99, %[arel_lim], 2
+            s_lshr_b32 s90, %[arel], 2
+            s_and_b32 s91, %[arel], 3
+            s_sub_u32 s91, 3, s91
+            """)
+        else:
+            emit("s_mov_b32 s99, %[arel_lim]")
         event_limit()
     if nopos():
         emit("""
