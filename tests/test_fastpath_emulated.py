@@ -132,6 +132,7 @@ def test_committed_loop_decodes_real_streams_on_the_emulator(program, family, n,
     p = corpus.plain(family, 4242 + n, n)
     blob = corpus.compress_alone(p, dict_size=ds, lc=lc, lp=lp, pb=pb, known_size=True, preset=6 if family == "T" else 0)
     assert oracle.lzma1_alone(blob, n)[0] == p
+    ds = max(4096, int.from_bytes(blob[1:5], "little"))     # (liblzma rounds the dictionary size in the header up)
     payload = blob[13:]
     out, m, entries, exits, in_pos = run_fast_loop(program, payload, lc, lp, pb, ds, n, p)
     assert out == p[:len(out)]
