@@ -66,7 +66,7 @@ def main():
                 got = (m.s["range"], m.s["code"], m.s["state"], [m.s["rep0"], m.s["rep1"], m.s["rep2"], m.s["rep3"]], in_pos)
                 assert got == (rc.range, rc.code, st.state, st.reps, rc.p), "state differs at the hand-over: %r" % (got,)
                 if out:
-                    assert m.s["prev"] == p[len(out) - 1], "prevByte differs"
+                    assert m.s["prev"] == want[len(out) - 1], "prevByte differs"
         except Exception as e:  # noqa: BLE001
             print("MISMATCH (%s): %s: %s" % (what, type(e).__name__, e), flush=True)
             raise

@@ -109,11 +109,14 @@ class Machine:
         m = parts[0]
         rest = parts[1] if len(parts) > 1 else ""
         mods = {}
-        for key in ("offset", "row_mask", "bank_mask"):
+        for key in ("offset", "row_mask", "bank_mask", "row_shr"):
             mm = re.search(key + r":(\w+)", rest)
             if mm:
                 mods[key] = int(mm.group(1), 0)
                 rest = rest.replace(mm.group(0), "")
+        mm = re.search(r"quad_perm:\[(\d),(\d),(\d),(\d)\]", rest)
+        if mm:
+            mods["quad_perm"] = [int(x) for x in mm.groups()]
         rest = re.sub(r"quad_perm:\[[^\]]*\]", "", rest)
         ops = [self._reg(o) for o in _split_ops(rest)]
         base = m[:-4] if m.endswith("_e64") or m.endswith("_e32") else m
@@ -494,11 +497,28 @@ class Machine:
     def i_v_readfirstlane_b32(self, o, m):
         self.s[o[0][1]] = int(self.v[o[1][1]][0])
 
-    def i_v_sub_u32_dpp(self, o, mods):
+    def _dpp(self, mods, src):
+        """(enabled lanes, src0 as the DPP control presents it); bound_ctrl is 0: a lane without a source is disabled"""
         rm, bm = mods["row_mask"], mods["bank_mask"]
         lane = np.arange(64)
         en = (((rm >> (lane // 16)) & 1) & ((bm >> ((lane % 16) // 4)) & 1)).astype(bool)
-        self.wv(o[0], self.rv(o[1]) - self.rv(o[2]), mask=en)
+        from_lane = lane.copy()
+        if "row_shr" in mods:
+            from_lane = lane - mods["row_shr"]
+            en &= (lane % 16) >= mods["row_shr"]
+            from_lane = np.where(from_lane < 0, 0, from_lane)
+        elif mods.get("quad_perm", [0, 1, 2, 3]) != [0, 1, 2, 3]:
+            qp = np.array(mods["quad_perm"])
+            from_lane = (lane // 4) * 4 + qp[lane % 4]
+        return en, src[from_lane]
+
+    def i_v_sub_u32_dpp(self, o, mods):
+        en, a = self._dpp(mods, self.rv(o[1]))
+        self.wv(o[0], a - self.rv(o[2]), mask=en)
+
+    def i_v_mov_b32_dpp(self, o, mods):
+        en, a = self._dpp(mods, self.rv(o[1]))
+        self.wv(o[0], a, mask=en)
 
     # ---- LDS / memory -----------------------------------------------------------------------------
     def i_ds_read_u16(self, o, mods):

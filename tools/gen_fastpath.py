@@ -1083,7 +1083,12 @@ def sec_match():
     hbit(H_IS_REP, L("rep"), stage=2)
     # simple match (:215-668)
     bounds("v40")  # for the length coder's first decision
-    emit("s_mov_b32 %[rep3], %[rep2]\ns_mov_b32 %[rep2], %[rep1]\ns_mov_b32 %[rep1], %[rep0]")
+    if "vreps" in VARIANT:
+        # the four reps live in lanes 0..3 of v34 (lane 0 mirrors the scalar rep0): the shift of :216 is one DPP move,
+        # the rotations of a rep match one quad permute + one lane read; rep1..3 go back to SGPRs where the loop is left
+        emit("v_mov_b32_dpp v34, v34 row_shr:1 row_mask:0x1 bank_mask:0x1")
+    else:
+        emit("s_mov_b32 %[rep3], %[rep2]\ns_mov_b32 %[rep2], %[rep1]\ns_mov_b32 %[rep1], %[rep0]")
     len_pick(H_LEN_C)
     emit("ds_read_u16 v35, v56 offset:%d" % (P_ALIGN * 2))
     len_decode("lm", P_LEN, H_LEN_C, H_LEN_C2, posslot=True)  # leaves the posSlot block requested, s92 = its base
@@ -1159,6 +1164,8 @@ def sec_match():
     tree_update(4, ["v35"])
     emit("v_readlane_b32 s80, v23, s88\ns_add_u32 %[rep0], s93, s80")  # v23: slot -> the four bits, reversed
     label("distdone")
+    if "vreps" in VARIANT:
+        emit("v_writelane_b32 v34, %[rep0], 0")
     # :633-653 in one test.  rep0 is valid iff rep0 < dictSize and (window full or rep0 <= window.pos);
     # while the window is not full window.pos = pos - wbase < dictSize, so both say
     # rep0 <= min(pos - wbase, dictSize - 1).  The end marker (rep0 = 0xFFFFFFFF) fails it too
@@ -1195,26 +1202,37 @@ def sec_rep():
     label("g1")
     hbit_one(H_G0, next_head=H_G1)
     hbit(H_G1, L("g2"), stage=2)
-    emit("s_mov_b32 s80, %%[rep1]\ns_mov_b32 %%[rep1], %%[rep0]\ns_mov_b32 %%[rep0], s80\ns_branch %s" % L("replen"))
+    if "vreps" in VARIANT:
+        emit("v_readlane_b32 %%[rep0], v34, 1\nv_mov_b32_dpp v34, v34 quad_perm:[1,0,2,3] row_mask:0x1 bank_mask:0x1\ns_branch %s"
+             % L("replen"))
+    else:
+        emit("s_mov_b32 s80, %%[rep1]\ns_mov_b32 %%[rep1], %%[rep0]\ns_mov_b32 %%[rep0], s80\ns_branch %s" % L("replen"))
     label("g2")
     hbit_one(H_G1, next_head=H_G2)
     hbit(H_G2, L("g3"), stage=2)
-    emit("""
-    s_mov_b32 s80, %%[rep2]
-    s_mov_b32 %%[rep2], %%[rep1]
-    s_mov_b32 %%[rep1], %%[rep0]
-    s_mov_b32 %%[rep0], s80
-    s_branch %s
-    """ % L("replen"))
+    if "vreps" in VARIANT:
+        emit("v_readlane_b32 %%[rep0], v34, 2\nv_mov_b32_dpp v34, v34 quad_perm:[2,0,1,3] row_mask:0x1 bank_mask:0x1\ns_branch %s"
+             % L("replen"))
+    else:
+        emit("""
+        s_mov_b32 s80, %%[rep2]
+        s_mov_b32 %%[rep2], %%[rep1]
+        s_mov_b32 %%[rep1], %%[rep0]
+        s_mov_b32 %%[rep0], s80
+        s_branch %s
+        """ % L("replen"))
     label("g3")
     hbit_one(H_G2)
-    emit("""
-    s_mov_b32 s80, %[rep3]
-    s_mov_b32 %[rep3], %[rep2]
-    s_mov_b32 %[rep2], %[rep1]
-    s_mov_b32 %[rep1], %[rep0]
-    s_mov_b32 %[rep0], s80
-    """)
+    if "vreps" in VARIANT:
+        emit("v_readlane_b32 %[rep0], v34, 3\nv_mov_b32_dpp v34, v34 quad_perm:[3,0,1,2] row_mask:0x1 bank_mask:0x1")
+    else:
+        emit("""
+        s_mov_b32 s80, %[rep3]
+        s_mov_b32 %[rep3], %[rep2]
+        s_mov_b32 %[rep2], %[rep1]
+        s_mov_b32 %[rep1], %[rep0]
+        s_mov_b32 %[rep0], s80
+        """)
     label("replen")
     bounds("v40")
     len_request(P_REP_LEN)
@@ -1284,6 +1302,8 @@ def sec_exits():
         emit("v_readfirstlane_b32 %[pos], v17")
     if "warel" in VARIANT:
         emit("s_sub_u32 s80, 3, s91\ns_lshl2_add_u32 %[arel], s90, s80")
+    if "vreps" in VARIANT:
+        emit("v_readlane_b32 %[rep1], v34, 1\nv_readlane_b32 %[rep2], v34, 2\nv_readlane_b32 %[rep3], v34, 3")
     emit("s_waitcnt lgkmcnt(0)\nds_write_b16 v47, v40\ns_waitcnt lgkmcnt(0)\ns_branch %s" % L("end"))
     emit_stubs()
     emit_wstubs()
@@ -1360,6 +1380,14 @@ def gen():
         else:
             emit("s_mov_b32 s99, %[arel_lim]")
         event_limit()
+    if "vreps" in VARIANT:
+        assert "litrun" not in VARIANT  # (v34)
+        emit("""
+        v_mov_b32 v34, %[rep0]
+        v_writelane_b32 v34, %[rep1], 1
+        v_writelane_b32 v34, %[rep2], 2
+        v_writelane_b32 v34, %[rep3], 3
+        """)
     if nopos():
         emit("""
         v_mov_b32 v17, %[pos]
