@@ -76,6 +76,10 @@ H_IS_MATCH, H_IS_REP, H_G0, H_G1, H_G2, H_REP0_LONG, H_LEN_C, H_LEN_C2, H_REP_C,
 #   vperm    normalisation: code = code << 8 | byte as one v_perm_b32 (no scalar mask of the byte)
 #   bralign  tools/layout.py: conditional branches in the lower half of a 16-byte block; stub32 / head32 /
 #            pktl64: normalisation stubs, out-of-line blocks and the literal loop on 32 / 32 / 64-byte boundaries
+# count-only changes prepared in round 2, checked on the emulator (tests/test_fastpath_emulated.py, tools/fuzz_emulated.py);
+# the first five measured once on the hardware (+6.6 % on incompressible data, +0.9 % on text, profiles/r02/layout_scan.md):
+# `--variant next` switches all of them on
+NEXT_VARIANT = {"slot0", "vprev", "rmov", "nopos", "l7blk", "warel", "vreps"}
 DEFAULT_VARIANT = {"lgather", "hdpp", "flim", "cflag", "tuc", "vperm", "rlhoist", "bralign", "stub32", "head32", "pktl64"}
 VARIANT = set(DEFAULT_VARIANT)
 
@@ -1459,6 +1463,9 @@ if __name__ == "__main__":
         OUT = sys.argv[sys.argv.index("--out") + 1]
     if "--without" in sys.argv:
         VARIANT.difference_update(sys.argv[sys.argv.index("--without") + 1].split(","))
+    if "next" in VARIANT:
+        VARIANT.discard("next")
+        VARIANT.update(NEXT_VARIANT)
     text, final, n_nops = render()
     with open(OUT, "w") as f:
         f.write(text)
