@@ -51,7 +51,8 @@ enum {
     XLZ_ERR_BAD_ARG = -7,        /* new: NULL pointer / unknown format                           */
     XLZ_ERR_DEVICE = -8,         /* new: HIP runtime failure or no gfx950 device                 */
     XLZ_ERR_UNSUPPORTED = -9,    /* new: stream outside what the GPU path implements (DESIGN.md
-                                    section 5: >= 4 GiB of input or output per stream)          */
+                                    section 5.2: a dictionary > 2 GiB on a stream >= 4 GiB; a unit
+                                    >= 4 GiB of a device-resident xlz_batch; container features) */
     XLZ_ERR_CLOSED = -10,        /* errAlreadyClosed (readcloser.go:14)                          */
     XLZ_ERR_NEED_ONE_READER = -11, /* errNeedOneReader (reader1.go:26)                           */
     XLZ_ERR_INSUFFICIENT_PROPS = -12 /* errInsufficientProperties (reader2.go:43)                */
@@ -87,6 +88,8 @@ typedef struct xlz_result {
 
 /* ---- library ------------------------------------------------------------- */
 const char *xlz_version(void);
+const char *xlz_build_id(void);       /* hash of the sources this binary was compiled from (lzma_amd/build.py);
+                                         measurements quote it so that a number names the kernel that ran   */
 const char *xlz_strerror(int status); /* text of the matching reference error (errors.go:5-12)    */
 int xlz_device_count(void);           /* number of HIP devices, 0 if none                         */
 

@@ -444,10 +444,12 @@ def xz_index(data):
     return [{f: getattr(blocks[i], f) for f in fields} for i in range(n.value)], total.value
 
 
-def xz_decode(ctx, data, verify=True):
+def xz_decode(ctx, data, verify=True, max_size=None):
     """Decode a whole .xz file (all streams, all blocks) as one GPU batch -> bytes.
-    verify: check every block's CRC32 / CRC64."""
+    verify: check every block's CRC32 / CRC64.  max_size: refuse (ERR_OUT_CAP) a file whose index announces more."""
     _, total = xz_index(data)
+    if max_size is not None and total > max_size:
+        raise LzmaError(ERR_OUT_CAP, "xlz_xz_decode: the index announces %d bytes, max_size is %d" % (total, max_size))
     buf = ctypes.create_string_buffer(data, len(data))
     out = ctypes.create_string_buffer(max(total, 1))
     out_len = ctypes.c_uint64()
@@ -481,9 +483,13 @@ def sevenzip_index(data, ctx=None):
             [(su[i].size, su[i].crc if su[i].has_crc else None) for i in range(ns.value)], total.value)
 
 
-def sevenzip_decode(ctx, data, verify=True):
-    """Decode every folder of a .7z archive as one GPU batch -> the files' bytes back to back."""
+def sevenzip_decode(ctx, data, verify=True, max_size=None):
+    """Decode every folder of a .7z archive as one GPU batch -> the files' bytes back to back.
+    max_size: refuse (ERR_OUT_CAP) an archive whose header announces more decoded bytes than that -- the sizes come
+    from an untrusted header and the output buffer is allocated from them."""
     _, _, total = sevenzip_index(data, ctx)
+    if max_size is not None and total > max_size:
+        raise LzmaError(ERR_OUT_CAP, "xlz_7z_decode: the archive announces %d bytes, max_size is %d" % (total, max_size))
     buf = ctypes.create_string_buffer(data, len(data))
     out = ctypes.create_string_buffer(max(total, 1))
     out_len = ctypes.c_uint64()

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.environ.get("XLZ_SO") or os.path.join(_HERE, "libxlz.so")  # XLZ_SO: A/B builds
+DEFAULT_SO = os.path.join(_HERE, "libxlz.so")
+SO_PATH = os.environ.get("XLZ_SO") or DEFAULT_SO  # XLZ_SO: A/B builds (announced on stderr when used; bench.py refuses it)
 
 # status codes (include/xlz.h)
 OK = 0
@@ -35,7 +36,7 @@ UNKNOWN_SIZE = 0xFFFFFFFFFFFFFFFF
 
 # every symbol include/xlz.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "xlz_version", "xlz_strerror", "xlz_device_count", "xlz_decode_prop", "xlz_decode_dict_size",
+    "xlz_version", "xlz_build_id", "xlz_strerror", "xlz_device_count", "xlz_decode_prop", "xlz_decode_dict_size",
     "xlz_decode_dict_size2", "xlz_decode_unpack_size", "xlz_ctx_create", "xlz_ctx_destroy",
     "xlz_ctx_device", "xlz_ctx_event_record", "xlz_ctx_event_elapsed_ms", "xlz_ctx_enable_batching",
     "xlz_ctx_batching_stats", "xlz_decode_batch", "xlz_batch_create", "xlz_batch_run", "xlz_batch_sync",
@@ -115,9 +116,13 @@ def lib():
         raise RuntimeError(
             "lzma_amd: %s is missing -- build the HIP extension first "
             "(python -m lzma_amd.build); there is no CPU fallback" % SO_PATH)
+    if SO_PATH != DEFAULT_SO:
+        import sys
+        print("lzma_amd: XLZ_SO is set -- loading %s instead of the in-tree library" % SO_PATH, file=sys.stderr)
     L = ctypes.CDLL(SO_PATH)
     vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     L.xlz_version.restype = ctypes.c_char_p
+    L.xlz_build_id.restype = ctypes.c_char_p
     L.xlz_strerror.restype = ctypes.c_char_p
     L.xlz_strerror.argtypes = [i32]
     L.xlz_device_count.restype = i32
@@ -180,3 +185,17 @@ def lib():
 
 def strerror(status):
     return lib().xlz_strerror(status).decode()
+
+
+def library_info():
+    """which binary is loaded: path, SHA-256 of the file, the source hash compiled into it and the hash of the
+    sources in the tree now (equal unless the library is stale or was swapped with XLZ_SO)"""
+    import hashlib
+    from . import build
+    with open(SO_PATH, "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()
+    bid = lib().xlz_build_id().decode()
+    tree = build.source_id()
+    return {"path": os.path.relpath(SO_PATH, os.path.dirname(_HERE)) if SO_PATH.startswith(os.path.dirname(_HERE)) else SO_PATH,
+            "sha256": sha, "build_id": bid, "tree_source_id": tree, "built_from_tree": bid == tree,
+            "xlz_so_override": SO_PATH != DEFAULT_SO}

@@ -15,6 +15,17 @@ HEADERS = ["xlz_format.h", "xlz_check.h", "xlz_fastpath.inc", os.path.join("..",
 ARCH = "gfx950"
 
 
+def source_id():
+    """12 hex digits over every source the library is compiled from: compiled into the library (xlz_build_id) so that
+    a bench line or a test can tell WHICH kernel ran, whatever the file's time stamp says"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
 def _stale():
     if not os.path.exists(SO):
         return True
@@ -26,13 +37,14 @@ def _stale():
 def build(force=False, verbose=False, extra_flags=(), out=None):
     """Compile every HIP source for gfx950 into lzma_amd/libxlz.so."""
     if out is None and os.environ.get("XLZ_SO"):
+        print("lzma_amd.build: XLZ_SO is set, not building: %s" % os.environ["XLZ_SO"], file=sys.stderr)
         return os.environ["XLZ_SO"]  # an A/B build made by hand
     if out is None and not force and not _stale():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-           "-I", os.path.join(HERE, "..", "include")]
+           "-I", os.path.join(HERE, "..", "include"), '-DXLZ_BUILD_ID="%s"' % source_id()]
     cmd += list(extra_flags)
     cmd += [os.path.join(CSRC, f) for f in SOURCES]
     cmd += ["-o", out or SO]

@@ -41,6 +41,7 @@ struct Rd {
     const uint8_t *p;
     size_t n, pos = 0;
     bool bad = false;
+    size_t left() const { return n - pos; }
     uint8_t byte()
     {
         if (pos >= n) {
@@ -83,7 +84,7 @@ struct Digests {
 
 bool read_digests(Rd &r, uint64_t count, Digests &d)
 {
-    if (count > kMaxItems) return false;
+    if (count > kMaxItems || count > 8 * (uint64_t)r.left()) return false; // >= 1 bit of header per digest
     d.defined.assign((size_t)count, 1);
     d.crc.assign((size_t)count, 0);
     if (r.byte() == 0) { // not all defined: a bit vector, MSB first
@@ -142,7 +143,9 @@ bool read_folder(Rd &r, Folder &f)
         if (mb & 0x10) {
             n_in = r.number();
             n_out = r.number();
-            if (n_in > 32 || n_out > 32) return false;
+            // a coder without an input or an output stream does not exist (7-Zip refuses it); with n_in == 0 the
+            // folder below would claim zero packed streams and place_folders would index past PackInfo
+            if (n_in == 0 || n_out == 0 || n_in > 32 || n_out > 32) return false;
         }
         uint64_t psz = 0;
         size_t ppos = r.pos;
@@ -174,6 +177,7 @@ bool read_folder(Rd &r, Folder &f)
         r.number();
     }
     const uint64_t n_packed = total_in - n_bind;
+    if (n_packed == 0) return false; // every folder consumes at least one packed stream
     if (n_packed > 1)
         for (uint64_t k = 0; k < n_packed; k++) r.number();
     f.method = method;
@@ -191,6 +195,7 @@ int read_streams_info(Rd &r, Streams &s)
         if (n > kMaxItems) return XLZ_ERR_UNSUPPORTED;
         id = r.byte();
         if (id == kSize) {
+            if (n > r.left()) return XLZ_ERR_RESULT; // every size is at least one byte: no allocation the header cannot back
             s.pack_sizes.resize((size_t)n);
             for (auto &v : s.pack_sizes) v = r.number();
             id = r.byte();
@@ -208,6 +213,7 @@ int read_streams_info(Rd &r, Streams &s)
         const uint64_t nf = r.number();
         if (nf > kMaxItems) return XLZ_ERR_UNSUPPORTED;
         if (r.byte() != 0) return XLZ_ERR_UNSUPPORTED; // external folder definitions
+        if (nf > r.left() / 3) return XLZ_ERR_RESULT; // a folder takes >= 2 header bytes + 1 byte of unpack size
         s.folders.resize((size_t)nf);
         for (auto &f : s.folders)
             if (!read_folder(r, f)) return XLZ_ERR_RESULT;
@@ -241,9 +247,15 @@ int read_streams_info(Rd &r, Streams &s)
             }
             id = r.byte();
         }
-        uint64_t total_sub = 0;
-        for (auto &f : s.folders) total_sub += f.n_sub;
+        uint64_t total_sub = 0, sized = 0;
+        for (auto &f : s.folders) {
+            total_sub += f.n_sub;
+            sized += f.n_sub ? f.n_sub - 1 : 0; // sizes in the header: all but the last of each folder
+        }
         if (total_sub > kMaxItems) return XLZ_ERR_UNSUPPORTED;
+        // the sizes must be in the header (one byte each at least); without a kSize attribute a folder has at most
+        // one stream whose size is known at all
+        if (sized > (id == kSize ? (uint64_t)r.left() : 0)) return XLZ_ERR_RESULT;
         s.subs.clear();
         for (auto &f : s.folders) { // sizes: all but the last of each folder, the last is the rest
             uint64_t sum = 0;
@@ -308,7 +320,7 @@ int place_folders(const Streams &s, size_t file_len, std::vector<xlz_7z_folder> 
         memset(&o, 0, sizeof o);
         o.method = f.method;
         if (f.n_pack != 1) o.method = XLZ_7Z_UNSUPPORTED;
-        if (pi + f.n_pack > s.pack_sizes.size()) return XLZ_ERR_RESULT;
+        if (f.n_pack < 1 || pi >= s.pack_sizes.size() || f.n_pack > s.pack_sizes.size() - pi) return XLZ_ERR_RESULT;
         o.pack_off = off;
         o.pack_len = s.pack_sizes[pi];
         for (uint32_t k = 0; k < f.n_pack; k++) {

@@ -129,6 +129,11 @@ struct xlz_batch {
 // ---------------------------------------------------------------- helpers ----
 extern "C" const char *xlz_version(void) { return "xlz 0.1 (gfx950)"; }
 
+#ifndef XLZ_BUILD_ID // lzma_amd/build.py: hash of every source file this library was compiled from
+#define XLZ_BUILD_ID "unknown"
+#endif
+extern "C" const char *xlz_build_id(void) { return XLZ_BUILD_ID; }
+
 extern "C" const char *xlz_strerror(int st)
 {
     switch (st) {
@@ -1384,33 +1389,37 @@ int session_prepare(xlz_reader *r, hipStream_t stream)
               ((ss->in_loaded < total || more_coming) ? UNIT_F_MORE_INPUT : 0u);
     if (ss->started && r->pending_reset) u.flags |= UNIT_F_RESET_MODEL; // before the first launch the model is fresh anyway
     if (ss->started && r->pending_reopen) u.flags |= UNIT_F_REOPEN;
-    r->pending_reset = r->pending_reopen = false;
+    // (pending_reset / pending_reopen are cleared by sessions_step once the launch that consumed them has succeeded)
     return XLZ_OK;
 }
 
 // One refill of every reader in `rs` as ONE launch: each reader's unit continues from its saved
 // state and stops after about kChunk more bytes.  Fills r->chunk / r->finished / r->status.
-int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs)
+int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &all)
 {
-    if (rs.empty()) return XLZ_OK;
+    if (all.empty()) return XLZ_OK;
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t n = rs.size();
     uint32_t max_lc_lp = 0;
-    std::vector<Unit> units(n);
-    for (size_t i = 0; i < n; i++) {
-        int st = session_prepare(rs[i], ctx->stream);
-        if (st == XLZ_ERR_UNSUPPORTED && n == 1) { // this stream ends here; others are not affected
-            rs[i]->finished = true;
-            rs[i]->status = XLZ_ERR_UNSUPPORTED;
-            rs[i]->chunk.clear();
-            rs[i]->rd = 0;
-            return XLZ_OK;
+    std::vector<xlz_reader *> live; // the readers of this launch: one that cannot be prepared ends alone
+    std::vector<Unit> units;
+    for (xlz_reader *r : all) {
+        int st = session_prepare(r, ctx->stream);
+        if (st == XLZ_ERR_UNSUPPORTED) { // this stream ends here; the others are not affected
+            r->finished = true;
+            r->status = XLZ_ERR_UNSUPPORTED;
+            r->chunk.clear();
+            r->rd = 0;
+            continue;
         }
-        if (st != XLZ_OK) return st;
-        units[i] = rs[i]->ss->unit;
-        max_lc_lp = std::max(max_lc_lp, rs[i]->ss->model_lc_lp);
+        if (st != XLZ_OK) return st; // the device failed: nothing was launched, pending Reset / Reopen flags are still set
+        live.push_back(r);
+        units.push_back(r->ss->unit);
+        max_lc_lp = std::max(max_lc_lp, r->ss->model_lc_lp);
     }
+    if (live.empty()) return XLZ_OK;
+    const std::vector<xlz_reader *> &rs = live;
+    const size_t n = rs.size();
     // units / order / results of this launch: in the first reader's control block when it is alone,
     // else in a scratch allocation
     Unit *d_units = nullptr;
@@ -1467,6 +1476,7 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs)
             const uint32_t new_pos = (uint32_t)u.out_len;
             ss->started = true;
             ss->rebase = 0;
+            r->pending_reset = r->pending_reopen = false; // this launch has applied them
             // (the device counts input modulo 2^32, relative arithmetic only; the window is < 4 GiB)
             ss->consumed = ss->in_skip + (uint32_t)((uint32_t)u.in_consumed - (uint32_t)ss->in_skip);
             r->n_refills++;
@@ -1677,6 +1687,13 @@ int reader_refill(xlz_reader *r)
             r->whole = true;
         else if (st != XLZ_OK)
             return st;
+    }
+    if (r->whole && r->streaming && !r->in_eof && !r->finished) {
+        // a model that does not fit LDS on a FED reader: the whole-stream path needs the whole stream.  Nothing has been
+        // dropped yet (xlz_reader_feed only drops behind a session), so ask for the rest and decode once the end is
+        // declared -- never decode a partial input as if it were the stream (silent truncation)
+        r->need_input = true;
+        return XLZ_OK;
     }
     if (!r->whole) {
         Batcher *bt = r->ctx->batcher;

@@ -663,6 +663,9 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_
 // ranking over the whole CU instead of the SIMD: no further gain.)
 __device__ __forceinline__ void set_priority(uint32_t p)
 {
+#ifdef XLZ_NO_SETPRIO // A/B builds (tools/overlap_probe.py: do prioritised decode waves starve a copy kernel's waves?)
+    return;
+#endif
     if (p == 0)
         __builtin_amdgcn_s_setprio(0);
     else if (p == 1)

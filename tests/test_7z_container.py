@@ -52,6 +52,34 @@ def test_number_encoding_round_trips_through_the_index():
     assert subs2 == [(len(fo[1][2][0]), zlib.crc32(fo[1][2][0])), (len(fo[3][2][0]), zlib.crc32(fo[3][2][0]))]
 
 
+def test_coder_without_an_input_stream_is_refused():
+    """a coder with flag 0x10 and n_in = 0 made the folder claim zero packed streams and
+    place_folders index past PackInfo -- a 48-byte archive with valid CRCs crashed xlz_7z_index.  The fixture is that
+    archive; header counts that the remaining header bytes cannot back are refused before anything is allocated."""
+    import os
+    a = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "7z_coder_without_input.7z"), "rb").read()
+    assert len(a) == 48
+    with pytest.raises(LzmaError) as e:
+        lzma_amd.sevenzip_index(a)
+    assert e.value.status == lzma_amd.ERR_RESULT
+
+    def with_header(hdr):
+        start = struct.pack("<QQI", 0, len(hdr), zlib.crc32(hdr))
+        return b"7z\xbc\xaf\x27\x1c" + bytes([0, 4]) + struct.pack("<I", zlib.crc32(start)) + start + hdr
+    # n_out = 0, and a lone coder whose only input is bound away (no packed stream left): refused as well
+    for coder in (bytes([0x11, 0x00]) + number(1) + number(0),):
+        hdr = bytes([1, 4, 7, 11]) + number(1) + b"\x00" + number(1) + coder + bytes([12]) + number(5) + bytes([0, 0, 0])
+        with pytest.raises(LzmaError):
+            lzma_amd.sevenzip_index(with_header(hdr))
+    # 2^24 folders / pack sizes / substreams announced by a header of a few bytes: no allocation, an error
+    for hdr in (bytes([1, 4, 7, 11]) + number((1 << 24) - 1) + b"\x00",
+                bytes([1, 4, 6]) + number(0) + number((1 << 24) - 1) + bytes([9]),
+                bytes([1, 4, 7, 11]) + number(1) + b"\x00" + number(1) + bytes([0x01, 0x00, 12]) + number(5) + bytes([0])
+                + bytes([8, 13]) + number((1 << 24) - 1) + bytes([0])):
+        with pytest.raises(LzmaError):
+            lzma_amd.sevenzip_index(with_header(hdr))
+
+
 def test_empty_archive():
     start = struct.pack("<QQI", 0, 0, 0)
     a = b"7z\xbc\xaf\x27\x1c" + bytes([0, 4]) + struct.pack("<I", zlib.crc32(start)) + start

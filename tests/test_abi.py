@@ -89,3 +89,11 @@ def test_xlz_so_override_loads_another_build(xlz_so, tmp_path):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=dict(os.environ, XLZ_SO=other))
     assert r.returncode == 0, r.stderr
     assert r.stdout.split()[0] == other and "xlz" in r.stdout
+
+
+def test_library_was_built_from_the_sources_in_the_tree(xlz_so):
+    """xlz_build_id() is a hash of every source file, compiled into the binary (lzma_amd/build.py): a stale or swapped
+    libxlz.so cannot pass for the kernel in the tree -- bench.py quotes the same id and the file's SHA-256"""
+    info = N.library_info()
+    assert info["build_id"] == info["tree_source_id"] and info["built_from_tree"], info
+    assert len(info["sha256"]) == 64 and not info["xlz_so_override"]

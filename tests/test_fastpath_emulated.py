@@ -146,11 +146,15 @@ def test_committed_loop_decodes_real_streams_on_the_emulator(program, family, n,
     assert in_pos == rc.p and s["prev"] == p[len(out) - 1]
 
 
-@pytest.mark.parametrize("add,remove", [((), ("lgather",)), ((), ("hdpp",)), ((), ("flim", "cflag")), ((), ("rlhoist", "vperm", "tuc")),
-                                        (("lit8g",), ()), (("order3", "pwhoist"), ()), (("order1",), ("bralign",)),
-                                        (("litrun",), ("flim",)), (("slot0",), ()), (("slot0", "lit8g"), ("cflag",)),
-                                        (("vprev",), ()), (("rmov",), ()), (("nopos",), ()), (("l7blk",), ()), (("warel",), ()), (("vreps",), ()),
-                                        (("vprev", "slot0", "rmov", "nopos", "l7blk", "warel", "vreps"), ())])
+NEXT = ("slot0", "vprev", "rmov", "nopos", "l7blk", "warel", "vreps")   # round 2's prepared variants: the default since round 3
+
+
+@pytest.mark.parametrize("add,remove", [((), ("lgather",) + NEXT), ((), ("hdpp",) + NEXT), ((), ("flim", "cflag") + NEXT),
+                                        ((), ("rlhoist", "vperm", "tuc") + NEXT), (("lit8g",), NEXT), (("order3", "pwhoist"), NEXT),
+                                        (("order1",), ("bralign",) + NEXT), (("litrun",), ("flim",) + NEXT),
+                                        (("slot0", "lit8g"), ("cflag",) + NEXT), ((), ("hdpp",)), ((), ("rlhoist", "vperm", "tuc")),
+                                        ((), ("slot0",)), ((), ("vprev",)), ((), ("rmov",)), ((), ("nopos",)), ((), ("l7blk",)),
+                                        ((), ("warel",)), ((), ("vreps",)), ((), NEXT)])
 def test_generator_switches_still_decode(add, remove):
     """the code paths kept in the generator as measured alternatives (profiles/r02/layout_scan.md)
     are not dead code: each of them decodes a stream correctly on the emulator"""
@@ -163,12 +167,12 @@ def test_generator_switches_still_decode(add, remove):
     assert (m.s["range"], m.s["code"], m.s["state"], m.s["rep0"]) == (rc.range, rc.code, st.state, st.reps[0])
 
 
-@pytest.mark.parametrize("variants", [(), ("slot0", "vprev", "rmov", "nopos", "l7blk", "warel", "vreps")])
-def test_end_marker_and_error_exits(program, variants):
+@pytest.mark.parametrize("without", [(), NEXT])
+def test_end_marker_and_error_exits(program, without):
     """exit 2 (distance 0xFFFFFFFF: the end marker, decompress.go:633-645) on a stream of unknown size, and exit 1
     (a distance the window does not hold, :651-653) on corrupted streams: same position and bytes as the oracle"""
-    if variants:
-        program = _render(variants, ())
+    if without:
+        program = _render((), without)   # round 2's loop
     lc, lp, pb, ds, n = 3, 0, 2, 1 << 16, 3000
     p = corpus.plain("T", 5, n)
     blob = corpus.compress_alone(p, dict_size=ds, known_size=False, preset=6)       # ends with the marker
@@ -222,12 +226,13 @@ def test_dictionary_epoch_that_starts_inside_the_output(program):
     assert (m.s["range"], m.s["code"], m.s["state"], m.s["rep0"]) == (rc.range, rc.code, st.state, st.reps[0])
 
 
-def test_prepared_variants_on_a_window_that_wraps(program):
-    """slot0 + vprev + rmov + nopos + l7blk + warel + vreps (switched off, to be measured next round) on the two
+@pytest.mark.parametrize("without", [(), NEXT])
+def test_prepared_variants_on_a_window_that_wraps(program, without):
+    """slot0 + vprev + rmov + nopos + l7blk + warel + vreps (the committed loop since round 3; `without`: round 2's loop) on the two
     configurations the switch test does not reach: a 4 KiB dictionary that wraps several times (nopos keeps the
     window's fill as max(window.pos, 0 or dictSize)) and an epoch that starts 70 000 bytes into the output, with
     late-landing loads"""
-    prog = _render(("slot0", "vprev", "rmov", "nopos", "l7blk", "warel", "vreps"), ())
+    prog = _render((), without) if without else program
     for fam, n, lc, lp, pb, ds, base in (("Z", 9000, 1, 1, 1, 4096, 0), ("M", 7000, 3, 0, 2, 4096, 70_000)):
         p = corpus.plain(fam, 4242 + n, n)
         blob = corpus.compress_alone(p, dict_size=ds, lc=lc, lp=lp, pb=pb, known_size=True, preset=0)

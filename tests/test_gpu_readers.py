@@ -334,6 +334,25 @@ def test_streaming_input_edge_cases(ctx):
     assert e is None and out == p
 
 
+def test_fed_reader_with_a_model_beyond_lds_is_not_truncated(ctx):
+    """lc+lp > 8 does not fit a CU's LDS, the session refuses it and the reader takes the
+    whole-stream path -- which, on a reader whose input is FED, once ran on the pieces fed so far and ended the stream
+    early without an error.  Now the reader asks for the rest of the input first."""
+    import io
+    p = corpus.plain("T", 6700, 900_000)
+    blob = corpus.compress_alone(p, dict_size=1 << 16, lc=8, lp=2, pb=0, preset=0)
+    assert len(blob) > 100_000
+    for piece in (4096, 70_000):
+        r, err = lzma_amd.NewReader1(ctx, io.BytesIO(blob), piece=piece)
+        assert err is None
+        out, e = r.read_all(chunk=50_000)
+        assert e is None and out == p, piece
+        assert r.stats()[1] == 1            # ONE whole-stream decode, after the end of the input was declared
+    r, err = lzma_amd.NewReader1(ctx, io.BytesIO(blob[:len(blob) // 2]), piece=4096)   # a truncated source: clean EOF (parity note 4)
+    out, e = r.read_all(chunk=50_000)
+    assert e is None and 0 < len(out) < len(p) and out == p[:len(out)]
+
+
 def test_known_size_streams_refilled_more_than_once(ctx):
     """a stream of known size gets a window of its size only (session_open): a refill that stops early --
     input fed 64 bytes at a time, or simply a stream longer than one refill but shorter than

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import lzma_amd
-from sevenzip_craft import archive, copy_folder, lzma2_folder, lzma_folder
+from sevenzip_craft import archive, bcj_lzma_folder, copy_folder, lzma2_folder, lzma_folder
 
 
 def _mutate(rnd, b, tail_from=None):
@@ -89,11 +89,35 @@ def fuzz_7z(seconds, seed):
             for fc in (True, False):
                 a = archive(fo, with_substreams=ws, folder_crc=fc)
                 samples.append((a, 32 + struct.unpack("<Q", a[12:20])[0]))
+    # folders with complex coders (flag 0x10: explicit stream counts) -- round 2's fuzz never produced n_in = 0, which
+    # crashed place_folders; half of the mutations of these samples rewrite a count byte behind a 0x1x / 0x3x
+    # coder byte to 0 / 1 / 2 / 33
+    complex_samples = []
+    for data in (files[1], files[2]):
+        rec, packed = bcj_lzma_folder(data)
+        for ws in (True, False):
+            a = archive([(rec, packed, [data])], with_substreams=ws, folder_crc=True)
+            complex_samples.append((a, 32 + struct.unpack("<Q", a[12:20])[0]))
+        crec, cpacked = lzma_folder(data)
+        raw = ("raw", b"\x01" + bytes([crec[0] | 0x10]) + crec[1:4] + b"\x01\x01" + crec[4:])   # one coder, counts spelled out
+        a = archive([(raw, cpacked, [data])], folder_crc=True)
+        complex_samples.append((a, 32 + struct.unpack("<Q", a[12:20])[0]))
     t_end = time.time() + seconds
     n = ok = 0
     while time.time() < t_end:
-        a, hs = rnd.choice(samples)
-        b = _mutate(rnd, a, tail_from=hs)
+        if rnd.random() < 0.25:
+            a, hs = rnd.choice(complex_samples)
+            b = bytearray(a)
+            if rnd.random() < 0.5:
+                cand = [i for i in range(hs, len(b) - 6) if b[i] & 0xD0 == 0x10 and (b[i] & 0x0F) in (1, 3, 4)]
+                if cand:
+                    i = rnd.choice(cand)
+                    b[i + 1 + (b[i] & 0x0F) + rnd.randrange(2)] = rnd.choice([0, 0, 1, 2, 33])
+            else:
+                b = _mutate(rnd, a, tail_from=hs)
+        else:
+            a, hs = rnd.choice(samples)
+            b = _mutate(rnd, a, tail_from=hs)
         if len(b) > max(hs, 32) and rnd.random() < 0.8:  # the CRCs of the end header and of the start header
             b[28:32] = struct.pack("<I", zlib.crc32(bytes(b[hs:])) & 0xFFFFFFFF)
             b[8:12] = struct.pack("<I", zlib.crc32(bytes(b[12:32])) & 0xFFFFFFFF)

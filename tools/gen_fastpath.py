@@ -81,7 +81,7 @@ H_IS_MATCH, H_IS_REP, H_G0, H_G1, H_G2, H_REP0_LONG, H_LEN_C, H_LEN_C2, H_REP_C,
 # `--variant next` switches all of them on
 NEXT_VARIANT = {"slot0", "vprev", "rmov", "nopos", "l7blk", "warel", "vreps"}
 DEFAULT_VARIANT = {"lgather", "hdpp", "flim", "cflag", "tuc", "vperm", "rlhoist", "bralign", "stub32", "head32", "pktl64"}
-VARIANT = set(DEFAULT_VARIANT)
+VARIANT = set(DEFAULT_VARIANT) | NEXT_VARIANT   # round 3: the prepared variants are the committed loop
 
 
 def hdpp_lane(j):
