@@ -6,27 +6,35 @@
 A "step" is one pass of the hot path (the gfx950 decode kernel) over one batch of synthetic
 compressed streams that is already resident in HBM.
 
-N = 1 (default): the headline `value` is BASELINE.json configs[1] ("cfg2-T": 4096 independent
-LZMA1 streams, lc=3/lp=0/pb=2, 64 KiB dictionary, 1 MiB uncompressed each, text-like data),
-timed over K steps.  The same JSON line carries a `configs` array with every other BASELINE
-configuration measured in the same process on the same GPU (fewer steps each, see --side-steps):
-cfg2-R (the incompressible family, the shape of the reference's own randomfile.dat benchmark),
-cfg3 (65 536 streams), cfg4 (ONE raw LZMA2 stream of 4096 dictionary-reset units), cfg5
-(8192 streams, lc2/lp1/pb1, 8 MiB dictionary) and cfg5-wrap (24 MiB streams whose 8 MiB window
-wraps, distances up to 8 MiB).  Every decoded byte of every config is compared with the
-plaintext's SHA-256, and every config has its own CPU baseline.
+ONE workload at every N (strong scaling): BASELINE.json configs[2] / north_star's target, "cfg3" -- ONE
+seeded batch of 65 536 independent LZMA1 streams (lc=3/lp=0/pb=2, 64 KiB dictionary, 64 KiB of
+text-like data each).  Rank r of N (one rank per GPU under torch.distributed.run) generates and
+decodes shard r of `multigpu.partition_by_weight` (weights = the uncompressed sizes, SURVEY.md section
+8e); N = 1 decodes the whole batch.  No data-path collective: torch.distributed provides the barrier,
+the MAX of the timed region and a 24-byte SUM of bookkeeping.  value = bytes of the whole batch x K /
+max-rank time.  (`--headline cfg3-heavy`: the same batch with 1 MiB per stream, SURVEY 8d's optional
+heavy variant for an 8-GPU node -- 8 x 8192 streams of 64 KiB are only two wave rounds per GPU.)
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling of cfg3 -- ONE seeded
-65 536-stream batch, rank r decodes shard r of `multigpu.partition_by_weight` (weights = the
-uncompressed sizes), no data-path collective; torch.distributed only
-provides the barrier and the max-over-ranks of the timed region.  value = bytes of the whole
-batch / max-rank time.  The 1-GPU point of that curve is configs["cfg3"] of the N = 1 line.
+At N = 1 the same JSON line also carries
+  * `configs`: every other BASELINE configuration measured in the same process on the same GPU
+    (--side-steps each): cfg2-T (configs[1]: 4096 x 1 MiB), cfg2-T-p6 (the same plaintext behind
+    liblzma preset 6: rounds 1 and 2's headline), cfg2-R (incompressible, the shape of the reference's
+    randomfile.dat benchmark), cfg4 (ONE raw LZMA2 stream of 4096 dictionary-reset units), cfg5 (8192
+    streams, lc2/lp1/pb1, 8 MiB dictionary), cfg5-wrap (24 MiB streams whose 8 MiB window wraps).
+    All corpora use ONE encoder setting (ENC_FAST) so that the configs can be compared; every config
+    has its own `roofline` (incl. `issue`: the instruction-issue and lone-wave-latency bounds this
+    kernel really runs against) and `cpu_baseline`; every decoded byte is compared with the
+    plaintext's SHA-256;
+  * `host_to_host`: cfg3 and cfg2-T through xlz_decode_batch -- host buffers in, host buffers out,
+    PCIe included, with the phase times (what a Go caller of the drop-in sees; never `value`);
+  * `stream_count_sweep`: 64 / 256 / 1024 / 4096 streams of cfg2-T with the CPU baseline beside each:
+    one wave decodes one stream, so a small batch leaves the chip idle -- the break-even is stated;
+  * `containers`: a multi-block .xz file through xlz_xz_decode (host to host, CRC64 verified).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the decode kernel against HBM bandwidth with
-algorithmic bytes (compressed bytes read once + decoded bytes written once), timed with HIP
-events on the kernel's own stream.  `cpu_baseline` times the CPU oracle (a C restatement of the
-Go reference's algorithm; the Go toolchain does not exist here) on a bounded sample of the same
-streams.
+`roofline` prices the decode kernel against HBM bandwidth with algorithmic bytes (compressed bytes
+read once + decoded bytes written once), timed with HIP events on the kernel's own stream.
+`cpu_baseline` times the CPU oracle (a C restatement of the Go reference's algorithm; the Go toolchain
+does not exist here) on a bounded sample of the same streams, on rank 0 at N = 1.
 """
 import argparse
 import hashlib
@@ -43,19 +51,24 @@ if ROOT not in sys.path:
 GIB = float(1 << 30)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md chip table)
 
-# liblzma encoder settings of the corpora.  The headline keeps round 1's preset 6; the side
-# configs use a fast hash-chain setting so that ~25 GiB of plaintext is compressed within the
-# run's time budget (ratio 0.35 instead of 0.31 on the text family: slightly more literals).
+# liblzma encoder setting of the corpora: ONE fast hash-chain setting for every config, so that ~35 GiB of plaintext is
+# compressed within the run's time budget and the configs can be compared with each other (round 2 mixed preset 6 for
+# the headline with this one for the rest).  cfg2-T-p6 keeps rounds 1-2's headline (the same plaintext behind preset 6:
+# ratio 0.31 instead of 0.35, fewer literals per byte) for continuity.
 ENC_FAST = {"mode": 1, "mf": 3, "nice_len": 32, "depth": 2}  # lzma.MODE_FAST, lzma.MF_HC3
 ENC_FAST_NAME = "liblzma MODE_FAST/HC3/nice_len 32/depth 2"
 
 CONFIGS = {
-    "cfg2-T": dict(fmt="lzma1", family="T", streams=4096, size=1 << 20, dict=65536, lc=3, lp=0, pb=2, enc=6,
+    "cfg3": dict(fmt="lzma1", family="T", streams=65536, size=65536, dict=65536, lc=3, lp=0, pb=2, enc=ENC_FAST,
+                 baseline="configs[2]: 65 536 LZMA1 streams, default params (north_star's target batch)"),
+    "cfg3-heavy": dict(fmt="lzma1", family="T", streams=65536, size=1 << 20, dict=65536, lc=3, lp=0, pb=2, enc=ENC_FAST,
+                       baseline="configs[2], heavy variant (SURVEY 8d): 65 536 streams of 1 MiB, for 8-GPU nodes"),
+    "cfg2-T": dict(fmt="lzma1", family="T", streams=4096, size=1 << 20, dict=65536, lc=3, lp=0, pb=2, enc=ENC_FAST,
                    baseline="configs[1]: 4096 LZMA1 streams, 64 KiB dict, 1 MiB each"),
+    "cfg2-T-p6": dict(fmt="lzma1", family="T", streams=4096, size=1 << 20, dict=65536, lc=3, lp=0, pb=2, enc=6,
+                      baseline="configs[1] behind liblzma preset 6 (the headline of rounds 1 and 2)"),
     "cfg2-R": dict(fmt="lzma1", family="R", streams=4096, size=1 << 20, dict=65536, lc=3, lp=0, pb=2, enc=ENC_FAST,
                    baseline="configs[1], incompressible family (literal-only, the shape of randomfile.dat.lzma)"),
-    "cfg3": dict(fmt="lzma1", family="T", streams=65536, size=65536, dict=65536, lc=3, lp=0, pb=2, enc=ENC_FAST,
-                 baseline="configs[2]: 65 536 LZMA1 streams, default params"),
     "cfg4": dict(fmt="lzma2", family="T", streams=1, segments=4096, size=256 << 10, dict=65536, lc=3, lp=0, pb=2,
                  enc=ENC_FAST, baseline="configs[3]: one large LZMA2 stream, 4096 dictionary-reset units"),
     "cfg5": dict(fmt="lzma1", family="T", streams=8192, size=2 << 20, dict=8 << 20, lc=2, lp=1, pb=1, enc=ENC_FAST,
@@ -63,7 +76,10 @@ CONFIGS = {
     "cfg5-wrap": dict(fmt="lzma1", family="F", streams=64, size=24 << 20, dict=8 << 20, lc=2, lp=1, pb=1, enc=ENC_FAST,
                       baseline="configs[4] variant: 24 MiB streams, the 8 MiB window wraps, distances up to 8 MiB"),
 }
-SIDE = ["cfg2-R", "cfg3", "cfg4", "cfg5", "cfg5-wrap"]
+HEADLINES = ["cfg3", "cfg3-heavy"]
+SIDE = ["cfg2-T", "cfg2-T-p6", "cfg2-R", "cfg4", "cfg5", "cfg5-wrap"]
+EXTRAS = ["h2h", "sweep", "xz"]
+SWEEP_COUNTS = [64, 256, 1024]  # (4096 is cfg2-T itself)
 
 
 def log(*a):
@@ -218,18 +234,23 @@ def occupancy(batch, kernel_ms):
                       "queue key is the unit's compressed size"}
 
 
+def library():
+    """which binary runs: path, SHA-256 of the file, the source hash compiled into it (xlz_build_id) and whether that is
+    the hash of the sources in the tree"""
+    from lzma_amd import _native
+    return _native.library_info()
+
+
 def kernel_rev():
-    """Identity of the kernel sources the numbers belong to (profiles are tied to it)."""
-    h = hashlib.sha1()
-    for f in ("xlz_kernel.hip", "xlz_fastpath.inc", "xlz_format.h"):
-        h.update(open(os.path.join(ROOT, "lzma_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:12]
+    """Identity of the kernel the numbers belong to: the source hash compiled into the loaded library (profiles are
+    tied to it)."""
+    return library()["build_id"]
 
 
 def profile_for(name):
     """Counters of the committed rocprofv3 --pmc passes over this config (tools/profile_bench.sh
     + tools/save_profile.py): bench.py cannot profile itself.  Reported only when the profile was
-    taken on the kernel sources that are running now."""
+    taken on the library build that is running now."""
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "current.json")))
     except Exception:
@@ -240,7 +261,46 @@ def profile_for(name):
     return e
 
 
-def roofline(name, cin, cout, units, kernel_ms, occ=None):
+# Measured ceilings of one CU with 16 single-wave workgroups (tools/ubench/mix2.hip, profiles/r02/ubench_mix2.txt):
+# scalar instructions share ONE port per CU (0.97 per cycle), simple wave64 VALU instructions reach 1.28 per cycle.
+SALU_PER_CU_CYCLE, VALU_PER_CU_CYCLE, CUS, CLOCK_HZ = 0.97, 1.28, 256, 2.4e9
+
+
+def issue_bounds(prof, out_bytes_per_launch, kernel_ms, lone, slots):
+    """The two bounds this kernel really runs against (the HBM roof is three orders of magnitude away):
+      issue_bound    the CU's instruction ports: per decoded byte the kernel issues s scalar and v vector instructions
+                     (SQ counters of the committed profile of THIS build and config), a CU issues at most 0.97 / 1.28 of
+                     them per cycle -> CUs x clock / max(s / 0.97, v / 1.28) bytes per second;
+      latency_bound  one wave's serial dependent chain: the rate of a LONE wave on this data (a live 64-unit launch, one
+                     wave on 64 of 1024 SIMDs: nothing competes for issue) x the wave slots of the full launch.
+    frac_of_bound = achieved / min(both).  The kernel sits at the knee of the two with 16 waves per CU."""
+    achieved = out_bytes_per_launch / (kernel_ms / 1e3)
+    r = {"achieved_decoded_GBps": round(achieved / 1e9, 3)}
+    bounds = []
+    if prof and "issue" in prof and "salu_per_decoded_byte" in prof["issue"]:
+        i = prof["issue"]
+        cyc = max(i["salu_per_decoded_byte"] / SALU_PER_CU_CYCLE, i["valu_per_decoded_byte"] / VALU_PER_CU_CYCLE)
+        ib = CUS * CLOCK_HZ / cyc
+        r["issue_bound_GBps"] = round(ib / 1e9, 3)
+        r["issue_bound_from"] = {"salu_per_decoded_byte": i["salu_per_decoded_byte"], "valu_per_decoded_byte": i["valu_per_decoded_byte"],
+                                 "branch_per_decoded_byte": i.get("branch_per_decoded_byte"),
+                                 "ceilings_per_cu_cycle": {"salu": SALU_PER_CU_CYCLE, "valu": VALU_PER_CU_CYCLE},
+                                 "cus": CUS, "clock_ghz": CLOCK_HZ / 1e9, "binding_port": "salu" if
+                                 i["salu_per_decoded_byte"] / SALU_PER_CU_CYCLE >= i["valu_per_decoded_byte"] / VALU_PER_CU_CYCLE else "valu",
+                                 "source": i.get("source")}
+        bounds.append(ib)
+    if lone and slots:
+        lb = lone["bytes_per_s_per_wave"] * slots
+        r["latency_bound_GBps"] = round(lb / 1e9, 3)
+        r["latency_bound_from"] = dict(lone, wave_slots=slots)
+        bounds.append(lb)
+    if bounds:
+        r["frac_of_bound"] = round(achieved / min(bounds), 4)
+        r["binding"] = "issue" if len(bounds) == 2 and bounds[0] <= bounds[1] else ("latency" if len(bounds) == 2 else "only one bound known")
+    return r
+
+
+def roofline(name, cin, cout, units, kernel_ms, occ=None, lone=None):
     algo = cin + cout  # per launch: compressed bytes read once + decoded bytes written once
     achieved = algo / 1e9 / (kernel_ms / 1e3)
     prof = profile_for(name)
@@ -250,6 +310,7 @@ def roofline(name, cin, cout, units, kernel_ms, occ=None):
          "kernel": "xlz::xlz_decode_kernel", "kernel_ms": round(kernel_ms, 3),
          "algorithmic_bytes_per_launch": algo, "units_per_launch": units}
     issue = dict(occ) if occ else {}
+    issue.update(issue_bounds(prof, cout, kernel_ms, lone, occ["slots"] if occ else None))
     if prof:
         r["traffic_from_profile"] = {"source": prof["source"], "kernel_rev": prof["kernel_rev"],
                                      "fetch": prof["fetch_bytes_per_launch_raw"], "write": prof["write_bytes_per_launch"]}
@@ -332,6 +393,42 @@ def liblzma_sanity(comp, osz, threads, target_s=3.0):
             "sample": "%d streams in %.2f s" % (n, dt)}
 
 
+def lone_wave_sample(spec, comp):
+    """the first 64 units of a corpus as a batch of their own: 64 waves on 1024 SIMDs, nothing competes for issue"""
+    if spec["fmt"] == "lzma2":   # the first 64 segments of the stream (cut at a dictionary-reset chunk)
+        c, pos, out, want = comp[0], 0, 0, min(64, spec["segments"]) * spec["size"]
+        while out < want:
+            ctl = c[pos]
+            if ctl >= 0x80:
+                unc = (((ctl & 0x1F) << 16) | (c[pos + 1] << 8) | c[pos + 2]) + 1
+                pos += (6 if ctl >= 0xC0 else 5) + ((c[pos + 3] << 8) | c[pos + 4]) + 1
+            else:
+                unc = ((c[pos + 1] << 8) | c[pos + 2]) + 1
+                pos += 3 + unc
+            out += unc
+        return [c[:pos] + b"\x00"], out
+    return comp[:64], spec["size"]
+
+
+def xz_file(pool, blocks, size):
+    """-> (bytes of a multi-block .xz file, sha256 of the plaintext): `blocks` independently compressed blocks as
+    concatenated single-block streams (what pixz / `xz -T` style tools write; CRC64 checks)"""
+    res = list(pool.map(_gen_xz_block, [(9000 + i, size) for i in range(blocks)], chunksize=max(1, blocks // 256)))
+    h = hashlib.sha256()
+    for _, pl in res:
+        h.update(pl)
+    return b"".join(c for c, _ in res), h.digest()
+
+
+def _gen_xz_block(job):
+    import lzma
+    import corpus
+    seed, size = job
+    p = corpus.plain("T", seed, size)
+    filt = [dict(corpus.lzma1_filters(dict_size=1 << 20, preset=ENC_FAST)[0], id=lzma.FILTER_LZMA2)]
+    return lzma.compress(p, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC64, filters=filt), p
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,14 +437,21 @@ def main():
     ap.add_argument("--side-steps", type=int, default=3, help="timed steps of each entry of `configs` (1 warm-up)")
     ap.add_argument("--configs", default="all",
                     help="N=1: comma list of side configs to run (%s), 'all' or 'none'" % ",".join(SIDE))
-    ap.add_argument("--headline", default="cfg2-T", choices=list(CONFIGS), help="N=1: the config reported as `value`")
+    ap.add_argument("--extras", default="all", help="N=1: comma list of %s, 'all' or 'none'" % ",".join(EXTRAS))
+    ap.add_argument("--headline", default="cfg3", choices=list(CONFIGS),
+                    help="the ONE workload reported as `value` at every N (cfg3; cfg3-heavy for big nodes; any other "
+                         "config for profiling runs)")
     ap.add_argument("--scale", type=float, default=1.0, help="dev runs: multiply every config's stream count")
     ap.add_argument("--trace-out", default="", help="dev: save the per-unit (t_start, t_end, in_len) stamps of every config "
                                                      "as <prefix><config>.npz")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=12.0)
     ap.add_argument("--side-cpu-target-s", type=float, default=4.0)
+    ap.add_argument("--allow-xlz-so", action="store_true", help="dev: accept a library swapped in with XLZ_SO (recorded in the line)")
     args = ap.parse_args()
+    if os.environ.get("XLZ_SO") and not args.allow_xlz_so:
+        raise SystemExit("bench.py: XLZ_SO is set (%s): the numbers would belong to another library than the tree's; "
+                         "pass --allow-xlz-so for an A/B run" % os.environ["XLZ_SO"])
 
     from lzma_amd import multigpu
     rank, world, local_rank = multigpu.env_rank()
@@ -361,26 +465,29 @@ def main():
                 v["segments"] = max(8, int(v["segments"] * args.scale))
             else:
                 v["streams"] = max(8, int(v["streams"] * args.scale))
-    if world == 1:
-        side = [] if args.configs == "none" else SIDE if args.configs == "all" else \
-            [c for c in args.configs.split(",") if c and c != args.headline]
-        names = [args.headline] + [c for c in side if c != args.headline]
-    else:
-        names = ["cfg3"]
+    head = args.headline
+    side, extras = [], []
+    if world == 1:  # the side configs, the sweep and the host-to-host legs are single-GPU measurements
+        side = [] if args.configs == "none" else SIDE if args.configs == "all" else [c for c in args.configs.split(",") if c]
+        side = [c for c in side if c != head]
+        extras = [] if args.extras == "none" else EXTRAS if args.extras == "all" else [e for e in args.extras.split(",") if e]
+    if ("h2h" in extras or "sweep" in extras) and "cfg2-T" not in side and head != "cfg2-T":
+        side.append("cfg2-T")   # (their corpus)
+    names = [head] + side
 
     # ---- synthetic corpora, generated BEFORE anything touches the GPU (the generator forks
     # worker processes; a process that has initialised HIP must not fork workers)
     ncpu = effective_cpus()
     workers = max(1, min((os.cpu_count() or 1) // max(1, min(world, 8)), 64))
     corp = {}
-    shard = None
+    xz = None
     t_gen0 = time.time()
     with ProcessPoolExecutor(max_workers=workers) as pool:
         for name in names:
             spec = specs[name]
             t0 = time.time()
-            if world > 1:
-                # strong scaling: ONE batch (seed 1), this rank's shard of it
+            if name == head:
+                # strong scaling: ONE batch (seed 1), this rank's shard of it (N = 1: all of it)
                 weights = [out_size_of(spec)] * spec["streams"]
                 shard = multigpu.partition_by_weight(weights, world)[rank]
                 comp, dig = make_corpus(pool, spec, 1, shard)
@@ -390,6 +497,10 @@ def main():
             log("[rank %d] corpus %s: %d streams x %d B, ratio %.3f, generated in %.1f s with %d workers"
                 % (rank, name, len(comp), out_size_of(spec), sum(map(len, comp)) / (len(comp) * out_size_of(spec)),
                    time.time() - t0, workers))
+        if "xz" in extras:
+            t0 = time.time()
+            xz = xz_file(pool, max(8, int(1024 * args.scale)), 1 << 20)
+            log("[rank %d] corpus xz: %d bytes in %.1f s" % (rank, len(xz[0]), time.time() - t0))
     gen_s = time.time() - t_gen0
 
     import torch
@@ -411,12 +522,36 @@ def main():
     import lzma_amd
     from lzma_amd import build
     build.build()
+    lib_info = library()
+    if not lib_info["built_from_tree"] and not args.allow_xlz_so:
+        raise SystemExit("bench.py: %s was not built from the sources in the tree (build id %s, tree %s)"
+                         % (lib_info["path"], lib_info["build_id"], lib_info["tree_source_id"]))
     ctx = lzma_amd.Context(local_rank)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     def barrier():
         multigpu.barrier(dist, torch.cuda.synchronize)
 
-    def gpu_leg(name, steps, warmup):
+    def lone_leg(name):
+        """live: bytes per second of ONE wave on this config's data (latency bound of roofline.issue)"""
+        spec = specs[name]
+        sample, osz = lone_wave_sample(spec, corp[name][0])
+        b = make_batch(lzma_amd, ctx, dict(spec, segments=min(64, spec.get("segments", 1))), sample)
+        b.run()
+        b.sync()
+        b.run()
+        b.sync()
+        t0, t1, _ = b.unit_trace()
+        res = b.results()
+        b.close()
+        import numpy as np
+        dur = (t1.astype(np.int64) - t0.astype(np.int64)) / 1e8  # s
+        per_unit = sum(r[0] for r in res) / max(1, len(dur))
+        return {"bytes_per_s_per_wave": round(float(per_unit / np.median(dur)), 1), "units": int(len(dur)),
+                "unit_ms_median": round(float(np.median(dur)) * 1e3, 3),
+                "source": "live: a launch of the config's first %d units alone (one wave each, the rest of the chip idle)" % len(dur)}
+
+    def gpu_leg(name, steps, warmup, with_lone=True):
         spec = specs[name]
         comp, dig = corp[name]
         osz = out_size_of(spec)
@@ -432,92 +567,199 @@ def main():
             t0_, t1_, il_ = batch.unit_trace()
             np.savez_compressed(args.trace_out + name + ".npz", t_start=t0_, t_end=t1_, in_len=il_)
         batch.close()
-        return t_local, kernel_ms, cin, cout, units, occ
+        lone = lone_leg(name) if with_lone and spec["streams"] * spec.get("segments", 1) > 64 else None
+        return t_local, kernel_ms, cin, cout, units, occ, lone
 
     def cpu_leg(name, target_s):
-        if args.no_cpu_baseline:
+        if args.no_cpu_baseline or rank != 0 or world != 1:   # contract: rank 0 at N = 1 only
             return None
         spec = specs[name]
         comp, dig = corp[name]
         threads = int(os.environ.get("XLZ_BENCH_CPU_THREADS", "0")) or ncpu
         return cpu_baseline(spec, comp, dig, threads, target_s)
 
-    # ------------------------------------------------------------ N > 1: strong scaling ----
-    if world > 1:
-        name = "cfg3"
+    def h2h_leg(name, reps=3, repeat=1):
+        """xlz_decode_batch: host buffers in, host buffers out (PCIe included) -- the drop-in caller's rate.
+        repeat > 1: the config's streams `repeat` times over in ONE call (a call of several wave rounds: the library
+        pipelines upload / decode / download of sub-batches)"""
+        import numpy as np
+        from lzma_amd import _native as N
         spec = specs[name]
-        t_local, kernel_ms, cin, cout, units, occ = gpu_leg(name, args.steps, args.warmup)
-        t_max = multigpu.max_over_ranks(t_local, dist, device="cuda" if backend == "nccl" else "cpu")
-        n_mine = multigpu.max_over_ranks(float(len(corp[name][0])), dist, device="cuda" if backend == "nccl" else "cpu")
-        sums = torch.tensor([float(len(corp[name][0])), float(cin), float(cout)], dtype=torch.float64,
-                            device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(sums)  # 24 bytes of bookkeeping, not data: streams / bytes over all shards
-        cpu = cpu_leg(name, args.side_cpu_target_s) if rank == 0 else None
-        barrier()
-        if rank == 0:
-            total_streams = int(sums[0].item())
-            assert total_streams == spec["streams"], "the shards do not add up to the batch"
-            total_out = spec["streams"] * out_size_of(spec) * args.steps
-            line = {
-                "metric": "decompressed GiB/s (aggregate batch)", "value": round(total_out / GIB / t_max, 4), "unit": "GiB/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(t_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-                "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-                "config": {"workload": workload_text(name, spec, per_gpu=False) + "; ONE batch split over %d GPUs" % world,
-                           "streams_total": total_streams, "streams_largest_shard": int(n_mine),
-                           "bytes_per_stream": out_size_of(spec),
-                           "compression_ratio": round(sums[1].item() / sums[2].item(), 4), "bit_exact": "all",
-                           "parallelism": "one batch sharded by stream x%d (partition_by_weight), no collective" % world,
-                           "n1_reference": "configs[cfg3] of the --gpus 1 line is the 1-GPU point of this curve"},
-                "roofline": dict(roofline(name, cin, cout, units, kernel_ms, occ), note="rank 0's shard"),
-                "cpu_baseline": cpu,
-            }
-            print(json.dumps(line), flush=True)
-        dist.destroy_process_group()
-        return
+        comp, dig = corp[name]
+        comp, dig = comp * repeat, dig * repeat
+        n, osz = len(comp), out_size_of(spec)
+        ins = [np.frombuffer(c, dtype=np.uint8) for c in comp]
+        out = np.zeros((n, osz), dtype=np.uint8)   # one host buffer per stream, touched
+        descs = (N.StreamDesc * n)()
+        for i in range(n):
+            descs[i].inp, descs[i].in_len = ins[i].ctypes.data, ins[i].size
+            descs[i].out, descs[i].out_cap = out[i].ctypes.data, osz
+            descs[i].format = lzma_amd.FMT_LZMA2_RAW if spec["fmt"] == "lzma2" else lzma_amd.FMT_LZMA_ALONE
+            descs[i].dict_size = spec["dict"] if spec["fmt"] == "lzma2" else 0
+        res = (N.Result * n)()
+        best = None
+        for _ in range(reps + 1):   # the first call allocates the pinned pools
+            t0 = time.perf_counter()
+            st = N.lib().xlz_decode_batch(ctx._h, descs, n, res)
+            dt = time.perf_counter() - t0
+            if st != 0:
+                raise SystemExit("xlz_decode_batch failed: %d" % st)
+            cs = ctx.last_call_stats()
+            if best is None or dt < best[0]:
+                best = (dt, cs)
+        bad = [i for i in range(n) if res[i].status != 0 or res[i].out_len != osz]
+        if bad:
+            raise SystemExit("host_to_host %s: %d streams failed" % (name, len(bad)))
+        with ThreadPoolExecutor(max_workers=16) as ex:
+            ok = list(ex.map(lambda i: hashlib.sha256(out[i]).digest() == dig[i], range(n)))
+        if not all(ok):
+            raise SystemExit("host_to_host %s: decoded bytes differ from the plaintext" % name)
+        dt, cs = best
+        return {"name": name if repeat == 1 else "%s x%d" % (name, repeat), "value": round(n * osz / GIB / dt, 4), "unit": "GiB/s",
+                "ms_per_call": round(dt * 1e3, 3),
+                "streams": n, "bytes_per_stream": osz, "bit_exact": "all", "calls": reps + 1, "reported": "best call",
+                "sub_batches": cs["sub_batches"],
+                "phases_ms": {"pack_upload": round(cs["upload_ms"], 3), "decode": round(cs["decode_ms"], 3),
+                              "download_scatter": round(cs["download_ms"], 3),
+                              "note": "sub_batches > 1: a pipeline -- pack_upload = until the first sub-batch was on the device, decode = "
+                                      "first launch to last results (the other uploads and downloads run inside it), "
+                                      "download_scatter = what was left after that"},
+                "slot_occupancy": round(cs["slot_occupancy"], 4), "wave_slots": cs["wave_slots"],
+                "path": "xlz_decode_batch: pageable host buffers in, pageable host buffers out, through the library's pinned pools"}
 
-    # ------------------------------------------------------------ N = 1: all configs ----
+    # ------------------------------------------------------------ the headline: one workload at every N ----
+    spec = specs[head]
+    t_local, kernel_ms, cin, cout, units, occ, lone = gpu_leg(head, args.steps, args.warmup)
+    t_max = multigpu.max_over_ranks(t_local, dist, device=red_dev)
+    n_max = multigpu.max_over_ranks(float(len(corp[head][0])), dist, device=red_dev)
+    sums = [float(len(corp[head][0])), float(cin), float(cout)]
+    if world > 1:
+        t = torch.tensor(sums, dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t)  # 24 bytes of bookkeeping, not data: streams / bytes over all shards
+        sums = [float(x) for x in t.tolist()]
+    total_streams = int(sums[0])
+    assert total_streams == spec["streams"], "the shards do not add up to the batch"
+    total_out = spec["streams"] * out_size_of(spec) * args.steps
+    head_res = {
+        "value": round(total_out / GIB / t_max, 4), "ms_per_step": round(t_max / args.steps * 1e3, 3),
+        "roofline": roofline(head, cin, cout, units, kernel_ms, occ, lone),
+    }
+    if world > 1:
+        head_res["roofline"]["note"] = "rank 0's shard"
+
+    # ------------------------------------------------------------ N = 1: the other configs and the extras ----
     results = {}
-    for name in names:
-        head = name == args.headline
-        steps, warmup = (args.steps, args.warmup) if head else (args.side_steps, 1)
-        t_local, kernel_ms, cin, cout, units, occ = gpu_leg(name, steps, warmup)
-        spec = specs[name]
+    for name in side:
+        sp = specs[name]
+        steps, warmup = args.side_steps, 1
+        tl, kms, ci, co, un, oc, ln = gpu_leg(name, steps, warmup)
         n = len(corp[name][0])
-        total_out = n * out_size_of(spec) * steps
         results[name] = {
-            "name": name, "baseline_config": spec["baseline"], "workload": workload_text(name, spec),
-            "value": round(total_out / GIB / t_local, 4), "unit": "GiB/s", "steps": steps, "warmup": warmup,
-            "ms_per_step": round(t_local / steps * 1e3, 3), "kernel_ms": round(kernel_ms, 3),
-            "streams": n, "bytes_per_stream": out_size_of(spec), "compression_ratio": round(cin / cout, 4),
-            "bit_exact": "all", "roofline": roofline(name, cin, cout, units, kernel_ms, occ),
+            "name": name, "baseline_config": sp["baseline"], "workload": workload_text(name, sp),
+            "value": round(n * out_size_of(sp) * steps / GIB / tl, 4), "unit": "GiB/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(tl / steps * 1e3, 3), "kernel_ms": round(kms, 3),
+            "streams": n, "bytes_per_stream": out_size_of(sp), "compression_ratio": round(ci / co, 4),
+            "bit_exact": "all", "roofline": roofline(name, ci, co, un, kms, oc, ln),
         }
-    for name in names:  # CPU legs after all GPU work: the host cores are quiet
-        head = name == args.headline
-        results[name]["cpu_baseline"] = cpu_leg(name, args.cpu_target_s if head else args.side_cpu_target_s)
+    h2h, sweep, containers = None, None, None
+    if "h2h" in extras:
+        h2h = [h2h_leg(n) for n in dict.fromkeys([head, "cfg2-T"]) if n in corp]
+        if "cfg2-T" in corp and args.scale == 1.0:
+            h2h.append(h2h_leg("cfg2-T", reps=2, repeat=4))   # 16 384 x 1 MiB: four wave rounds in one call
+        log("[h2h] " + ", ".join("%s %.2f GiB/s" % (x["name"], x["value"]) for x in h2h))
+    if "sweep" in extras and "cfg2-T" in corp:
+        sweep = []
+        comp, dig = corp["cfg2-T"]
+        sp = specs["cfg2-T"]
+        for k in SWEEP_COUNTS:
+            if k >= len(comp):
+                continue
+            b = make_batch(lzma_amd, ctx, sp, comp[:k])
+            tl, kms = timed_steps(ctx, b, 2, 1, torch.cuda.synchronize)
+            oc = occupancy(b, kms)
+            verify_all(b, k, sp["size"], dig[:k], "sweep %d" % k)
+            b.close()
+            sweep.append({"streams": k, "value": round(k * sp["size"] * 2 / GIB / tl, 4), "unit": "GiB/s", "kernel_ms": round(kms, 3),
+                          "slot_occupancy": oc and oc["slot_occupancy"], "bit_exact": "all"})
+    if "xz" in extras and xz is not None:
+        data, want = xz
+        t0 = time.perf_counter()
+        out = lzma_amd.xz_decode(ctx, data, verify=True)
+        t1 = time.perf_counter()
+        out = lzma_amd.xz_decode(ctx, data, verify=True)
+        dt = min(t1 - t0, time.perf_counter() - t1)
+        if hashlib.sha256(out).digest() != want:
+            raise SystemExit("xz container: decoded bytes differ from the plaintext")
+        containers = [{"name": "xz-blocks", "workload": "one .xz file of %d independently compressed 1 MiB blocks (LZMA2, 1 MiB "
+                       "dictionary, CRC64), %s; xlz_xz_decode: file in host memory -> decoded bytes in host memory, every block's "
+                       "CRC64 verified on the host" % (max(8, int(1024 * args.scale)), ENC_FAST_NAME),
+                       "value": round(len(out) / GIB / dt, 4), "unit": "GiB/s", "ms_per_call": round(dt * 1e3, 3),
+                       "compressed_bytes": len(data), "decoded_bytes": len(out), "bit_exact": "all", "calls": 2, "reported": "best call"}]
+        del out
+
+    # ---- CPU legs after all GPU work: the host cores are quiet
+    cpu_head = cpu_leg(head, args.cpu_target_s)
+    for name in side:
+        results[name]["cpu_baseline"] = cpu_leg(name, args.side_cpu_target_s)
         log("[cpu] %s: %s" % (name, results[name]["cpu_baseline"] and results[name]["cpu_baseline"]["value"]))
-    h = results[args.headline]
-    spec = specs[args.headline]
+    if sweep and not args.no_cpu_baseline:
+        comp, dig = corp["cfg2-T"]
+        threads = int(os.environ.get("XLZ_BENCH_CPU_THREADS", "0")) or ncpu
+        for e in sweep:
+            e["cpu_baseline"] = cpu_baseline(specs["cfg2-T"], comp[:e["streams"]], dig[:e["streams"]], threads, 2.0)
+        full = results.get("cfg2-T")
+        pts = [(e["streams"], e["value"], e["cpu_baseline"]["value"]) for e in sweep]
+        if full and full.get("cpu_baseline"):
+            pts.append((full["streams"], full["value"], full["cpu_baseline"]["value"]))
+        wins = [k for k, g, c in pts if g >= c]
+        sweep = {"workload": "the first k streams of cfg2-T (device-resident, kernel rate) against the CPU baseline on the same k "
+                             "streams with %d host threads" % threads,
+                 "points": sweep + ([{"streams": full["streams"], "value": full["value"], "unit": "GiB/s", "kernel_ms": full["kernel_ms"],
+                                      "slot_occupancy": full["roofline"].get("issue", {}).get("slot_occupancy"),
+                                      "cpu_baseline": full["cpu_baseline"]}] if full else []),
+                 "break_even_streams": min(wins) if wins else None,
+                 "note": "one wave decodes one stream (LZMA1 is a serial chain, decompress.go:13); the chip holds 4096 waves: below "
+                         "the break-even the host's cores are the faster decoder (include/xlz.h, INTEGRATION.md)"}
+    if containers and not args.no_cpu_baseline:
+        import lzma
+        t0 = time.perf_counter()
+        ref = lzma.decompress(xz[0])
+        dt = time.perf_counter() - t0
+        containers[0]["cpu_baseline"] = {"value": round(len(ref) / GIB / dt, 4), "unit": "GiB/s", "cores": 1, "kind": "liblzma 5.x (xz) via Python",
+                                         "sample": "the whole file in %.2f s on one thread (xz 5.2 decodes a file on one thread; the "
+                                                   "reference has no container code)" % dt}
+        del ref
     sanity = None
-    if not args.no_cpu_baseline and spec["fmt"] == "lzma1":
+    if cpu_head is not None and spec["fmt"] == "lzma1":
         try:
-            sanity = liblzma_sanity(corp[args.headline][0], out_size_of(spec), ncpu)
+            sanity = liblzma_sanity(corp[head][0], out_size_of(spec), ncpu)
         except Exception as e:  # a sanity line must never fail the bench
             log("liblzma sanity line skipped: %r" % (e,))
-    line = {
-        "metric": "decompressed GiB/s (aggregate batch)", "value": h["value"], "unit": "GiB/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": h["ms_per_step"], "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": h["workload"], "streams_per_gpu": h["streams"], "bytes_per_stream": h["bytes_per_stream"],
-                   "compression_ratio": h["compression_ratio"], "bit_exact": "all",
-                   "parallelism": "shard-by-stream x1, no collective", "corpus_generation_s": round(gen_s, 1),
-                   "kernel_rev": kernel_rev()},
-        "roofline": h["roofline"],
-        "cpu_baseline": h["cpu_baseline"],
-        "cpu_sanity_liblzma": sanity,
-        "configs": [results[n] for n in names if n != args.headline],
-    }
-    print(json.dumps(line), flush=True)
+    if world > 1:
+        barrier()
+    if rank == 0:
+        line = {
+            "metric": "decompressed GiB/s (aggregate batch)", "value": head_res["value"], "unit": "GiB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": head_res["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": workload_text(head, spec, per_gpu=False) + "; ONE seeded batch split by stream over %d GPU%s"
+                       % (world, "" if world == 1 else "s"),
+                       "streams_total": total_streams, "streams_largest_shard": int(n_max),
+                       "bytes_per_stream": out_size_of(spec), "compression_ratio": round(sums[1] / sums[2], 4), "bit_exact": "all",
+                       "parallelism": "one batch sharded by stream x%d (partition_by_weight), no collective" % world,
+                       "corpus_generation_s": round(gen_s, 1), "kernel_rev": lib_info["build_id"], "library": lib_info},
+            "roofline": head_res["roofline"],
+            "cpu_baseline": cpu_head,
+        }
+        if world == 1:
+            line["cpu_sanity_liblzma"] = sanity
+            line["host_to_host"] = h2h
+            line["stream_count_sweep"] = sweep
+            line["containers"] = containers
+            line["configs"] = [results[n] for n in side if n in results]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
     ctx.close()
 
 

@@ -123,8 +123,31 @@ int xlz_ctx_batching_stats(xlz_ctx *ctx, uint64_t *batches, uint64_t *streams);
 /* Replaces a loop of `r, _ := NewReader1(src); io.Copy(dst, r)` over n independent
  * streams (reader1_test.go:76-80).  One bad stream never fails the batch: the return
  * value is XLZ_OK unless the call itself could not run; per-stream outcomes are in
- * results[i].  Thread-safe across contexts; calls on one context are serialised.   */
+ * results[i].  Thread-safe across contexts; calls on one context are serialised.
+ * A call of several wave rounds (>= 8192 streams and >= 2 GiB of output) is cut into up
+ * to eight sub-batches whose upload, decode and download overlap.                    */
 int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_result *results);
+
+/* What the most recent successful xlz_decode_batch on `ctx` spent where, and how well it filled the GPU.
+ * ONE wave decodes one stream (LZMA1 has no parallelism inside a stream: decompress.go:13 is a serial
+ * chain), at about 5 MB/s of output; the chip holds `wave_slots` (4096) of them.  A call with few
+ * streams leaves most of the chip idle -- slot_occupancy says how much of it worked -- and below the
+ * break-even stated in INTEGRATION.md the host's own cores are faster.                              */
+typedef struct xlz_call_stats {
+    double upload_ms;      /* parse headers, pack the inputs into pinned memory, host -> device     */
+    double decode_ms;      /* decode launch(es) until the per-stream results are on the host        */
+    double download_ms;    /* device -> host and scatter into the callers' buffers                  */
+    double total_ms;
+    double kernel_span_ms; /* first wave's start to last wave's end of the main launch (device clock) */
+    double slot_occupancy; /* busy wave time / (wave_slots x kernel span): 1.0 = every slot busy throughout */
+    uint64_t streams;      /* n of the call                                                          */
+    uint64_t units;        /* work units of the main launch (streams; LZMA2: dictionary-reset units) */
+    uint32_t wave_slots;   /* resident single-wave workgroups of the launch                          */
+    uint32_t sub_batches;  /* > 1: the call ran as a pipeline (upload k+1 / decode k / download k-1); then
+                              upload_ms = until the first sub-batch was on the device, decode_ms = first
+                              launch to last results, download_ms = what was left after that            */
+} xlz_call_stats;
+int xlz_ctx_last_call_stats(xlz_ctx *ctx, xlz_call_stats *out);
 
 /* ---- device-resident batch: upload once, decode many times ---------------- */
 typedef struct xlz_batch xlz_batch;

@@ -76,6 +76,14 @@ class Context:
             raise LzmaError(st, "xlz_ctx_batching_stats")
         return a.value, b.value
 
+    def last_call_stats(self):
+        """phase times and slot occupancy of the last decode_batch on this context (xlz_ctx_last_call_stats) -> dict"""
+        cs = N.CallStats()
+        st = N.lib().xlz_ctx_last_call_stats(self._h, ctypes.byref(cs))
+        if st != OK:
+            raise LzmaError(st, "xlz_ctx_last_call_stats")
+        return {k: getattr(cs, k) for k, _ in N.CallStats._fields_}
+
     def event_record(self, slot):
         st = N.lib().xlz_ctx_event_record(self._h, slot)
         if st != OK:

@@ -39,7 +39,7 @@ EXPORTS = [
     "xlz_version", "xlz_build_id", "xlz_strerror", "xlz_device_count", "xlz_decode_prop", "xlz_decode_dict_size",
     "xlz_decode_dict_size2", "xlz_decode_unpack_size", "xlz_ctx_create", "xlz_ctx_destroy",
     "xlz_ctx_device", "xlz_ctx_event_record", "xlz_ctx_event_elapsed_ms", "xlz_ctx_enable_batching",
-    "xlz_ctx_batching_stats", "xlz_decode_batch", "xlz_batch_create", "xlz_batch_run", "xlz_batch_sync",
+    "xlz_ctx_batching_stats", "xlz_decode_batch", "xlz_ctx_last_call_stats", "xlz_batch_create", "xlz_batch_run", "xlz_batch_sync",
     "xlz_batch_results", "xlz_batch_download", "xlz_batch_device_output", "xlz_batch_last_kernel_ms",
     "xlz_batch_stats", "xlz_batch_destroy", "xlz_new_reader1", "xlz_new_reader2",
     "xlz_new_lzma_decompressor_for_sevenzip", "xlz_new_lzma2_decompressor_for_sevenzip",
@@ -69,6 +69,13 @@ class Result(ctypes.Structure):
         ("status", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
     ]
+
+
+class CallStats(ctypes.Structure):
+    _fields_ = [("upload_ms", ctypes.c_double), ("decode_ms", ctypes.c_double), ("download_ms", ctypes.c_double),
+                ("total_ms", ctypes.c_double), ("kernel_span_ms", ctypes.c_double), ("slot_occupancy", ctypes.c_double),
+                ("streams", ctypes.c_uint64), ("units", ctypes.c_uint64), ("wave_slots", ctypes.c_uint32),
+                ("sub_batches", ctypes.c_uint32)]
 
 
 class XzBlock(ctypes.Structure):
@@ -142,6 +149,7 @@ def lib():
     L.xlz_ctx_event_record.argtypes = [vp, i32]
     L.xlz_ctx_event_elapsed_ms.argtypes = [vp, i32, i32, ctypes.POINTER(ctypes.c_float)]
     L.xlz_decode_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), sz, ctypes.POINTER(Result)]
+    L.xlz_ctx_last_call_stats.argtypes = [vp, ctypes.POINTER(CallStats)]
     L.xlz_batch_create.argtypes = [vp, ctypes.POINTER(StreamDesc), sz, ctypes.POINTER(vp)]
     L.xlz_batch_run.argtypes = [vp]
     L.xlz_batch_sync.argtypes = [vp]

@@ -161,6 +161,6 @@ constexpr uint32_t kPrioTabWords = 1u << 20; // XCC_ID[3:0] : HW_ID[15:0]
 int launch_decode(const LaunchParams &p, int num_cus, void *stream /* hipStream_t */);
 uint32_t decode_lds_bytes(uint32_t max_lc_lp);
 uint32_t big_model_grid(int num_cus);
-uint32_t decode_grid(uint32_t max_lc_lp, int num_cus); // resident workgroups of the LDS-model launch
+uint32_t decode_grid(uint32_t max_lc_lp, int num_cus, uint32_t n_units); // resident workgroups of the LDS-model launch over n_units units (~0u: the most)
 
 } // namespace xlz

@@ -62,7 +62,8 @@ static void batcher_shutdown(Batcher *bt); // defined next to the readers
 struct HostPipe {
     static constexpr int kRing = 4;
     static constexpr size_t kRingBytes = 64u << 20;
-    std::mutex mu; // one staged call at a time per context
+    std::mutex mu_in;  // the pinned input image: one pack + upload at a time per context
+    std::mutex mu_out; // the pinned output ring: one download at a time per context
     uint8_t *pin_in = nullptr;
     size_t pin_in_cap = 0;
     uint8_t *ring[kRing] = {};
@@ -80,6 +81,8 @@ struct xlz_ctx {
     hipEvent_t ev[8] = {};
     std::mutex mu;
     HostPipe pipe;
+    xlz_call_stats last_call = {}; // of the most recent xlz_decode_batch on this context (xlz_ctx_last_call_stats)
+    bool have_last_call = false;
 };
 
 // per-stream bookkeeping of a batch
@@ -437,7 +440,8 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     *out = nullptr;
     for (size_t i = 0; i < n; i++)
         if (!streams[i].in && streams[i].in_len) return XLZ_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    // (no ctx->mu here: planning touches only the new batch, the pinned staging image has its own mutex -- a pipelined
+    //  xlz_decode_batch creates sub-batch k+1 while sub-batch k is launched and collected)
     HIP_TRY(hipSetDevice(ctx->device));
 
     xlz_batch *b = new (std::nothrow) xlz_batch;
@@ -583,13 +587,13 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     }
     if (b->n_normal) { // the matched-literal half of every resident model (xlz_format.h)
         b->mlit_stride = num_matched_probs(b->max_lc_lp);
-        const size_t slots = (size_t)decode_grid(b->max_lc_lp, ctx->num_cus);
+        const size_t slots = (size_t)decode_grid(b->max_lc_lp, ctx->num_cus, ~0u);
         if (hipMalloc(&b->d_mlit, slots * b->mlit_stride * sizeof(uint16_t)) != hipSuccess) return fail(XLZ_ERR_DEVICE);
     }
     {
         // pack the payloads into the context's pinned image (several host threads), one H2D copy
         HostPipe &hp = ctx->pipe;
-        std::lock_guard<std::mutex> pl(hp.mu);
+        std::lock_guard<std::mutex> pl(hp.mu_in);
         if (hp.pin_in_cap < b->in_bytes) {
             if (hp.pin_in) (void)hipHostFree(hp.pin_in);
             hp.pin_in = nullptr;
@@ -708,7 +712,7 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
     const uint32_t grid = std::min<uint32_t>((uint32_t)n, big ? big_model_grid(ctx->num_cus)
-                                                              : decode_grid(b->max_lc_lp, ctx->num_cus));
+                                                              : decode_grid(b->max_lc_lp, ctx->num_cus, (uint32_t)n));
     int st = XLZ_ERR_DEVICE;
     if (hipMalloc(&d_units, n * sizeof(Unit)) == hipSuccess && hipMalloc(&d_order, n * sizeof(uint32_t)) == hipSuccess &&
         hipMalloc(&d_res, n * sizeof(UnitResult)) == hipSuccess &&
@@ -756,7 +760,7 @@ int collect(xlz_batch *b)
     xlz_ctx *ctx = b->ctx;
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipEventSynchronize(b->ev1)); // this batch's launches (a later batch may already be queued behind them)
     std::vector<UnitResult> &ur = b->unit_results;
     ur.resize(b->units.size());
     if (!ur.empty())
@@ -917,7 +921,7 @@ extern "C" int xlz_batch_unit_trace(xlz_batch *b, uint32_t *t_start, uint32_t *t
 extern "C" int xlz_batch_launch_info(xlz_batch *b, uint32_t *workgroups, uint32_t *lds_bytes)
 {
     if (!b) return XLZ_ERR_BAD_ARG;
-    const uint32_t grid = std::min<uint32_t>(b->n_normal, decode_grid(b->max_lc_lp, b->ctx->num_cus));
+    const uint32_t grid = std::min<uint32_t>(b->n_normal, decode_grid(b->max_lc_lp, b->ctx->num_cus, b->n_normal));
     if (workgroups) *workgroups = grid;
     if (lds_bytes) *lds_bytes = decode_lds_bytes(b->max_lc_lp);
     return XLZ_OK;
@@ -992,14 +996,17 @@ int download_all(xlz_batch *b, const xlz_stream_desc *streams, const xlz_result 
     }
     if (chunks.empty()) return XLZ_OK;
 
-    std::lock_guard<std::mutex> pl(hp.mu);
+    std::lock_guard<std::mutex> pl(hp.mu_out);
     HIP_TRY(hipSetDevice(ctx->device));
     if (!hp.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&hp.copy_stream, hipStreamNonBlocking));
     for (int r = 0; r < HostPipe::kRing; r++) {
         if (!hp.ring[r]) HIP_TRY(hipHostMalloc(&hp.ring[r], HostPipe::kRingBytes, hipHostMallocDefault));
         if (!hp.ring_ev[r]) HIP_TRY(hipEventCreateWithFlags(&hp.ring_ev[r], hipEventDisableTiming));
     }
-    HIP_TRY(hipStreamSynchronize(ctx->stream)); // the decode has finished (results were read)
+    // the decode of THIS batch has finished (its results were read).  Not hipStreamSynchronize(ctx->stream): in a
+    // pipelined call the next sub-batch is decoding on that stream right now, and waiting for it is what made round 2's
+    // overlap experiments look as if "a copy does not start under a running launch" (it does: tools/overlap_probe.py)
+    HIP_TRY(hipEventSynchronize(b->ev1));
 
     // scatter workers: chunk k is claimed by one worker, which waits for its copy event
     const unsigned nworkers = std::min<unsigned>(host_threads(b->out_bytes), HostPipe::kRing);
@@ -1076,35 +1083,207 @@ int download_all(xlz_batch *b, const xlz_stream_desc *streams, const xlz_result 
 
 static int decode_oversize(xlz_ctx *ctx, const xlz_stream_desc *streams, xlz_result *results, const std::vector<size_t> &idx);
 
+// busy wave time / (wave slots x launch span) of a batch's last main launch, from the units' s_memrealtime stamps
+static void launch_occupancy(xlz_batch *b, xlz_call_stats &cs)
+{
+    uint32_t slots = 0;
+    (void)xlz_batch_launch_info(b, &slots, nullptr);
+    cs.wave_slots = slots;
+    cs.units = b->unit_results.size();
+    cs.slot_occupancy = 0;
+    cs.kernel_span_ms = 0;
+    if (b->unit_results.empty() || slots == 0) return;
+    uint32_t t0 = b->unit_results[0].t_start;
+    for (const UnitResult &u : b->unit_results)
+        if ((int32_t)(u.t_start - t0) < 0) t0 = u.t_start;
+    uint64_t busy = 0;
+    uint32_t span = 0;
+    for (const UnitResult &u : b->unit_results) {
+        busy += (uint32_t)(u.t_end - u.t_start);
+        span = std::max(span, (uint32_t)(u.t_end - t0));
+    }
+    if (span == 0) return;
+    cs.kernel_span_ms = span / 1e5; // 100 MHz ticks
+    cs.slot_occupancy = (double)busy / ((double)slots * span);
+}
+
+extern "C" int xlz_ctx_last_call_stats(xlz_ctx *ctx, xlz_call_stats *out)
+{
+    if (!ctx || !out) return XLZ_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->have_last_call) return XLZ_ERR_BAD_ARG;
+    *out = ctx->last_call;
+    return XLZ_OK;
+}
+
+// Where a call of several wave rounds is cut into sub-batches whose upload, decode and download overlap: equal
+// shares of the output, each at least one wave round of streams and about 1 GiB, at most eight.  One sub-batch =
+// the plain sequence (a single wave round has nothing to overlap: every stream needs the whole launch).
+static void plan_sub_batches(const xlz_stream_desc *streams, size_t n, std::vector<size_t> &cuts)
+{
+    cuts.assign(1, 0);
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++) total += streams[i].out_cap;
+    const size_t k_round = 4096; // streams of one wave round (16 waves on each of 256 CUs)
+    size_t n_sub = std::min<size_t>(std::min<size_t>(8, n / k_round), (size_t)(total >> 30));
+    if (n_sub >= 2) {
+        uint64_t acc = 0;
+        size_t next = 1;
+        for (size_t i = 0; i < n && next < n_sub; i++) {
+            acc += streams[i].out_cap;
+            if (acc >= total / n_sub * next && i + 1 - cuts.back() >= k_round / 2 && n - (i + 1) >= k_round / 2) {
+                cuts.push_back(i + 1);
+                next++;
+            }
+        }
+    }
+    cuts.push_back(n);
+}
+
 extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_result *results)
 {
     if (!ctx || (!streams && n) || (!results && n)) return XLZ_ERR_BAD_ARG;
     for (size_t i = 0; i < n; i++)
         if (!streams[i].out && streams[i].out_cap) return XLZ_ERR_BAD_ARG;
-    // upload (pinned image, one copy) -> decode -> download (pinned ring, D2H overlapped with the scatter
-    // into the callers' buffers).  Splitting a call into sub-batches whose upload / decode / download
-    // overlap was built and measured in round 2 and is NOT here: on this stack a D2H copy enqueued on
-    // a second stream did not start before the running decode launch had finished, and a call of one
-    // wave round has nothing to overlap anyway.
+    // upload (pinned image, one copy) -> decode -> download (pinned ring, D2H overlapped with the scatter into the
+    // callers' buffers).  A call of several wave rounds runs as a PIPELINE of sub-batches on three host threads:
+    // sub-batch k+1 is parsed, packed and uploaded and sub-batch k-1 is downloaded and scattered while sub-batch k
+    // decodes; the launches are queued back to back on the context's stream.  (The reference's pump interleaves
+    // producing and consuming by construction, reader1.go:223-254.)  Copies on a second stream run at full PCIe speed
+    // under the persistent decode grid and do not slow it (tools/overlap_probe.py: 57 GB/s either way).
     const char *dbg = getenv("XLZ_DEBUG"); // debugging aid: log HIP failures and the phase times of this call
     const auto t0 = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (dbg) fprintf(stderr, "xlz_decode_batch: %-10s at %.1f ms\n", what,
-                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    std::vector<size_t> cuts;
+    plan_sub_batches(streams, n, cuts);
+    const size_t S = cuts.size() - 1;
+    xlz_call_stats cs;
+    memset(&cs, 0, sizeof cs);
+    cs.streams = n;
+    cs.sub_batches = (uint32_t)S;
+
+    std::vector<xlz_batch *> sub(S, nullptr);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int> created(S, 0), decoded(S, 0); // 0 pending, 1 done, -1 failed
+    int st_up = XLZ_OK, st_down = XLZ_OK;
+    bool abort_all = false;
+    double t_first_up = 0, t_decoded = 0, occ_busy = 0, occ_span = 0;
+
+    auto uploader = [&] {
+        for (size_t k = 0; k < S; k++) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (abort_all) return;
+            }
+            xlz_batch *b = nullptr;
+            const int st = xlz_batch_create(ctx, streams + cuts[k], cuts[k + 1] - cuts[k], &b);
+            if (dbg) fprintf(stderr, "xlz_decode_batch: sub-batch %zu uploaded at %.1f ms\n", k, now_ms());
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                sub[k] = b;
+                created[k] = st == XLZ_OK ? 1 : -1;
+                if (st != XLZ_OK) st_up = st, abort_all = true;
+                if (k == 0) t_first_up = now_ms();
+            }
+            cv.notify_all();
+            if (st != XLZ_OK) return;
+        }
     };
-    xlz_batch *b = nullptr;
-    int st = xlz_batch_create(ctx, streams, n, &b);
-    if (st != XLZ_OK) return st;
-    lap("uploaded");
-    st = xlz_batch_run(b);
-    if (st == XLZ_OK) st = xlz_batch_results(b, results);
-    lap("decoded");
-    if (st == XLZ_OK) st = download_all(b, streams, results);
-    lap("downloaded");
+    auto downloader = [&] {
+        for (size_t k = 0; k < S; k++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return decoded[k] != 0 || abort_all; });
+                if (decoded[k] != 1) return;
+            }
+            const int st = download_all(sub[k], streams + cuts[k], results + cuts[k]);
+            if (dbg) fprintf(stderr, "xlz_decode_batch: sub-batch %zu downloaded at %.1f ms\n", k, now_ms());
+            if (st != XLZ_OK) {
+                std::lock_guard<std::mutex> lk(mu);
+                st_down = st;
+                abort_all = true;
+                cv.notify_all();
+                return;
+            }
+        }
+    };
+    std::thread th_up, th_down;
+    if (S > 1) {
+        th_up = std::thread(uploader);
+        th_down = std::thread(downloader);
+    }
+    // this thread: launch sub-batch k as soon as it is uploaded (queued behind k-1 on the stream), then collect k-1
+    int st = XLZ_OK;
+    auto collect_one = [&](size_t k) {
+        int e = xlz_batch_results(sub[k], results + cuts[k]);
+        if (e == XLZ_OK) {
+            xlz_call_stats one;
+            memset(&one, 0, sizeof one);
+            launch_occupancy(sub[k], one);
+            cs.units += one.units;
+            cs.wave_slots = std::max(cs.wave_slots, one.wave_slots);
+            cs.kernel_span_ms += one.kernel_span_ms;
+            occ_busy += one.slot_occupancy * one.kernel_span_ms;
+            occ_span += one.kernel_span_ms;
+        }
+        if (dbg) fprintf(stderr, "xlz_decode_batch: sub-batch %zu decoded at %.1f ms\n", k, now_ms());
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            decoded[k] = e == XLZ_OK ? 1 : -1;
+            if (e != XLZ_OK) abort_all = true;
+            t_decoded = now_ms();
+        }
+        cv.notify_all();
+        return e;
+    };
+    if (S == 1) {
+        uploader();
+        st = st_up;
+        if (st == XLZ_OK) st = xlz_batch_run(sub[0]);
+        if (st == XLZ_OK) st = collect_one(0);
+        if (st == XLZ_OK) downloader(), st = st_down;
+    } else {
+        for (size_t k = 0; k < S && st == XLZ_OK; k++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return created[k] != 0 || abort_all; });
+                if (created[k] != 1) break;
+            }
+            st = xlz_batch_run(sub[k]);
+            if (st == XLZ_OK && k > 0) st = collect_one(k - 1);
+        }
+        bool all_launched;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            all_launched = created[S - 1] == 1 && !abort_all;
+        }
+        if (st == XLZ_OK && all_launched) st = collect_one(S - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (st != XLZ_OK) abort_all = true;
+        }
+        cv.notify_all();
+        th_up.join();
+        th_down.join();
+        if (st == XLZ_OK) st = st_up != XLZ_OK ? st_up : st_down;
+    }
+    const double t_end = now_ms();
+    cs.upload_ms = t_first_up;             // until the first sub-batch was on the device
+    cs.decode_ms = t_decoded - t_first_up; // first launch to the last results (uploads and downloads of the others inside)
+    cs.download_ms = t_end - t_decoded;    // what was left to download when the last sub-batch had decoded
+    cs.total_ms = t_end;
+    cs.slot_occupancy = occ_span > 0 ? occ_busy / occ_span : 0;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        ctx->last_call = cs;
+        ctx->have_last_call = st == XLZ_OK;
+    }
     std::vector<size_t> big; // streams of 4 GiB and more do not fit a unit's 32-bit counters: sessions
-    for (size_t i = 0; i < n && st == XLZ_OK; i++)
-        if (b->plans[i].oversize) big.push_back(i);
-    xlz_batch_destroy(b);
+    for (size_t k = 0; k < S && st == XLZ_OK; k++)
+        for (size_t i = 0; i < sub[k]->n; i++)
+            if (sub[k]->plans[i].oversize) big.push_back(cuts[k] + i);
+    for (xlz_batch *b : sub) xlz_batch_destroy(b); // (hipFree waits for the device: all of them at the end)
     if (st == XLZ_OK && !big.empty()) st = decode_oversize(ctx, streams, results, big);
     return st;
 }

@@ -1176,7 +1176,15 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
     }
 }
 
-__global__ __launch_bounds__(64) void xlz_decode_kernel(LaunchParams p)
+// Resident waves per SIMD.  The compiler's default register allocation took 108 VGPRs -- FOUR waves per SIMD (512 / 112),
+// so a grid of 20 single-wave workgroups per CU was never resident (round 2's "20 waves per CU: +-0.5 %" measured nothing).
+// XLZ_WAVES_PER_EU = 5 caps the allocation at 96 VGPRs (the fast loop's fixed v13..v63 stay; the C++ around it spills 16
+// registers in cold code).
+#ifndef XLZ_WAVES_PER_EU
+#define XLZ_WAVES_PER_EU 5
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XLZ_WAVES_PER_EU, XLZ_WAVES_PER_EU)))
+void xlz_decode_kernel(LaunchParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds_probs[];
     decode_units<false>(p, lds_probs, p.mlit + (size_t)blockIdx.x * p.mlit_stride);
@@ -1192,20 +1200,29 @@ uint32_t decode_lds_bytes(uint32_t max_lc_lp) { return num_probs(max_lc_lp) * 2u
 
 uint32_t big_model_grid(int num_cus) { return (uint32_t)num_cus; } // one workgroup per CU
 // resident single-wave workgroups per CU of the LDS-model launch
-static uint32_t decode_per_cu(uint32_t max_lc_lp)
+// The CU's instruction issue saturates at 16 waves; a fifth wave per SIMD adds 3.5 % on launches of many
+// rounds (measured on the cfg3 shape, profiles/r03/ab_occupancy.txt) but stretches every round by a quarter, which a
+// launch of one or two rounds cannot win back (8192 units: 4096 + 4096 becomes 5120 + 3072).  So: 20 per CU from four
+// rounds on, 16 below.
+static uint32_t decode_per_cu(uint32_t max_lc_lp, uint32_t n_units, int num_cus)
 {
     const uint32_t fit = kMaxLdsBytes / decode_lds_bytes(max_lc_lp);
     uint32_t per_cu = fit;
 #ifdef XLZ_PER_CU_MAX // A/B builds
     if (per_cu > XLZ_PER_CU_MAX) per_cu = XLZ_PER_CU_MAX;
 #else
-    if (per_cu > 16) per_cu = 16;  // measured: 12..16 resident waves is the plateau
+    if (per_cu > 4 * XLZ_WAVES_PER_EU) per_cu = 4 * XLZ_WAVES_PER_EU; // what the register allocation lets be resident
+    if (per_cu > 16 && n_units < 4u * per_cu * (uint32_t)num_cus) per_cu = 16;
 #endif
     if (per_cu > 4) per_cu &= ~3u; // equal load on the four SIMDs
     return per_cu;
 }
 
-uint32_t decode_grid(uint32_t max_lc_lp, int num_cus) { return decode_per_cu(max_lc_lp) * (uint32_t)num_cus; }
+// resident workgroups of the LDS-model launch over n_units units (n_units = ~0u: the most any launch uses)
+uint32_t decode_grid(uint32_t max_lc_lp, int num_cus, uint32_t n_units)
+{
+    return decode_per_cu(max_lc_lp, n_units, num_cus) * (uint32_t)num_cus;
+}
 
 int launch_decode(const LaunchParams &p, int num_cus, void *stream)
 {
@@ -1218,7 +1235,7 @@ int launch_decode(const LaunchParams &p, int num_cus, void *stream)
     }
     const uint32_t lds = decode_lds_bytes(p.max_lc_lp);
     if (lds > kMaxLdsBytes) return -1;
-    uint32_t grid = decode_grid(p.max_lc_lp, num_cus);
+    uint32_t grid = decode_grid(p.max_lc_lp, num_cus, p.n_units);
     if (grid > p.n_units) grid = p.n_units;
     if (grid == 0) return 0;
     if (lds > 64u * 1024u &&

@@ -56,3 +56,35 @@ def test_strong_scaling_shards_are_a_partition_of_the_one_batch():
                     assert c == whole[i] and d == wd[i]
                     seen[i] = True
         assert len(seen) == spec["streams"]
+
+
+def test_the_headline_is_one_workload_at_every_n_and_the_xz_file_is_what_liblzma_reads():
+    """the curve's points must be one workload: cfg3 is the default headline, the side list does not
+    contain it, every corpus uses the one encoder setting except the explicitly named preset-6 entry"""
+    assert bench.HEADLINES[0] == "cfg3" and "cfg3" not in bench.SIDE
+    assert all(bench.CONFIGS[n]["enc"] == bench.ENC_FAST for n in bench.CONFIGS if n != "cfg2-T-p6")
+    with ProcessPoolExecutor(max_workers=2) as pool:
+        data, want = bench.xz_file(pool, 5, 30_000)
+    p = lzma.decompress(data)
+    assert len(p) == 150_000 and hashlib.sha256(p).digest() == want
+    import lzma_amd
+    blocks, total = lzma_amd.xz_index(data)
+    assert len(blocks) == 5 and total == 150_000
+    # the lone-wave sample of an LZMA2 config is a valid stream of its first segments
+    spec = _tiny("cfg4", segments=70, size=5_000)
+    with ProcessPoolExecutor(max_workers=2) as pool:
+        comp, dig = bench.make_corpus(pool, spec, 1)
+    sample, osz = bench.lone_wave_sample(spec, comp)
+    assert osz == 64 * 5_000
+    got = oracle.lzma2_raw(sample[0], spec["dict"], osz)
+    assert got[1] == 0 and len(got[0]) == osz
+
+
+def test_issue_bounds_arithmetic():
+    prof = {"issue": {"salu_per_decoded_byte": 20.0, "valu_per_decoded_byte": 20.0, "source": "x"}}
+    r = bench.issue_bounds(prof, 4 << 30, 200.0, {"bytes_per_s_per_wave": 6e6}, 4096)
+    # scalar port binds: 256 CUs x 2.4 GHz / (20 / 0.97) cycles per byte
+    assert abs(r["issue_bound_GBps"] - 256 * 2.4 / (20 / 0.97)) < 0.01
+    assert abs(r["latency_bound_GBps"] - 6e6 * 4096 / 1e9) < 0.01
+    assert r["binding"] == "latency" and 0 < r["frac_of_bound"] < 1
+    assert bench.issue_bounds(None, 1 << 30, 100.0, None, None) == {"achieved_decoded_GBps": round((1 << 30) / 0.1 / 1e9, 3)}

@@ -74,3 +74,54 @@ def test_one_stream_wraps_an_8_mib_window(ctx):
     # decompress.go:22) leaves the encoder's, the decode derails -- identically in the oracle
     assert len(want[1][0]) > 1_048_583 and want[1][0][:1_048_583] == p2[:1_048_583]
     assert got[1] == want[1]
+
+
+def test_a_call_of_several_wave_rounds_runs_as_a_pipeline(ctx):
+    """xlz_decode_batch with 12 288 streams / 3 GiB of output: three sub-batches whose upload, decode and download
+    overlap (xlz_call_stats.sub_batches).  Host buffers in and out; every stream's bytes, status and consumed input
+    as for the same streams decoded alone -- including damaged streams in every sub-batch (one bad stream never
+    fails the call) and an empty one."""
+    import ctypes
+    import numpy as np
+    from lzma_amd import _native as N
+    nd, n, size = 48, 12288, 256 << 10
+    ps = [corpus.plain("TMZR"[i % 4], 93_000 + i, size) for i in range(nd)]
+    cs = [corpus.compress_alone(p, preset=0) for p in ps]
+    bad = {}
+    for j in (5, 4100, 4101, 9000, n - 1):      # damaged: a flipped byte deep inside, or cut short
+        c = bytearray(cs[j % nd])
+        if j % 2:
+            c[len(c) // 2] ^= 0x55
+        else:
+            del c[len(c) * 2 // 3:]
+        bad[j] = bytes(c)
+    bad[7000] = b""
+    ins = [np.frombuffer(bad.get(i, cs[i % nd]), dtype=np.uint8) for i in range(n)]
+    out = np.zeros((n, size), dtype=np.uint8)
+    descs = (N.StreamDesc * n)()
+    for i in range(n):
+        descs[i].inp = ins[i].ctypes.data if ins[i].size else None
+        descs[i].in_len = ins[i].size
+        descs[i].out, descs[i].out_cap = out[i].ctypes.data, size
+        descs[i].format = FMT_LZMA_ALONE
+    res = (N.Result * n)()
+    assert N.lib().xlz_decode_batch(ctx._h, descs, n, res) == 0
+    st = ctx.last_call_stats()
+    assert st["sub_batches"] == 3 and st["streams"] == n and st["units"] == n - 1   # (the empty stream has no unit)
+    assert 0.5 < st["slot_occupancy"] <= 1.0 and st["total_ms"] > 0
+    hs = [hashlib.sha256(p).digest() for p in ps]
+    for i in range(n):
+        if i in bad:
+            want = oracle.lzma1_alone(bad[i], size)
+            assert (bytes(out[i][: res[i].out_len]), res[i].status, res[i].in_consumed) == want, i
+        else:
+            assert res[i].status == 0 and res[i].out_len == size and res[i].in_consumed == len(cs[i % nd]), i
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as ex:
+        ok = list(ex.map(lambda i: i in bad or hashlib.sha256(out[i]).digest() == hs[i % nd], range(n)))
+    assert all(ok)
+    # the same call again (pinned pools warm), and a small call right after it: one sub-batch
+    assert N.lib().xlz_decode_batch(ctx._h, descs, n, res) == 0
+    assert all(res[i].status == 0 for i in range(n) if i not in bad)
+    got = lzma_amd.decode_batch(ctx, [Stream(cs[0], FMT_LZMA_ALONE, out_cap=size)])
+    assert got[0][0] == ps[0] and ctx.last_call_stats()["sub_batches"] == 1

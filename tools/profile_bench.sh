@@ -1,15 +1,15 @@
 #!/bin/bash
 # rocprofv3 passes over ONE bench.py config (run on the GPU box via gpurun).
-#   tools/profile_bench.sh <tag> <config> [extra bench args]     config: cfg2-T (default), cfg2-R, cfg3, ...
+#   tools/profile_bench.sh <tag> <config> [extra bench args]     config: cfg3 (default), cfg2-T, cfg2-R, cfg4, cfg5, ...
 # 1) --kernel-trace --stats  2) --pmc FETCH_SIZE  3) --pmc WRITE_SIZE  4) SQ instruction mix  5) SQ issue activity
 # Counter passes are separate runs and never combined with tracing (pool rule).  The program after
 # `--` is python3 itself (no env / shell hop: the profiler has initialised the GPU by then).
 set -u
 : "${GRAFT_REPO_ROOT:?run this on the GPU box through gpurun (GRAFT_REPO_ROOT is set there)}"
-TAG=${1:-r02}; CFG=${2:-cfg2-T}; shift; shift
+TAG=${1:-r03}; CFG=${2:-cfg3}; shift; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-ARGS="--headline $CFG --configs none --steps 3 --warmup 1 --no-cpu-baseline $@"
+ARGS="--headline $CFG --configs none --extras none --steps 3 --warmup 1 --no-cpu-baseline $@"
 echo "bench args: $ARGS" > $O/command.txt
 rocprofv3 --kernel-trace --stats -d $O/kt --output-format csv -- python3 $R/bench.py $ARGS > $O/kt.json 2> $O/kt.err || exit 1
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py $ARGS > $O/fetch.json 2> $O/fetch.err || exit 1

@@ -5,7 +5,7 @@ usage: python tools/save_profile.py <tag> <dest-prefix> [config]   e.g.  r02a pr
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # kernel_rev()
+import bench  # kernel_rev(): the build id compiled into lzma_amd/libxlz.so (must be the library the profile ran on)
 
 tag, dest = sys.argv[1], sys.argv[2]
 cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg2-T"
@@ -31,6 +31,8 @@ w = csv.writer(open(dest + "_pmc.csv", "w"))
 w.writerow(["pass", "dispatch", "grid", "wg", "vgpr", "sgpr", "counter", "value"])
 w.writerows(rows)
 line = json.loads(open(src + "/kt.json").read().strip().splitlines()[-1])
+assert line["config"]["kernel_rev"] == bench.kernel_rev(), "the profile was taken on another build than lzma_amd/libxlz.so"
+decoded = line["config"]["streams_total"] * line["config"]["bytes_per_stream"]
 mean = lambda k: sum(vals[k]) / len(vals[k])
 fetch = mean("FETCH_SIZE") * 1024
 write = mean("WRITE_SIZE") * 1024
@@ -39,7 +41,7 @@ grid = int(rows[0][2]) // 64  # single-wave workgroups = wave slots of the launc
 CUS, CLK = 256, 2.4e9
 cu_cycles = kernel_ms / 1e3 * CLK * CUS
 entry = {
-    "workload": line["config"]["workload"], "kernel_rev": bench.kernel_rev(), "source": dest + "_pmc.csv",
+    "workload": line["config"]["workload"], "kernel_rev": line["config"]["kernel_rev"], "source": dest + "_pmc.csv",
     "fetch_bytes_per_launch_raw": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KiB units x 1024), mean over the launches "
             "of xlz_decode_kernel; FETCH_SIZE taken raw: this kernel's reads are one-byte-per-lane gathers and 4-byte-per-"
@@ -55,8 +57,11 @@ entry = {
         "salu_utilisation": round(mean("SQ_INSTS_SALU") / cu_cycles / 0.97, 4),
         "valu_utilisation": round(mean("SQ_INSTS_VALU") / cu_cycles / 1.28, 4),
         "instructions_per_decoded_byte": round((mean("SQ_INSTS_SALU") + mean("SQ_INSTS_VALU") + mean("SQ_INSTS_BRANCH") +
-                                               mean("SQ_INSTS_LDS") + mean("SQ_INSTS_VMEM")) /
-                                              (line["config"]["streams_per_gpu"] * line["config"]["bytes_per_stream"]), 2),
+                                               mean("SQ_INSTS_LDS") + mean("SQ_INSTS_VMEM")) / decoded, 2),
+        # what bench.py's roofline.issue.issue_bound is made of
+        "salu_per_decoded_byte": round(mean("SQ_INSTS_SALU") / decoded, 3),
+        "valu_per_decoded_byte": round(mean("SQ_INSTS_VALU") / decoded, 3),
+        "branch_per_decoded_byte": round(mean("SQ_INSTS_BRANCH") / decoded, 3),
         # SQ_WAVE_CYCLES counts in quad-cycles per wave: x4 / (slots x kernel cycles) = average slot occupancy
         "slot_occupancy": round(mean("SQ_WAVE_CYCLES") * 4 / (grid * kernel_ms / 1e3 * CLK), 4),
         "budget": "measured ceilings per CU cycle: 0.97 SALU, 1.28 VALU (tools/ubench/mix2.hip); "
