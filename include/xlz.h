@@ -187,9 +187,11 @@ void xlz_batch_destroy(xlz_batch *batch);
  * stream is decoded exactly once, whatever its size or compression ratio.  An LZMA2
  * stream whose headers announce eight or more dictionary-reset units is served in runs
  * of whole units (<= 64 MiB of output each) decoded unit-parallel by the batch engine.
- * Two rare fallbacks decode the whole stream in one batch and skip what has been delivered:
- * models with lc+lp > 8 (HBM-resident model) and malformed LZMA2 streams whose copies
- * read window bytes of an earlier dictionary epoch.                                    */
+ * Sessions cover the reference's whole parameter range: a model with lc+lp > 8 (it does not fit
+ * a CU's LDS) runs in the HBM-model launch, an LZMA2 chunk that renews the model with larger
+ * properties makes the session grow its state block, and copies that read behind an LZMA2
+ * dictionary reset are served from an image of the reference's uncleared window buffer
+ * (window.go:135-140) that the device keeps per reader (dictSize bytes, like the window itself). */
 typedef struct xlz_reader xlz_reader;
 xlz_reader *xlz_new_reader1(xlz_ctx *ctx, const uint8_t *in, size_t in_len, int *err); /* NewReader1 */
 xlz_reader *xlz_new_reader2(xlz_ctx *ctx, const uint8_t *in, size_t in_len, int dict_size,
@@ -218,9 +220,11 @@ long xlz_reader_read(xlz_reader *r, uint8_t *p, size_t n, int *err);
  * xlz_reader_expect_more once, then: xlz_reader_read returns XLZ_NEED_INPUT whenever the decoder has
  * used up its input -- feed the next piece (any size; >= 128 KiB keeps LZMA2 chunks whole) or
  * declare the end, and read again.  The library keeps only the bytes the decoder has not consumed:
- * with this, a reader's memory is bounded on BOTH sides.  Streams with lc+lp > 4 after the first
- * piece, and malformed LZMA2 streams that read across a dictionary reset, end in XLZ_ERR_UNSUPPORTED
- * in this mode (there is no whole stream to fall back to).                                       */
+ * with this, a reader's memory is bounded on BOTH sides.  A fed reader decodes everything a reader
+ * over the whole buffer decodes (models up to lc = 8, lp = 4 taken up in mid-stream; copies that read
+ * behind an LZMA2 dictionary reset).  xlz_reader_expect_more is also accepted right after
+ * xlz_reader_reopen: (*Reader1).Reopen takes an io.ByteReader (reader1.go:166-176), `in` is then the
+ * first piece of the new stream (at least its five range-coder bytes).                            */
 int xlz_reader_expect_more(xlz_reader *r);
 int xlz_reader_feed(xlz_reader *r, const uint8_t *data, size_t n);
 int xlz_reader_feed_eof(xlz_reader *r);

@@ -367,12 +367,22 @@ class Reader1(_Reader):
         if st != OK:
             raise LzmaError(st, "Reset")
 
-    def Reopen(self, data, unpack_size=UNKNOWN_SIZE):
-        """(*Reader1).Reopen(inStream, unpackSize) (reader1.go:166-176): returns err"""
-        st = N.lib().xlz_reader_reopen(self._h, bytes(data), len(data), unpack_size)
+    def Reopen(self, data, unpack_size=UNKNOWN_SIZE, piece=1 << 20):
+        """(*Reader1).Reopen(inStream, unpackSize) (reader1.go:166-176): returns err.  `data`: the new raw stream as
+        bytes, or a file-like object that is then pulled `piece` bytes at a time (the reference takes an io.ByteReader)"""
+        head, src = _head_and_source(data, piece)
+        st = N.lib().xlz_reader_reopen(self._h, head, len(head), unpack_size)
+        self._src, self._piece = None, piece
         if st == ERR_HEADER_EOF:
             return io_EOF
-        return None if st == OK else LzmaError(st)
+        if st != OK:
+            return LzmaError(st)
+        if src is not None:
+            st = N.lib().xlz_reader_expect_more(self._h)
+            if st != OK:
+                return LzmaError(st, "xlz_reader_expect_more")
+            self._src = src
+        return None
 
 
 class Reader2(_Reader):

@@ -98,7 +98,11 @@ enum : uint32_t {
     AUX_STALE = 2,     // a copy reached in front of the current dictionary epoch and the launch had no
                        // epoch table: the bytes read there are NOT exact, the host decodes the stream
                        // again with one (window.go:135-140 does not clear the buffer)
-    AUX_NEED_INPUT = 4 // paused because the input window ran low (UNIT_F_MORE_INPUT)
+    AUX_NEED_INPUT = 4, // paused because the input window ran low (UNIT_F_MORE_INPUT)
+    AUX_GROW = 8,       // paused in front of an LZMA2 chunk whose properties need a larger model than the unit's state
+                        // block holds: lc+lp wanted in bits 8..11
+    AUX_GROW_SHIFT = 8,
+    AUX_GROW_MASK = 0xF00
 };
 
 // device-side status values = include/xlz.h
@@ -119,6 +123,8 @@ enum : int32_t {
 // matched-literal half of the model (which lives here for the unit's whole life, not in a
 // workgroup slot).
 constexpr uint32_t kStateWords = 64;
+constexpr uint32_t kStateShadowWord = 32; // words 32, 33 of the header: device address of the session's window image
+                                          // (LZMA2 readers; written by the host, read by the wave)
 static inline constexpr uint32_t state_probs_off() { return kStateWords * 4; }
 static inline constexpr uint32_t state_mprobs_off(uint32_t lc_lp) { return state_probs_off() + ((num_probs(lc_lp) * 2 + 15) & ~15u); }
 static inline constexpr uint32_t state_bytes(uint32_t lc_lp) { return state_mprobs_off(lc_lp) + num_matched_probs(lc_lp) * 2; }

@@ -1347,6 +1347,9 @@ extern "C" int xlz_decode_batch_multi(xlz_ctx *const *ctxs, size_t n_ctx, const 
 struct Session {
     uint8_t *d_ctl = nullptr;   // Unit | order | UnitResult | UnitState | input window
     uint8_t *d_win = nullptr;   // output window: [history | bytes of this refill | slack]
+    uint8_t *d_shadow = nullptr; // LZMA2: the reference's window buffer as of the last dictionary reset (dictSize bytes):
+                                 // what a copy reads behind a reset once the epoch's bytes have slid out of d_win
+                                 // (window.go:135-140 does not clear the buffer; the wave keeps the image, xlz_kernel.hip)
     size_t win_cap = 0, win_max = 0;
     size_t off_state = 0, off_in = 0, in_buf = 0;
     Unit unit;
@@ -1384,6 +1387,7 @@ struct xlz_reader {
     // streaming input (xlz_reader_expect_more / _feed / _feed_eof): `in` holds the bytes from stream
     // offset in_base on; what the decoder has consumed is dropped at every feed
     bool streaming = false, in_eof = false, need_input = false;
+    bool input_fresh = true; // nothing of the current input (constructor's or Reopen's) has been decoded yet: expect_more is allowed
     uint64_t in_base = 0;
     // unit-parallel LZMA2 (reader_parallel): the stream's dictionary-reset units, the next one to decode
     std::vector<uint64_t> par_in, par_out; // prefix sums of the units' input / output bytes
@@ -1437,6 +1441,7 @@ void session_free(Session *ss)
     if (!ss) return;
     if (ss->d_ctl) (void)hipFree(ss->d_ctl);
     if (ss->d_win) (void)hipFree(ss->d_win);
+    if (ss->d_shadow) (void)hipFree(ss->d_shadow);
     delete ss;
 }
 
@@ -1477,10 +1482,12 @@ int session_open(xlz_reader *r)
         ss->model_lc_lp = (uint32_t)u.lc + u.lp;
         known = u.unpack_size;
     }
-    if (ss->model_lc_lp > kMaxLcLpLds) {
+    if (ss->model_lc_lp > kMaxLcLp) { // (the constructors have refused these: DecodeProp)
         delete ss;
         return XLZ_ERR_UNSUPPORTED;
     }
+    // lc+lp > 8 does not fit a CU's LDS: the unit runs in the HBM-model launch (sessions_step), its model saved and
+    // restored like any other
     u.flags = UNIT_F_LAST;
     // output window: twice the dictionary (history + room to slide without overlap) + one refill;
     // a stream of known size never needs more than its size; start small, grow on demand
@@ -1502,6 +1509,20 @@ int session_open(xlz_reader *r)
     if (hipMemcpy(ss->d_ctl + 128, &zero, 4, hipMemcpyHostToDevice) != hipSuccess) { // order[0] = 0
         session_free(ss);
         return XLZ_ERR_DEVICE;
+    }
+    if (u.kind == UNIT_LZMA2) {
+        // the window image for reads behind a dictionary reset: allocated like the reference's window (eagerly, zero
+        // filled: window.go:18-29); its address sits in the state header where the wave looks for it
+        const uint64_t addr_words_off = ss->off_state + (size_t)kStateShadowWord * 4;
+        if (hipMalloc(&ss->d_shadow, u.dict_size) != hipSuccess || hipMemset(ss->d_shadow, 0, u.dict_size) != hipSuccess) {
+            session_free(ss);
+            return XLZ_ERR_DEVICE;
+        }
+        const uint64_t addr = (uint64_t)ss->d_shadow;
+        if (hipMemcpy(ss->d_ctl + addr_words_off, &addr, 8, hipMemcpyHostToDevice) != hipSuccess) {
+            session_free(ss);
+            return XLZ_ERR_DEVICE;
+        }
     }
     r->ss = ss;
     return XLZ_OK;
@@ -1572,16 +1593,41 @@ int session_prepare(xlz_reader *r, hipStream_t stream)
     return XLZ_OK;
 }
 
-// One refill of every reader in `rs` as ONE launch: each reader's unit continues from its saved
-// state and stops after about kChunk more bytes.  Fills r->chunk / r->finished / r->status.
+// Give a session's unit a state block for a larger model (the wave paused in front of an LZMA2 chunk whose properties
+// need it, AUX_GROW): the 256-byte register header moves over, the model itself is re-initialised by that chunk
+// (new properties always come with a state reset, reader2.go:155-165), the input window moves behind the new block.
+int session_grow_model(xlz_reader *r, uint32_t need, hipStream_t stream)
+{
+    Session *ss = r->ss;
+    if (need > kMaxLcLp) return XLZ_ERR_UNSUPPORTED;
+    const size_t new_off_in = align_up(ss->off_state + state_bytes(need), 256);
+    uint8_t *nc = nullptr;
+    if (hipMalloc(&nc, new_off_in + ss->in_buf) != hipSuccess) return XLZ_ERR_DEVICE;
+    if (hipMemcpyAsync(nc, ss->d_ctl, ss->off_state + kStateWords * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(nc + new_off_in, ss->d_ctl + ss->off_in, ss->in_buf, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) {
+        (void)hipFree(nc);
+        return XLZ_ERR_DEVICE;
+    }
+    (void)hipFree(ss->d_ctl);
+    ss->d_ctl = nc;
+    ss->off_in = new_off_in;
+    ss->model_lc_lp = need;
+    ss->unit.lc = (uint8_t)need; // LZMA2 units: lc = the largest lc+lp the model storage holds, lp = pb = 0
+    return XLZ_OK;
+}
+
+int sessions_launch(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs, bool big);
+
+// One refill of every reader in `all`: each reader's unit continues from its saved state and stops after about
+// kChunk more bytes.  The readers whose model fits LDS share ONE launch, those with lc+lp > 8 another (HBM-model
+// kernel).  Fills r->chunk / r->finished / r->status.
 int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &all)
 {
     if (all.empty()) return XLZ_OK;
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
-    uint32_t max_lc_lp = 0;
-    std::vector<xlz_reader *> live; // the readers of this launch: one that cannot be prepared ends alone
-    std::vector<Unit> units;
+    std::vector<xlz_reader *> normal, bigs; // one that cannot be prepared ends alone
     for (xlz_reader *r : all) {
         int st = session_prepare(r, ctx->stream);
         if (st == XLZ_ERR_UNSUPPORTED) { // this stream ends here; the others are not affected
@@ -1592,13 +1638,25 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &all)
             continue;
         }
         if (st != XLZ_OK) return st; // the device failed: nothing was launched, pending Reset / Reopen flags are still set
-        live.push_back(r);
-        units.push_back(r->ss->unit);
-        max_lc_lp = std::max(max_lc_lp, r->ss->model_lc_lp);
+        (r->ss->model_lc_lp > kMaxLcLpLds ? bigs : normal).push_back(r);
     }
-    if (live.empty()) return XLZ_OK;
-    const std::vector<xlz_reader *> &rs = live;
+    int st = XLZ_OK;
+    if (!normal.empty()) st = sessions_launch(ctx, normal, false);
+    if (st == XLZ_OK && !bigs.empty()) st = sessions_launch(ctx, bigs, true);
+    return st;
+}
+
+// ONE launch over prepared sessions of one kind (ctx->mu held, device set)
+int sessions_launch(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs, bool big)
+{
     const size_t n = rs.size();
+    uint32_t max_lc_lp = 0;
+    std::vector<Unit> units(n);
+    for (size_t i = 0; i < n; i++) {
+        units[i] = rs[i]->ss->unit;
+        if (big) units[i].flags |= UNIT_F_BIG_MODEL;
+        max_lc_lp = std::max(max_lc_lp, rs[i]->ss->model_lc_lp);
+    }
     // units / order / results of this launch: in the first reader's control block when it is alone,
     // else in a scratch allocation
     Unit *d_units = nullptr;
@@ -1624,6 +1682,16 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &all)
         }
     }
     uint16_t *d_mlit = nullptr; // resumable units keep their matched-literal tables in their state blocks
+    uint16_t *d_big = nullptr;  // HBM-model launch: one model slot per workgroup (restored from / saved to the unit's state)
+    uint32_t big_stride = 0;
+    if (big) {
+        big_stride = num_probs(max_lc_lp) + num_matched_probs(max_lc_lp);
+        const size_t grid = std::min<size_t>(n, big_model_grid(ctx->num_cus));
+        if (hipMalloc(&d_big, grid * big_stride * sizeof(uint16_t)) != hipSuccess) {
+            if (scratch) (void)hipFree(scratch);
+            return XLZ_ERR_DEVICE;
+        }
+    }
     int st = XLZ_ERR_DEVICE;
     std::vector<UnitResult> res(n);
     if (hipMemcpyAsync(d_units, units.data(), n * sizeof(Unit), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
@@ -1641,6 +1709,8 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &all)
         p.max_lc_lp = max_lc_lp;
         p.mlit = d_mlit;
         p.mlit_stride = 0;
+        p.scratch = d_big;
+        p.scratch_stride = big_stride;
         p.prio_tab = ctx->prio_tab;
         if (launch_decode(p, ctx->num_cus, ctx->stream) == 0 &&
             hipMemcpyAsync(res.data(), d_res, n * sizeof(UnitResult), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
@@ -1659,6 +1729,19 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &all)
             // (the device counts input modulo 2^32, relative arithmetic only; the window is < 4 GiB)
             ss->consumed = ss->in_skip + (uint32_t)((uint32_t)u.in_consumed - (uint32_t)ss->in_skip);
             r->n_refills++;
+            if (u.status == ST_PAUSED && (u.aux & AUX_GROW)) {
+                // the next chunk's properties need a larger model than the state block holds: nothing of it has been
+                // decoded; bytes produced before it are delivered below, the next refill resumes on the larger block
+                const int g = session_grow_model(r, (u.aux & AUX_GROW_MASK) >> AUX_GROW_SHIFT, ctx->stream);
+                if (g == XLZ_ERR_DEVICE) st = XLZ_ERR_DEVICE;
+                if (g == XLZ_ERR_UNSUPPORTED) {
+                    r->finished = true;
+                    r->status = XLZ_ERR_UNSUPPORTED;
+                    r->chunk.clear();
+                    r->rd = 0;
+                    continue;
+                }
+            }
             if (((u.aux & AUX_STALE) || u.status == ST_ERR_UNSUPPORTED) && r->streaming) {
                 // (no whole-stream fallback when the input is fed in pieces and dropped behind the decoder)
                 r->finished = true;
@@ -1695,6 +1778,7 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &all)
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) st = XLZ_ERR_DEVICE;
     }
     if (scratch) (void)hipFree(scratch);
+    if (d_big) (void)hipFree(d_big);
     return st;
 }
 
@@ -1842,6 +1926,7 @@ int reader_parallel_step(xlz_reader *r)
 // more decoded bytes into r->chunk (or the end of the stream into r->finished / r->status)
 int reader_refill(xlz_reader *r)
 {
+    r->input_fresh = false;
     if (r->desc.format == XLZ_FMT_LZMA2_RAW && !r->streaming && !r->whole && !r->ss && !r->par_tried)
         r->par = reader_parallel_plan(r);
     if (r->par) {
@@ -2163,8 +2248,10 @@ extern "C" int xlz_reader_reopen(xlz_reader *r, const uint8_t *in, size_t in_len
     if (!r || (!in && in_len)) return XLZ_ERR_BAD_ARG;
     if (r->closed) return XLZ_ERR_CLOSED;
     if (r->desc.format == XLZ_FMT_LZMA2_RAW || r->whole) return XLZ_ERR_UNSUPPORTED;
-    if (r->streaming && !r->in_eof) return XLZ_ERR_UNSUPPORTED; // the current stream is still being fed
-    r->streaming = false; // the new stream is given whole
+    // (a stream that is still being fed is simply abandoned, like the reference's old inStream)
+    r->streaming = false; // the new stream is given whole -- unless xlz_reader_expect_more follows: `in` is its first piece
+    r->in_eof = false;
+    r->input_fresh = true;
     r->in_base = 0;
     r->need_input = false;
     if (!r->ss) { // not started yet: open the session on the current stream's parameters first
@@ -2215,8 +2302,9 @@ extern "C" int xlz_reader_expect_more(xlz_reader *r)
 {
     if (!r) return XLZ_ERR_BAD_ARG;
     if (r->closed) return XLZ_ERR_CLOSED;
-    if (r->ss || r->whole) return XLZ_ERR_BAD_ARG; // before the first read
+    if (!r->input_fresh || r->whole) return XLZ_ERR_BAD_ARG; // before the first read of this input (constructor or Reopen)
     r->streaming = true;
+    r->in_eof = false;
     return XLZ_OK;
 }
 

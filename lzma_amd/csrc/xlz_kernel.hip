@@ -99,6 +99,11 @@ struct Dec {
     // exact launches: earlier dictionary epochs a copy may still read (window.Reset keeps the buffer)
     Epoch *epochs;
     uint32_t n_epochs;
+    // pull readers (sessions): the reference's window BUFFER as the last dictionary reset left it (dict_size bytes,
+    // circular index -> the last byte any earlier epoch wrote there, 0 if none).  A session's output window slides, so
+    // the bytes of earlier epochs are not in `out` any more; the walker copies every epoch that ends into this image
+    // (shadow_update).  nullptr for batch units (their whole output is in the arena: epoch table).
+    uint8_t *shadow;
     uint8_t *dump;       // 64 bytes per lane-row that predicated-off lanes store to
     uint32_t work_end;   // input position where the unit ends (remaining work = work_end - in_pos)
     uint32_t *prio_slot; // this wave's word in LaunchParams.prio_tab (rank_priority)
@@ -122,6 +127,11 @@ __device__ __forceinline__ uint32_t umod_small(uint32_t i, uint32_t d)
 // the first entry from the top that is long enough holds the byte.  Exact launches only.
 __device__ __forceinline__ uint32_t stale_byte(const uint8_t *__restrict__ out, const Dec &d, uint32_t c, bool want)
 {
+    if (d.shadow) { // sessions: the uncleared window buffer itself
+        const bool ok = want && c < d.dict_size;
+        const uint32_t v = d.shadow[ok ? c : 0u];
+        return ok ? v : 0u;
+    }
     uint32_t b = 0;
     bool found = !want;
     for (uint32_t k = d.n_epochs; k-- > 0;) { // wave-uniform trip count, selects instead of branches
@@ -135,6 +145,21 @@ __device__ __forceinline__ uint32_t stale_byte(const uint8_t *__restrict__ out, 
         found = found || hit;
     }
     return b;
+}
+
+// sessions: the dictionary epoch that ends at a reset goes into the window image.  The byte k positions behind the
+// write position has circular index window.pos - 1 - k (mod size; d.wpos IS the reference's wrapped window.pos, so this
+// holds even when the host has slid the epoch's start out of the buffer); the last min(epoch, dictSize) bytes are always
+// still in `out` (the host keeps dictSize bytes of history).
+__device__ __forceinline__ void shadow_update(Dec &d, const uint8_t *__restrict__ out, uint32_t lane)
+{
+    const uint32_t n = min(d.pos - d.wbase, d.dict_size);
+    for (uint32_t base = 0; base < n; base += kWave) {
+        const uint32_t k = min(base + lane, n - 1); // byte out[pos - 1 - k]
+        int64_t ci = (int64_t)d.wpos - 1 - (int64_t)k; // k < size, wpos < size: one wrap at most
+        if (ci < 0) ci += d.dict_size;
+        d.shadow[ci] = out[d.pos - 1 - k];
+    }
 }
 
 // dictionary reset (window.Reset): the epoch [wbase, pos) ends; remember it for stale reads
@@ -210,7 +235,7 @@ __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ out, Dec &d, uin
     const uint64_t lo = (uint64_t)dist + d.wbase; // virtual index >= wbase  <=>  pos + j >= lo
     const bool wrap = dist <= len;                // some i in [0, len] needs i mod dist
     if ((uint64_t)pos < lo && !(d.wbase == 0 && d.epoch0_clean)) {
-        if (d.epochs) {
+        if (d.epochs || d.shadow) {
             wave_copy_exact(out, d, dist, len, lane);
             return;
         }
@@ -797,7 +822,7 @@ __device__ __forceinline__ void reload_context(Dec &d, const uint8_t *__restrict
         const uint32_t fill = d.pos - d.wbase;
         const bool full = fill >= d.dict_size;
         const bool valid = dist <= d.dict_size; // GetByte with a larger distance indexes out of the reference's buffer
-        if (d.epochs) {
+        if (d.epochs || d.shadow) {
             const uint32_t sb = stale_byte(out, d, fill + d.dict_size - dist, !ok && !full && valid);
             b = (!ok && !full && valid) ? sb : b;
         } else if (d.state >= 7 && __builtin_amdgcn_readlane((int)(uint32_t)(!ok && !full), 1)) {
@@ -836,6 +861,7 @@ struct Walk {
     uint32_t h5;       // header[5] persists across chunks (reader2.go:37,147)
     bool last_unit, have_reader, first_chunk;
     bool more_input;   // UNIT_F_MORE_INPUT: the unit's input is a window of a longer stream
+    bool resumable;    // the unit has a state block (pull reader): it can pause for a larger model
     uint32_t model_lc_lp; // largest lc+lp this unit's model storage was sized for
 };
 
@@ -858,6 +884,7 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
         if (in_pos(d) == w.unit_end) // ReadByte fails (reader2.go:103-110)
             return w.last_unit ? ST_ERR_UNEXPECTED_EOF : ST_OK;
         if (d.arel > kInWindow - kFastInput) in_window(d, in_pos(d), lane);
+        const uint32_t chunk_start = in_pos(d);
         uint32_t c, h1 = 0, h2 = 0, h3 = 0, h4 = 0;
         IN_BYTE(c);
         // decodeChunkType (reader2.go:175-199): 0x03..0x7F fall through to end-of-stream
@@ -880,7 +907,20 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
             if (hl == 6) IN_BYTE(w.h5);
         }
         uint32_t unc = (h1 << 8) | h2; // :130
+        if (!stored && w.resumable && (!w.have_reader || sub >= 6) && w.h5 < 225) {
+            // pull readers: the chunk brings properties whose model is larger than the unit's state block (the host
+            // sized it by the headers it had seen when the session was opened; reader2.go:159-165 accepts any lc <= 8,
+            // lp <= 4 at any chunk).  Nothing of this chunk has had an effect yet: step back in front of it and pause --
+            // the host gives the unit a larger block (and the HBM-model launch beyond lc+lp = 8) and resumes.
+            const uint32_t need = w.h5 % 9 + (w.h5 / 9) % 5;
+            if (need > w.model_lc_lp || need > max_lc_lp) {
+                in_window(d, chunk_start, lane);
+                aux = (aux & ~AUX_GROW_MASK) | AUX_GROW | (need << AUX_GROW_SHIFT);
+                return ST_PAUSED;
+            }
+        }
         if (c == 1 || sub == 7) {      // dictionary reset: window.Reset (:132-134, window.go:135-140)
+            if (d.shadow && d.pos > d.wbase) shadow_update(d, out, lane);
             if (!epoch_push(d)) return ST_ERR_UNSUPPORTED; // more visible epochs than the table holds
             d.wbase = d.pos;
             d.wpos = 0;
@@ -938,8 +978,11 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
 enum : uint32_t {
     SV_RANGE, SV_CODE, SV_STATE, SV_REP0, SV_REP1, SV_REP2, SV_REP3, SV_LC, SV_LP_MASK, SV_POS_MASK, SV_SIZE_DEFINED,
     SV_BYTES_LEFT_LO, SV_BYTES_LEFT_HI, SV_POS, SV_WBASE, SV_WPOS, SV_PREV, SV_MATCH, SV_STALE, SV_CONSUMED, SV_CHUNK_END,
-    SV_LC_LP, SV_H5, SV_HAVE_READER, SV_FIRST_CHUNK, SV_PHASE, SV_AUX, SV_COUNT
+    SV_LC_LP, SV_H5, SV_HAVE_READER, SV_FIRST_CHUNK, SV_PHASE, SV_AUX,
+    SV_SHADOW_LO = 32, SV_SHADOW_HI = 33, // written by the HOST when the session is opened (xlz_format.h: kStateShadowWord)
+    SV_COUNT
 };
+static_assert(SV_AUX < SV_SHADOW_LO && SV_SHADOW_LO == kStateShadowWord, "state header layout");
 static_assert(SV_COUNT <= kStateWords, "UnitState header too small");
 
 enum : uint32_t { PH_NEXT = 0, PH_CHUNK = 1 }; // between chunks (or not started) / inside lzma_run of a chunk
@@ -1024,6 +1067,9 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
         w.last_unit = (flags & UNIT_F_LAST) != 0;
         w.more_input = lzma2 && (flags & UNIT_F_MORE_INPUT);
         w.model_lc_lp = st ? lc + lp : 0xFFu; // only a saved state block is sized per unit (LDS: per launch)
+        w.resumable = st != nullptr;
+        d.shadow = (st && lzma2) ? reinterpret_cast<uint8_t *>(rfl64(*reinterpret_cast<const uint64_t *>(st + SV_SHADOW_LO)))
+                                 : nullptr;
 
         uint32_t phase = PH_NEXT;
         uint32_t aux = 0;
@@ -1055,7 +1101,7 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
             w.have_reader = RFL(st[SV_HAVE_READER]) != 0;
             w.first_chunk = RFL(st[SV_FIRST_CHUNK]) != 0;
             phase = RFL(st[SV_PHASE]);
-            aux = RFL(st[SV_AUX]);
+            aux = RFL(st[SV_AUX]) & ~(AUX_GROW | AUX_GROW_MASK); // (a request for a larger model is answered by now)
             // input: continue at the saved position inside the (possibly moved) input window
             // ((*Reader1).Reopen: the input is a new stream, read from its first byte)
             const uint32_t consumed = (flags & UNIT_F_REOPEN) ? d.in_base : RFL(st[SV_CONSUMED]);
@@ -1213,8 +1259,8 @@ static uint32_t decode_per_cu(uint32_t max_lc_lp, uint32_t n_units, int num_cus)
 #else
     if (per_cu > 4 * XLZ_WAVES_PER_EU) per_cu = 4 * XLZ_WAVES_PER_EU; // what the register allocation lets be resident
     if (per_cu > 16 && n_units < 4u * per_cu * (uint32_t)num_cus) per_cu = 16;
-#endif
     if (per_cu > 4) per_cu &= ~3u; // equal load on the four SIMDs
+#endif
     return per_cu;
 }
 

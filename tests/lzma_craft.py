@@ -297,13 +297,18 @@ def lzma2_lzma_chunk(control, unc_size, payload, props=None):
 
 
 # ---- random LZMA2 streams with every kind of chunk and reset (differential fuzzing) --------------
-def random_lzma2_stream(rnd, dict_size=4096, max_chunks=8, max_packets=120):
+SMALL_PROPS = [(3, 0, 2), (0, 0, 0), (1, 1, 1), (0, 2, 0), (4, 0, 0)]
+# what reader2.go:159-165 accepts beyond the LZMA2 format's lc+lp <= 4: any lc <= 8, lp <= 4 (models up to 0x300 << 12)
+ANY_PROPS = SMALL_PROPS + [(4, 3, 1), (8, 0, 0), (5, 1, 3), (8, 4, 2), (6, 4, 0), (3, 4, 4)]
+
+
+def random_lzma2_stream(rnd, dict_size=4096, max_chunks=8, max_packets=120, props=SMALL_PROPS):
     """A structurally valid LZMA2 stream made of random packets, cut into chunks with random control
     bytes: stored chunks with and without dictionary reset, LZMA chunks that reset nothing / the
     state / state + properties / everything.  Rep matches are free to reach behind a dictionary
     reset (the bytes the reference's uncleared window still holds there).  -> (bytes, expected output
-    by the crafter's own window model)."""
-    lc, lp, pb = rnd.choice([(3, 0, 2), (0, 0, 0), (1, 1, 1), (0, 2, 0), (4, 0, 0)])
+    by the crafter's own window model).  props: the (lc, lp, pb) sets chunks choose from."""
+    lc, lp, pb = rnd.choice(props)
     w = Window(dict_size)
     e = None
     out = bytearray()
@@ -324,7 +329,7 @@ def random_lzma2_stream(rnd, dict_size=4096, max_chunks=8, max_packets=120):
         else:
             control = rnd.choice([0x80, 0x80, 0x80, 0xA0, 0xC0, 0xE0])
         if control >= 0xC0:
-            lc, lp, pb = rnd.choice([(3, 0, 2), (0, 0, 0), (1, 1, 1), (0, 2, 0), (4, 0, 0)])
+            lc, lp, pb = rnd.choice(props)
         if control == 0xE0:
             w.reset()
         if e is None:
@@ -358,3 +363,61 @@ def random_lzma2_stream(rnd, dict_size=4096, max_chunks=8, max_packets=120):
         out += lzma2_lzma_chunk(control, len(w.total) - start, pay, props_byte(lc, lp, pb))
     out += b"\x00"
     return bytes(out), bytes(w.total)
+
+
+def long_stale_lzma2_stream(dict_size, first_epoch=2_600_000, seed=1):
+    """An LZMA2 stream whose FIRST dictionary epoch is megabytes long (cheap to write: a few thousand literals, then
+    maximum-length matches), followed by stored chunks that reset the dictionary and 0x80 chunks whose rep matches, short
+    reps and matched literals read far behind the reset -- window bytes of an epoch that a pull reader's sliding output
+    window has long dropped (window.go:135-140 keeps them in the reference's buffer).  -> (bytes, expected output)"""
+    import random
+    rnd = random.Random(seed)
+    w = Window(dict_size)
+    e = Encoder(3, 0, 2, dict_size, window=w)
+    blob = b""
+    control = 0xE0
+    start = 0
+
+    def flush():
+        nonlocal blob, control, start
+        blob += lzma2_lzma_chunk(control, len(w.total) - start, e.payload(), props_byte(3, 0, 2))
+        control = 0x80
+        start = len(w.total)
+        e.new_chunk()
+    for i in range(3000):
+        e.literal(rnd.randrange(97, 123))
+    while len(w.total) < first_epoch:
+        fill = min(len(w.total), dict_size)
+        e.match(rnd.choice([1, 3, 7, 200, 2999, fill - 1, fill // 2, fill]), 273)
+        if rnd.random() < 0.05:
+            e.literal(rnd.randrange(256))
+        if len(w.total) - start > 900_000:
+            flush()
+    full = min(len(w.total), dict_size)
+    e.match(full - 1, 5)      # four distinct reps for the chunks behind the reset
+    e.match(77, 4)
+    e.match(full // 2, 6)
+    e.match(1500, 3)
+    flush()
+    for rounds in range(3):
+        w.reset()
+        data = bytes(rnd.randrange(65, 91) for _ in range(rnd.choice([2, 5, 40])))
+        for b in data:
+            w.put(b)
+        blob += lzma2_stored(data, dict_reset=True)
+        start = len(w.total)
+        e.literal(0x41)           # a matched literal whose matchByte lies behind the reset
+        e.rep(0, 8)
+        e.literal(0x42)
+        e.rep(2, 30)
+        e.short_rep()
+        e.rep(3, 273)
+        e.rep(1, 2)
+        e.match(3, 4)
+        e.rep(1, 100)
+        for _ in range(40):       # a longer epoch every other round: what the NEXT round reads is then a mix of two epochs
+            e.match(rnd.choice([1, 2, 5]), rnd.choice([20, 273]))
+            if rounds != 1:
+                break
+        flush()
+    return blob + b"\x00", bytes(w.total)

@@ -260,6 +260,35 @@ def test_random_crafted_lzma2_streams_cpu():
         assert got[1] == 0 and got[0] == want, seed
 
 
+def test_long_first_epoch_and_large_model_streams_cpu():
+    """the generators behind the session tests (tests/test_gpu_readers.py): a stream whose first dictionary epoch is
+    megabytes long with reads behind later resets, and random LZMA2 streams whose chunks renew the model with lc+lp up
+    to 12 -- crafter's window model = oracle (= the third restatement on a short one)"""
+    import lzma_pydec
+    from lzma_craft import ANY_PROPS, long_stale_lzma2_stream, random_lzma2_stream
+    for ds in (4096, 65536):
+        blob, want = long_stale_lzma2_stream(ds, first_epoch=300_000, seed=ds)
+        assert oracle.lzma2_raw(blob, ds, len(want) + 100) == (want, 0, len(blob))
+    blob, want = long_stale_lzma2_stream(4096, first_epoch=30_000)
+    assert lzma_pydec.lzma2_raw(blob, 4096)[:2] == (want, 0)
+    seen = set()
+    for seed in range(7000, 7060):
+        rnd = random.Random(seed)
+        ds = rnd.choice([4096, 4097, 65536])
+        blob, want = random_lzma2_stream(rnd, ds, max_chunks=10, props=ANY_PROPS)
+        assert oracle.lzma2_raw(blob, ds, len(want) + 100) == (want, 0, len(blob)), seed
+        pos = 0
+        while blob[pos] != 0:           # the properties the chunks bring
+            c = blob[pos]
+            if c >= 0x80:
+                if c >= 0xC0:
+                    seen.add((blob[pos + 5] % 9) + (blob[pos + 5] // 9) % 5)
+                pos += (6 if c >= 0xC0 else 5) + ((blob[pos + 3] << 8) | blob[pos + 4]) + 1
+            else:
+                pos += 3 + ((blob[pos + 1] << 8) | blob[pos + 2]) + 1
+    assert max(seen) == 12 and {5, 6, 7, 8}.intersection(seen) and min(seen) <= 4
+
+
 @pytest.mark.gpu
 def test_random_crafted_lzma2_streams_gpu(ctx):
     import lzma_amd

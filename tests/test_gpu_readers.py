@@ -176,6 +176,19 @@ def test_reader1_reset_and_reopen(ctx):
         assert e2 is None and out_b == want[0][n_a:]
         assert r.Reopen(b"", 5) is lzma_amd.io_EOF                       # rangeDec.Reopen -> Init: io.EOF, unwrapped
         assert r.Reopen(b"\x01\0\0\0\0", 5).status == lzma_amd.ERR_RESULT  # first byte != 0: ErrResultError
+        # the same with B pulled from a source a few bytes at a time ((*Reader1).Reopen takes an io.ByteReader,
+        # reader1.go:166-176): the first stream was given whole, the second is fed
+        import io
+        r, err = lzma_amd.NewLZMADecompressorForSevenZip(ctx, bytes([props_byte(3, 0, 2)]) + struct.pack("<I", ds), n_a,
+                                                         [pay_a])
+        r.__class__ = lzma_amd.Reader1
+        out_a, e1 = r.read_all(chunk=5000)
+        assert e1 is None and out_a == want[0][:n_a]
+        if with_reset:
+            r.Reset()
+        assert r.Reopen(io.BytesIO(pay_b), n_b, piece=37) is None
+        out_b, e2 = r.read_all(chunk=1000)
+        assert e2 is None and out_b == want[0][n_a:]
 
 
 def test_reopen_after_input_that_ended_inside_a_packet(ctx):
@@ -334,23 +347,90 @@ def test_streaming_input_edge_cases(ctx):
     assert e is None and out == p
 
 
-def test_fed_reader_with_a_model_beyond_lds_is_not_truncated(ctx):
-    """lc+lp > 8 does not fit a CU's LDS, the session refuses it and the reader takes the
-    whole-stream path -- which, on a reader whose input is FED, once ran on the pieces fed so far and ended the stream
-    early without an error.  Now the reader asks for the rest of the input first."""
+def test_fed_reader_with_a_model_beyond_lds_is_a_session_too(ctx):
+    """lc+lp > 8 does not fit a CU's LDS.  Round 2 sent such a reader to the whole-stream path -- which, on a reader
+    whose input is FED, ran on the pieces fed so far and ended the stream early without an error.  Now the
+    unit runs in the HBM-model launch with its state saved and restored like any other: no whole-stream decode, fed or
+    not.  (liblzma refuses to ENCODE lc+lp > 4: ordinary payloads relabelled with a large-model props byte decode to
+    deterministic garbage that must equal the oracle's.)"""
     import io
-    p = corpus.plain("T", 6700, 900_000)
-    blob = corpus.compress_alone(p, dict_size=1 << 16, lc=8, lp=2, pb=0, preset=0)
-    assert len(blob) > 100_000
-    for piece in (4096, 70_000):
-        r, err = lzma_amd.NewReader1(ctx, io.BytesIO(blob), piece=piece)
-        assert err is None
-        out, e = r.read_all(chunk=50_000)
-        assert e is None and out == p, piece
-        assert r.stats()[1] == 1            # ONE whole-stream decode, after the end of the input was declared
-    r, err = lzma_amd.NewReader1(ctx, io.BytesIO(blob[:len(blob) // 2]), piece=4096)   # a truncated source: clean EOF (parity note 4)
-    out, e = r.read_all(chunk=50_000)
-    assert e is None and 0 < len(out) < len(p) and out == p[:len(out)]
+    import struct
+    import oracle
+    for k, (lc, lp, pb) in enumerate([(8, 2, 0), (8, 4, 2), (5, 4, 1)]):
+        p = corpus.plain("TRM"[k], 6700 + k, 2_500_000)
+        c = bytearray(corpus.compress_alone(p, dict_size=1 << 16, preset=0))
+        c[0] = corpus.props_byte(lc, lp, pb)
+        c[5:13] = struct.pack("<Q", 3_000_000 + k)       # a defined size: the garbage decode may run long
+        c = bytes(c)
+        want = oracle.lzma1_alone(c, 3_100_000)
+        assert len(want[0]) > 1_200_000                   # more than one refill: the model is saved and restored
+        for piece in (None, 4096, 70_000):
+            r, err = lzma_amd.NewReader1(ctx, c if piece is None else io.BytesIO(c), piece or (1 << 20))
+            assert err is None
+            out, e = r.read_all(chunk=50_000)
+            assert out == want[0] and (e is None) == (want[1] >= 0), (lc, lp, pb, piece)
+            assert r.stats()[1] == 0
+
+
+def test_readers_read_behind_dictionary_resets_from_the_window_image(ctx):
+    """window.Reset keeps the buffer (window.go:135-140): a rep match behind an LZMA2 dictionary reset reads what an
+    EARLIER epoch left at that circular index.  A session's output window slides, so those bytes are long gone from it
+    when the first epoch is megabytes long; the wave keeps the reference's buffer image instead (shadow window).  Whole
+    input and fed input, against the crafter's own window model and the oracle; no whole-stream fallback any more."""
+    import io
+    import oracle
+    from lzma_craft import long_stale_lzma2_stream
+    for ds in (4096, 65536, 5000):
+        blob, want = long_stale_lzma2_stream(ds, seed=ds)
+        assert oracle.lzma2_raw(blob, ds, len(want) + 100) == (want, 0, len(blob))
+        for piece in (None, 1000, 70_000):
+            r, err = lzma_amd.NewReader2(ctx, blob if piece is None else io.BytesIO(blob), ds, piece or (1 << 20))
+            assert err is None
+            out, e = r.read_all(chunk=100_000)
+            assert e is None and out == want, (ds, piece)
+            assert r.stats()[1] == 0
+    # the small crafted streams of tests/test_crafted_streams.py (unwritten / short / wrapped previous epoch), fed
+    from test_crafted_streams import crafted_lzma2
+    for name, b, ds, cap, want in crafted_lzma2():
+        for piece in (None, 64, 700):
+            r, err = lzma_amd.NewReader2(ctx, b if piece is None else io.BytesIO(b), ds, piece or (1 << 20))
+            out, e = r.read_all(chunk=999)
+            assert e is None and out == want and r.stats()[1] == 0, (name, piece)
+
+
+def test_a_reader_grows_its_model_when_a_later_chunk_brings_larger_properties(ctx):
+    """reader2.go:155-165 renews the model with whatever lc <= 8, lp <= 4 a chunk header brings.  A session's state block
+    is sized by the headers the host had seen when it was opened; the wave pauses IN FRONT of a chunk that needs more,
+    the host moves the unit to a larger block (beyond lc+lp = 8: to the HBM-model launch) and resumes.  Fed readers
+    see only the first piece when they open: this is their only way to such a chunk."""
+    import io
+    import random
+    import oracle
+    from lzma_craft import ANY_PROPS, random_lzma2_stream
+    n_big = 0
+    for seed in range(7000, 7060):
+        rnd = random.Random(seed)
+        ds = rnd.choice([4096, 4097, 65536])
+        blob, want = random_lzma2_stream(rnd, ds, max_chunks=10, props=ANY_PROPS)
+        ow = oracle.lzma2_raw(blob, ds, len(want) + 100)
+        assert ow[0] == want and ow[1] == 0, seed
+        for piece in (None, 200):
+            r, err = lzma_amd.NewReader2(ctx, blob if piece is None else io.BytesIO(blob), ds, piece or (1 << 20))
+            assert err is None, seed
+            out, e = r.read_all(chunk=3000)
+            assert e is None and out == want, (seed, piece)
+            assert r.stats()[1] == 0
+        n_big += 1
+    assert n_big == 60
+    # the same streams in ONE batch call (models in LDS and in HBM side by side)
+    streams, wants = [], []
+    for seed in range(7000, 7060):
+        rnd = random.Random(seed)
+        ds = rnd.choice([4096, 4097, 65536])
+        blob, want = random_lzma2_stream(rnd, ds, max_chunks=10, props=ANY_PROPS)
+        streams.append(lzma_amd.Stream(blob, lzma_amd.FMT_LZMA2_RAW, out_cap=len(want) + 7, dict_size=ds))
+        wants.append((want, 0, len(blob)))
+    assert lzma_amd.decode_batch(ctx, streams) == wants
 
 
 def test_known_size_streams_refilled_more_than_once(ctx):

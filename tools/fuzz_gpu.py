@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import corpus, lzma_amd, oracle
 from lzma_amd import Stream, FMT_LZMA_ALONE, FMT_LZMA2_RAW
-from lzma_craft import random_lzma2_stream  # packet-level crafter: LZMA2 streams with every chunk / reset kind
+from lzma_craft import ANY_PROPS, SMALL_PROPS, random_lzma2_stream  # packet-level crafter: LZMA2 streams with every chunk / reset kind
 
 def damage(rng, c):
     c = bytearray(c)
@@ -75,7 +75,7 @@ def fuzz(ctx, budget, seed, per_round=160, verbose=True):
       for _ in range(per_round // 6):
           r2 = random.Random(int(rng.integers(1, 1 << 62)))
           d2 = r2.choice([4096, 4097, 8192, 65536])
-          c, expect = random_lzma2_stream(r2, d2)
+          c, expect = random_lzma2_stream(r2, d2, props=ANY_PROPS if r2.random() < 0.3 else SMALL_PROPS)
           cap = len(expect) + int(rng.choice([0, 0, 7, -1])) if len(expect) > 1 else len(expect)
           if rng.random() < 0.2 and len(c) > 8:
               c = bytearray(c)

@@ -22,7 +22,7 @@ import numpy as np
 import corpus
 import lzma_amd
 import oracle
-from lzma_craft import random_lzma2_stream
+from lzma_craft import ANY_PROPS, SMALL_PROPS, long_stale_lzma2_stream, random_lzma2_stream
 
 CAP = 6 << 20  # the oracle needs an output bound; streams that would decode to more are skipped
 
@@ -68,7 +68,10 @@ def one_stream(rng):
         return 2, c, d2
     r2 = random.Random(int(rng.integers(1, 1 << 62)))
     d2 = r2.choice([4096, 4097, 8192, 65536])
-    c, _ = random_lzma2_stream(r2, d2)
+    if r2.random() < 0.04:  # a first dictionary epoch far longer than a session's sliding window, read behind later resets
+        c, _ = long_stale_lzma2_stream(d2, first_epoch=r2.choice([200_000, 1_200_000, 2_300_000]), seed=r2.randrange(1 << 30))
+    else:  # half of them renew the model with properties beyond lc+lp = 4 (reader2.go:159-165 takes any lc <= 8, lp <= 4)
+        c, _ = random_lzma2_stream(r2, d2, props=ANY_PROPS if r2.random() < 0.5 else SMALL_PROPS)
     if rng.random() < 0.3 and len(c) > 8:
         c = bytearray(c)
         c[int(rng.integers(0, len(c)))] ^= 1 << int(rng.integers(0, 8))
@@ -224,16 +227,9 @@ def fuzz(ctx, budget, seed, verbose=True):
                     break
                 assert got <= CAP + (1 << 20), "reader runs past the oracle's output"
             out = b"".join(out)
-            if streaming and isinstance(e, lzma_amd.LzmaError) and e.status == lzma_amd.ERR_UNSUPPORTED:
-                # documented limit of FED input (include/xlz.h): a stream that reads across an LZMA2 dictionary
-                # reset, or whose later chunks need a model beyond lc+lp = 4, has no whole stream to fall back to.
-                # Legitimate only if the same stream, given whole, needs exactly that fallback -- and is right then.
-                r2, _ = lzma_amd.NewReader2(ctx, c, ds) if fmt == 2 else lzma_amd.NewReader1(ctx, c)
-                out2, e2 = r2.read_all(chunk=65536)
-                if r2.stats()[1] == 0:
-                    fail = "XLZ_ERR_UNSUPPORTED from the fed reader, but the whole-input reader needed no fallback"
-                out, e = out2, (e2 if e2 is not None else lzma_amd.io_EOF)
-                n_unsup[0] += 1
+            # (round 2 exempted fed readers that ended in XLZ_ERR_UNSUPPORTED -- reads behind a dictionary reset, models
+            #  beyond lc+lp = 4 -- as a documented limit.  The limit is gone: sessions keep the window image and grow
+            #  their model, so a fed reader must equal the oracle like any other.)
             if fail:
                 pass
             elif out != want[0]:
@@ -253,8 +249,8 @@ def fuzz(ctx, budget, seed, verbose=True):
             print("MISMATCH %s: %s -> %s" % (what, fail, fn), flush=True)
             raise AssertionError("reader and oracle differ (%s), input saved as %s" % (fail, fn))
         if verbose and n_total % 50 == 0:
-            print("%d readers ok so far (%d ending in an error, %d skipped, %d fed readers at the documented limit, "
-                  "%d Reopen cases, %d concurrent)" % (n_total, n_err, n_skipped, n_unsup[0], n_reopen, n_conc), flush=True)
+            print("%d readers ok so far (%d ending in an error, %d skipped, %d Reopen cases, %d concurrent)"
+                  % (n_total, n_err, n_skipped, n_reopen, n_conc), flush=True)
     if bctx is not None:
         bctx.close()
     return n_total, n_err
