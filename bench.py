@@ -78,7 +78,7 @@ CONFIGS = {
 }
 HEADLINES = ["cfg3", "cfg3-heavy"]
 SIDE = ["cfg2-T", "cfg2-T-p6", "cfg2-R", "cfg4", "cfg5", "cfg5-wrap"]
-EXTRAS = ["h2h", "sweep", "xz"]
+EXTRAS = ["h2h", "sweep", "xz", "lone"]   # lone: the 64-unit launches behind roofline.issue.latency_bound
 SWEEP_COUNTS = [64, 256, 1024]  # (4096 is cfg2-T itself)
 
 
@@ -242,9 +242,9 @@ def library():
 
 
 def kernel_rev():
-    """Identity of the kernel the numbers belong to: the source hash compiled into the loaded library (profiles are
-    tied to it)."""
-    return library()["build_id"]
+    """Identity of the kernel the numbers belong to: the hash of the device code's sources compiled into the loaded
+    library (profiles are tied to it; host-side changes do not change it)."""
+    return library()["kernel_id"]
 
 
 def profile_for(name):
@@ -447,6 +447,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=12.0)
     ap.add_argument("--side-cpu-target-s", type=float, default=4.0)
+    ap.add_argument("--corpus-cache", default="", help="dev (profiling passes): keep generated corpora in this directory and reuse them")
     ap.add_argument("--allow-xlz-so", action="store_true", help="dev: accept a library swapped in with XLZ_SO (recorded in the line)")
     args = ap.parse_args()
     if os.environ.get("XLZ_SO") and not args.allow_xlz_so:
@@ -486,13 +487,21 @@ def main():
         for name in names:
             spec = specs[name]
             t0 = time.time()
-            if name == head:
+            cache = os.path.join(args.corpus_cache, "xlz_corpus_%s_%g_%d_%d.pkl" % (name, args.scale, world, rank)) if args.corpus_cache else ""
+            if cache and os.path.exists(cache):
+                import pickle
+                comp, dig = pickle.load(open(cache, "rb"))
+            elif name == head:
                 # strong scaling: ONE batch (seed 1), this rank's shard of it (N = 1: all of it)
                 weights = [out_size_of(spec)] * spec["streams"]
                 shard = multigpu.partition_by_weight(weights, world)[rank]
                 comp, dig = make_corpus(pool, spec, 1, shard)
             else:
                 comp, dig = make_corpus(pool, spec, 1)
+            if cache and not os.path.exists(cache):
+                import pickle
+                os.makedirs(args.corpus_cache, exist_ok=True)
+                pickle.dump((comp, dig), open(cache, "wb"), protocol=4)
             corp[name] = (comp, dig)
             log("[rank %d] corpus %s: %d streams x %d B, ratio %.3f, generated in %.1f s with %d workers"
                 % (rank, name, len(comp), out_size_of(spec), sum(map(len, comp)) / (len(comp) * out_size_of(spec)),
@@ -567,7 +576,7 @@ def main():
             t0_, t1_, il_ = batch.unit_trace()
             np.savez_compressed(args.trace_out + name + ".npz", t_start=t0_, t_end=t1_, in_len=il_)
         batch.close()
-        lone = lone_leg(name) if with_lone and spec["streams"] * spec.get("segments", 1) > 64 else None
+        lone = lone_leg(name) if with_lone and "lone" in extras and spec["streams"] * spec.get("segments", 1) > 64 else None
         return t_local, kernel_ms, cin, cout, units, occ, lone
 
     def cpu_leg(name, target_s):
@@ -747,7 +756,7 @@ def main():
                        "streams_total": total_streams, "streams_largest_shard": int(n_max),
                        "bytes_per_stream": out_size_of(spec), "compression_ratio": round(sums[1] / sums[2], 4), "bit_exact": "all",
                        "parallelism": "one batch sharded by stream x%d (partition_by_weight), no collective" % world,
-                       "corpus_generation_s": round(gen_s, 1), "kernel_rev": lib_info["build_id"], "library": lib_info},
+                       "corpus_generation_s": round(gen_s, 1), "kernel_rev": lib_info["kernel_id"], "library": lib_info},
             "roofline": head_res["roofline"],
             "cpu_baseline": cpu_head,
         }

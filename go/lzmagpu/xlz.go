@@ -183,19 +183,25 @@ func (r *Reader1) Reset() {
 	runtime.KeepAlive(r)
 }
 
-// Reopen is (*Reader1).Reopen (reader1.go:166-176): a new raw stream on the same window and model
-// (taken whole: xlz_reader_reopen has no streaming form).
+// Reopen is (*Reader1).Reopen (reader1.go:166-176): a new raw stream on the same window and model.  Like the
+// constructors it takes the FIRST piece of the source now and feeds the rest as the decoder asks for it
+// (xlz_reader_expect_more is accepted right after xlz_reader_reopen): the source is never slurped.
 func (r *Reader1) Reopen(inStream io.ByteReader, unpackSize uint64) error {
-	data, err := slurp(inStream)
+	data, rest, err := firstPiece(asReader(inStream))
 	if err != nil {
 		return err
 	}
 	p, n := cbuf(data)
 	st := C.xlz_reader_reopen(r.h, p, n, C.uint64_t(unpackSize)) // the library copies the bytes
 	runtime.KeepAlive(data)
-	runtime.KeepAlive(r)
+	r.src = nil
 	switch st {
 	case C.XLZ_OK:
+		if rest != nil {
+			C.xlz_reader_expect_more(r.h)
+			r.src = rest
+		}
+		runtime.KeepAlive(r)
 		return nil
 	case C.XLZ_ERR_HEADER_EOF:
 		return io.EOF // rangeDec.Reopen returns Init's error unwrapped (reader1.go:170-173)
@@ -232,25 +238,6 @@ func (rc *readCloser) Close() error {
 		return fmt.Errorf("lzma: error closing: %w", err) // readcloser.go:21-23
 	}
 	return nil
-}
-
-// slurp drains a ByteReader; any error other than io.EOF is the caller's to see (the reference
-// would meet it inside Read).
-func slurp(br io.ByteReader) ([]byte, error) {
-	if r, ok := br.(io.Reader); ok { // bufio.Reader, bytes.Reader, ...
-		return io.ReadAll(r)
-	}
-	var buf []byte
-	for {
-		b, err := br.ReadByte()
-		if err == io.EOF {
-			return buf, nil
-		}
-		if err != nil {
-			return buf, err
-		}
-		buf = append(buf, b)
-	}
 }
 
 func cbuf(b []byte) (*C.uint8_t, C.size_t) {

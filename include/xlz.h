@@ -90,6 +90,7 @@ typedef struct xlz_result {
 const char *xlz_version(void);
 const char *xlz_build_id(void);       /* hash of the sources this binary was compiled from (lzma_amd/build.py);
                                          measurements quote it so that a number names the kernel that ran   */
+const char *xlz_kernel_id(void);      /* the same over the device code's sources only: what rocprof profiles are tied to   */
 const char *xlz_strerror(int status); /* text of the matching reference error (errors.go:5-12)    */
 int xlz_device_count(void);           /* number of HIP devices, 0 if none                         */
 

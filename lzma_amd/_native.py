@@ -36,7 +36,7 @@ UNKNOWN_SIZE = 0xFFFFFFFFFFFFFFFF
 
 # every symbol include/xlz.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "xlz_version", "xlz_build_id", "xlz_strerror", "xlz_device_count", "xlz_decode_prop", "xlz_decode_dict_size",
+    "xlz_version", "xlz_build_id", "xlz_kernel_id", "xlz_strerror", "xlz_device_count", "xlz_decode_prop", "xlz_decode_dict_size",
     "xlz_decode_dict_size2", "xlz_decode_unpack_size", "xlz_ctx_create", "xlz_ctx_destroy",
     "xlz_ctx_device", "xlz_ctx_event_record", "xlz_ctx_event_elapsed_ms", "xlz_ctx_enable_batching",
     "xlz_ctx_batching_stats", "xlz_decode_batch", "xlz_ctx_last_call_stats", "xlz_batch_create", "xlz_batch_run", "xlz_batch_sync",
@@ -130,6 +130,7 @@ def lib():
     vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     L.xlz_version.restype = ctypes.c_char_p
     L.xlz_build_id.restype = ctypes.c_char_p
+    L.xlz_kernel_id.restype = ctypes.c_char_p
     L.xlz_strerror.restype = ctypes.c_char_p
     L.xlz_strerror.argtypes = [i32]
     L.xlz_device_count.restype = i32
@@ -205,5 +206,6 @@ def library_info():
     bid = lib().xlz_build_id().decode()
     tree = build.source_id()
     return {"path": os.path.relpath(SO_PATH, os.path.dirname(_HERE)) if SO_PATH.startswith(os.path.dirname(_HERE)) else SO_PATH,
-            "sha256": sha, "build_id": bid, "tree_source_id": tree, "built_from_tree": bid == tree,
+            "sha256": sha, "build_id": bid, "kernel_id": lib().xlz_kernel_id().decode(), "tree_source_id": tree,
+            "built_from_tree": bid == tree,
             "xlz_so_override": SO_PATH != DEFAULT_SO}

@@ -15,12 +15,16 @@ HEADERS = ["xlz_format.h", "xlz_check.h", "xlz_fastpath.inc", os.path.join("..",
 ARCH = "gfx950"
 
 
-def source_id():
-    """12 hex digits over every source the library is compiled from: compiled into the library (xlz_build_id) so that
-    a bench line or a test can tell WHICH kernel ran, whatever the file's time stamp says"""
+KERNEL_FILES = ["xlz_kernel.hip", "xlz_fastpath.inc", "xlz_format.h"]  # what the device code is made of
+
+
+def source_id(files=None):
+    """12 hex digits over every source the library is compiled from (files=KERNEL_FILES: over the device code only):
+    compiled into the library (xlz_build_id / xlz_kernel_id) so that a bench line or a test can tell WHICH kernel ran,
+    whatever the file's time stamp says; profiles are tied to the kernel id"""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(SOURCES + HEADERS):
+    for f in sorted(files or (SOURCES + HEADERS)):
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:12]
@@ -44,7 +48,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-           "-I", os.path.join(HERE, "..", "include"), '-DXLZ_BUILD_ID="%s"' % source_id()]
+           "-I", os.path.join(HERE, "..", "include"), '-DXLZ_BUILD_ID="%s"' % source_id(), '-DXLZ_KERNEL_ID="%s"' % source_id(KERNEL_FILES)]
     cmd += list(extra_flags)
     cmd += [os.path.join(CSRC, f) for f in SOURCES]
     cmd += ["-o", out or SO]

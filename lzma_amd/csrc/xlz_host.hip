@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -69,6 +70,7 @@ struct HostPipe {
     uint8_t *ring[kRing] = {};
     hipEvent_t ring_ev[kRing] = {};
     hipStream_t copy_stream = nullptr;
+    hipStream_t up_stream = nullptr; // H2D of the pinned input image, piece by piece while the rest is still being packed
 };
 
 struct xlz_ctx {
@@ -136,6 +138,10 @@ extern "C" const char *xlz_version(void) { return "xlz 0.1 (gfx950)"; }
 #define XLZ_BUILD_ID "unknown"
 #endif
 extern "C" const char *xlz_build_id(void) { return XLZ_BUILD_ID; }
+#ifndef XLZ_KERNEL_ID // hash of the device code's sources only (xlz_kernel.hip, xlz_fastpath.inc, xlz_format.h)
+#define XLZ_KERNEL_ID "unknown"
+#endif
+extern "C" const char *xlz_kernel_id(void) { return XLZ_KERNEL_ID; }
 
 extern "C" const char *xlz_strerror(int st)
 {
@@ -603,23 +609,41 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
             hp.pin_in_cap = want;
         }
         uint8_t *stage = hp.pin_in;
+        if (!hp.up_stream && hipStreamCreateWithFlags(&hp.up_stream, hipStreamNonBlocking) != hipSuccess) return fail(XLZ_ERR_DEVICE);
         const unsigned nth = host_threads(b->in_bytes);
+        std::atomic<bool> copy_failed{false};
         auto pack = [&](unsigned t) {
             // units are laid out in arena order: thread t owns a contiguous run of them and the
-            // padding bytes that follow each (zeroed: the decoder's input window may run into them)
+            // padding bytes that follow each (zeroed: the decoder's input window may run into them).
+            // Every ~16 MiB it has packed go to the device at once: the bus works while the packing goes on.
+            (void)hipSetDevice(ctx->device);
             const size_t k0 = nu * t / nth, k1 = nu * (t + 1) / nth;
+            if (k0 >= k1) return;
+            uint64_t sent = b->units[k0].in_off;
+            if (t == 0) sent = 0;
+            auto flush_to = [&](uint64_t end) {
+                if (end > sent && hipMemcpyAsync(b->d_in + sent, stage + sent, (size_t)(end - sent), hipMemcpyHostToDevice,
+                                                 hp.up_stream) != hipSuccess)
+                    copy_failed = true;
+                sent = end;
+            };
             for (size_t k = k0; k < k1; k++) {
                 const Unit &u = b->units[k];
                 memcpy(stage + u.in_off, streams[u.stream].in + unit_src_off[k], u.in_len);
                 const uint64_t end = u.in_off + u.in_len;
                 const uint64_t next = k + 1 < nu ? b->units[k + 1].in_off : b->in_bytes;
                 if (next > end) memset(stage + end, 0, (size_t)(next - end));
+                if (next - sent >= (16u << 20)) flush_to(next);
             }
+            flush_to(k1 < nu ? b->units[k1].in_off : b->in_bytes);
         };
         if (nu && b->units[0].in_off) memset(stage, 0, (size_t)b->units[0].in_off);
-        if (!nu) memset(stage, 0, b->in_bytes);
+        if (!nu) {
+            memset(stage, 0, b->in_bytes);
+            if (hipMemcpyAsync(b->d_in, stage, b->in_bytes, hipMemcpyHostToDevice, hp.up_stream) != hipSuccess) copy_failed = true;
+        }
         run_threads(nth, pack);
-        if (hipMemcpy(b->d_in, stage, b->in_bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+        if (hipStreamSynchronize(hp.up_stream) != hipSuccess || copy_failed) return fail(XLZ_ERR_DEVICE);
     }
     if (nu) {
         if (hipMemcpy(b->d_units, b->units.data(), nu * sizeof(Unit), hipMemcpyHostToDevice) != hipSuccess ||

@@ -1246,20 +1246,24 @@ uint32_t decode_lds_bytes(uint32_t max_lc_lp) { return num_probs(max_lc_lp) * 2u
 
 uint32_t big_model_grid(int num_cus) { return (uint32_t)num_cus; } // one workgroup per CU
 // resident single-wave workgroups per CU of the LDS-model launch
-// The CU's instruction issue saturates at 16 waves; a fifth wave per SIMD adds 3.5 % on launches of many
-// rounds (measured on the cfg3 shape, profiles/r03/ab_occupancy.txt) but stretches every round by a quarter, which a
-// launch of one or two rounds cannot win back (8192 units: 4096 + 4096 becomes 5120 + 3072).  So: 20 per CU from four
-// rounds on, 16 below.
+// How many single-wave workgroups a CU really holds: gfx950 hands out LDS in granules of 1280 bytes (160 KiB / 128), so
+// the 7928-byte model of lc+lp = 3 takes 8960 bytes and EIGHTEEN fit, not the twenty that 163840 / 7928 promises
+// (measured: grids of 18, 19 and 20 per CU run alike, profiles/r03/ab_occupancy.txt), and the register allocation
+// (96 VGPRs) allows five waves per SIMD.  Per-wave speed at 16 waves per CU is already 78 % of a lone wave's
+// (bench.py roofline.issue.latency_bound), so the extra two buy 3.7 % on launches of many rounds and nothing on short
+// ones, where they only stretch every round (8192 units: 4096 + 4096 would become 4608 + 3584): 18 from four rounds
+// on, 16 (four per SIMD) below.
+constexpr uint32_t kLdsGranule = 1280;
 static uint32_t decode_per_cu(uint32_t max_lc_lp, uint32_t n_units, int num_cus)
 {
-    const uint32_t fit = kMaxLdsBytes / decode_lds_bytes(max_lc_lp);
-    uint32_t per_cu = fit;
+    const uint32_t alloc = (decode_lds_bytes(max_lc_lp) + kLdsGranule - 1) / kLdsGranule * kLdsGranule;
+    uint32_t per_cu = kMaxLdsBytes / alloc;
 #ifdef XLZ_PER_CU_MAX // A/B builds
     if (per_cu > XLZ_PER_CU_MAX) per_cu = XLZ_PER_CU_MAX;
 #else
     if (per_cu > 4 * XLZ_WAVES_PER_EU) per_cu = 4 * XLZ_WAVES_PER_EU; // what the register allocation lets be resident
     if (per_cu > 16 && n_units < 4u * per_cu * (uint32_t)num_cus) per_cu = 16;
-    if (per_cu > 4) per_cu &= ~3u; // equal load on the four SIMDs
+    if (per_cu > 4 && per_cu < 16) per_cu &= ~3u; // equal load on the four SIMDs
 #endif
     return per_cu;
 }

@@ -421,3 +421,28 @@ def long_stale_lzma2_stream(dict_size, first_epoch=2_600_000, seed=1):
                 break
         flush()
     return blob + b"\x00", bytes(w.total)
+
+
+def long_lzma1_stream(lc, lp, pb, dict_size=1 << 16, total=1_500_000, seed=1):
+    """A VALID .lzma stream of about `total` bytes for ANY lc <= 8, lp <= 4 (liblzma refuses to encode lc+lp > 4): a few
+    thousand literals, then long matches, rep matches and short reps with a literal here and there -- megabytes of output
+    from a few thousand packets.  -> (bytes with the 13-byte header and the end marker, expected output)"""
+    import random
+    rnd = random.Random(seed)
+    e = Encoder(lc, lp, pb, dict_size)
+    for i in range(2500):
+        e.literal(rnd.randrange(97, 123) if rnd.random() < 0.8 else rnd.randrange(256))
+    while len(e.w.total) < total:
+        fill = min(len(e.w.total), dict_size)
+        r = rnd.random()
+        if r < 0.55:
+            e.match(rnd.choice([1, 2, 9, 333, 2400, fill - 1, fill // 3, fill]), rnd.choice([273, 273, 100, 18]))
+        elif r < 0.7:
+            e.rep(rnd.randrange(4), rnd.choice([273, 64, 2]))
+        elif r < 0.8:
+            e.short_rep()
+        else:
+            e.literal(rnd.randrange(256))
+    want = bytes(e.w.total)
+    e.end_marker()
+    return alone_header(lc, lp, pb, dict_size) + e.payload(), want

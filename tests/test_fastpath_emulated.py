@@ -154,7 +154,8 @@ NEXT = ("slot0", "vprev", "rmov", "nopos", "l7blk", "warel", "vreps")   # round 
                                         (("order1",), ("bralign",) + NEXT), (("litrun",), ("flim",) + NEXT),
                                         (("slot0", "lit8g"), ("cflag",) + NEXT), ((), ("hdpp",)), ((), ("rlhoist", "vperm", "tuc")),
                                         ((), ("slot0",)), ((), ("vprev",)), ((), ("rmov",)), ((), ("nopos",)), ((), ("l7blk",)),
-                                        ((), ("warel",)), ((), ("vreps",)), ((), NEXT)])
+                                        ((), ("warel",)), ((), ("vreps",)), ((), NEXT), (("dbr",), ()), (("dbr",), ("l7blk", "slot0")), (("dbr", "dbrw"), ()),
+                                        (("dbrw",), ("slot0",))])
 def test_generator_switches_still_decode(add, remove):
     """the code paths kept in the generator as measured alternatives (profiles/r02/layout_scan.md)
     are not dead code: each of them decodes a stream correctly on the emulator"""

@@ -354,22 +354,25 @@ def test_fed_reader_with_a_model_beyond_lds_is_a_session_too(ctx):
     not.  (liblzma refuses to ENCODE lc+lp > 4: ordinary payloads relabelled with a large-model props byte decode to
     deterministic garbage that must equal the oracle's.)"""
     import io
-    import struct
     import oracle
+    from lzma_craft import long_lzma1_stream
     for k, (lc, lp, pb) in enumerate([(8, 2, 0), (8, 4, 2), (5, 4, 1)]):
-        p = corpus.plain("TRM"[k], 6700 + k, 2_500_000)
-        c = bytearray(corpus.compress_alone(p, dict_size=1 << 16, preset=0))
-        c[0] = corpus.props_byte(lc, lp, pb)
-        c[5:13] = struct.pack("<Q", 3_000_000 + k)       # a defined size: the garbage decode may run long
-        c = bytes(c)
-        want = oracle.lzma1_alone(c, 3_100_000)
-        assert len(want[0]) > 1_200_000                   # more than one refill: the model is saved and restored
+        c, p = long_lzma1_stream(lc, lp, pb, total=2_300_000 + 1000 * k, seed=6700 + k)   # a VALID stream (packet-level crafter)
+        want = oracle.lzma1_alone(c, len(p) + 100)
+        assert want == (p, 0, len(c))                     # more than two refills: the model is saved and restored
         for piece in (None, 4096, 70_000):
             r, err = lzma_amd.NewReader1(ctx, c if piece is None else io.BytesIO(c), piece or (1 << 20))
             assert err is None
             out, e = r.read_all(chunk=50_000)
-            assert out == want[0] and (e is None) == (want[1] >= 0), (lc, lp, pb, piece)
+            assert out == p and e is None, (lc, lp, pb, piece)
             assert r.stats()[1] == 0
+    # an all-zero payload is a long run of zero literals in every parameter set (Code stays 0): input EOF ends it
+    c = bytes([corpus.props_byte(8, 4, 4)]) + (1 << 16).to_bytes(4, "little") + b"\xff" * 8 + bytes(64_000)
+    want = oracle.lzma1_alone(c, 40 << 20)
+    assert want[1] == lzma_amd.OK_INPUT_EOF and len(want[0]) > (2 << 20)
+    r, err = lzma_amd.NewReader1(ctx, io.BytesIO(c), 1500)
+    out, e = r.read_all(chunk=1 << 20)
+    assert e is None and out == want[0] and r.stats()[1] == 0
 
 
 def test_readers_read_behind_dictionary_resets_from_the_window_image(ctx):
@@ -530,8 +533,8 @@ def test_reader2_decodes_dictionary_reset_units_in_parallel(ctx):
 
 
 def test_readers_on_models_beyond_lds(ctx):
-    """lc+lp > 8 (the reference accepts lc <= 8, lp <= 4): no session (the model does not fit LDS), the reader
-    takes the whole-stream path with its HBM-resident model; bytes and status are the oracle's"""
+    """lc+lp > 8 (the reference accepts lc <= 8, lp <= 4): the model does not fit LDS, the reader's unit runs in the
+    HBM-model launch; bytes and status are the oracle's"""
     import oracle
     p = corpus.plain("T", 6900, 30_000)
     c = bytearray(corpus.compress_alone(p))
@@ -542,4 +545,4 @@ def test_readers_on_models_beyond_lds(ctx):
     out, e = r.read_all(chunk=999)
     assert out == want[0] and ((e is None) == (want[1] >= 0))
     _, whole, _ = r.stats()
-    assert whole == 1
+    assert whole == 0      # (round 2: 1 -- such readers took the whole-stream path; now an HBM-model session)

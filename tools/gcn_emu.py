@@ -289,6 +289,11 @@ class Machine:
         self.ws64(o[0], r)
         self.scc = int(r != 0)
 
+    def i_s_lshl1_add_u32(self, o, m):
+        r = (self.rs(o[1]) << 1) + self.rs(o[2])
+        self.scc = int(r > M32)
+        self.s[o[0][1]] = r & M32
+
     def i_s_lshl2_add_u32(self, o, m):
         r = (self.rs(o[1]) << 2) + self.rs(o[2])
         self.scc = int(r > M32)

@@ -176,6 +176,31 @@ def decide(scalar_bound=False, rin="%[range]"):
     """.replace("RIN", rin))
 
 
+def decide_branchy(k, rin="%[range]"):
+    """dbr: one decision against bound s80 that BRANCHES on the outcome (VCC is wave-uniform: s_cbranch_vccz) instead of
+    selecting, tree slot included: each outcome writes the range and the slot with two scalar instructions of its own --
+    no s_cmp_lg vcc, no s_cselect, no s_sub in front of the outcome: two scalar-port instructions less per decision; the
+    bit-1 outcome lies out of line.  Branches do not issue on the scalar port, which is what binds literal-heavy
+    data.  VCC = (code < bound) stays valid behind it (l7blk)."""
+    uid[0] += 1
+    one, join = "d%d" % uid[0], "d%dj" % uid[0]
+    first = "slot0" in VARIANT and k == 0
+    emit("""
+    v_cmp_gt_u32 vcc, s80, v29
+    s_cbranch_vccz ONE
+    s_mov_b32 %[range], s80
+    """.replace("ONE", L(one)))
+    emit("s_mov_b32 s88, 3" if first else "s_lshl1_add_u32 s88, s88, 1")
+    label(join)
+
+    def out_of_line(one=one, join=join, first=first, rin=rin):
+        label(one)
+        emit("v_subrev_u32 v29, s80, v29\ns_sub_u32 %%[range], %s, s80" % rin)
+        emit("s_mov_b32 s88, 2" if first else "s_lshl_b32 s88, s88, 1")
+        emit("s_branch %s" % L(join))
+    deferred.append(out_of_line)
+
+
 def nchk(prefix=None, pick=None, mid=None, late_test=False, rreg=None):
     """normalisation test; the stub is emitted out of line at the end of the block.
     prefix / pick: functions that emit the first instructions of the NEXT decision -- the
@@ -394,8 +419,11 @@ def walk(nbits, blocks, early_exit=None, filler="s_nop 0"):
     emit(filler)
     emit("v_readlane_b32 s80, v55, 1\n" + slot_init())
     for k in range(nbits):
-        decide()
-        slot_step(k)  # J = 2J + SCC = 2J + !bit
+        if "dbrw" in VARIANT:
+            decide_branchy(k)
+        else:
+            decide()
+            slot_step(k)  # J = 2J + SCC = 2J + !bit
         if k + 1 < nbits:
             nchk(prefix=lambda: level_prefix(k + 1, blocks), pick=lambda: level_pick(k + 1))
             if early_exit:
@@ -473,6 +501,10 @@ def slot_init():
 
 def level_rec(k=None, rin="%[range]"):
     """decision of a recorded level on the probability in s86 (parked in lane k of v54)"""
+    if "dbr" in VARIANT and lgather():
+        emit("s_lshr_b32 s80, %s, 11\ns_mul_i32 s80, s80, s86" % rin)
+        decide_branchy(k, rin)
+        return
     emit("s_lshr_b32 s80, %s, 11\ns_mul_i32 s80, s80, s86" % rin)
     if k is not None and not lgather():
         emit("v_writelane_b32 v54, s86, %d" % k)
