@@ -126,7 +126,12 @@ int xlz_ctx_batching_stats(xlz_ctx *ctx, uint64_t *batches, uint64_t *streams);
  * value is XLZ_OK unless the call itself could not run; per-stream outcomes are in
  * results[i].  Thread-safe across contexts; calls on one context are serialised.
  * A call of several wave rounds (>= 8192 streams and >= 2 GiB of output) is cut into up
- * to eight sub-batches whose upload, decode and download overlap.                    */
+ * to eight sub-batches whose upload, decode and download overlap.
+ * BREAK-EVEN: one wave decodes one unit (a stream; an LZMA2 dictionary-reset unit) at
+ * 4-6 MB/s and the chip holds 4096 of them, so a call with few units is slower than the
+ * host's own cores: measured on 1 MiB text streams, 64 units 0.34 GiB/s (16 host cores:
+ * 1.26), 256 units 1.35 (1.23), 1024 units 5.1, 4096 units 16.9.  Below about 250 units
+ * per 16 host cores decode on the CPU, or gather more streams first.   */
 int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_result *results);
 
 /* What the most recent successful xlz_decode_batch on `ctx` spent where, and how well it filled the GPU.
@@ -278,6 +283,9 @@ int xlz_xz_decode(xlz_ctx *ctx, const uint8_t *file, size_t len, uint8_t *out, s
                   uint64_t *out_len, int verify, size_t *unverified);
 
 /* ---- .7z container front-end ----------------------------
+ * (The parser was written from 7-Zip's published format description and has only been exercised
+ * on archives built from that description by tests/sevenzip_craft.py and on their mutations:
+ * the build image has no 7-Zip to write or cross-check real archives with.)
  * Outside the reference, which only offers the two bodgit/sevenzip decompressor constructors
  * (reader1.go:28-61 method 03 01 01, reader2.go:45-75 method 21).  A .7z archive keeps its data in
  * folders, each ONE compressed stream with out-of-band properties -- exactly what those

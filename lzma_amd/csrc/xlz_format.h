@@ -29,7 +29,12 @@ constexpr uint32_t LEN_HIGH = 4 + 256;
 constexpr uint32_t LEN_CODER_SIZE = 4 + 256 + 256; // 516
 constexpr uint32_t P_LEN = 820;
 constexpr uint32_t P_REP_LEN = P_LEN + LEN_CODER_SIZE; // 1336
-constexpr uint32_t P_LIT = P_REP_LEN + LEN_CODER_SIZE; // 1852
+// The rep-length coder's HIGH tree (256 probs: rep matches of 18 bytes and more, rare) is not in LDS: it is the first
+// kRepHigh entries of the model's HBM part (in front of the matched-literal tables).  Without it the model of
+// lc+lp = 3 is 7416 bytes = SIX of gfx950's 1280-byte LDS granules instead of seven: 20 workgroups fit a CU, not 18.
+constexpr uint32_t REP_LEN_LDS_SIZE = 4 + 256;     // choice, choice2, 2 pad, low[16][8], mid[16][8]
+constexpr uint32_t P_LIT = P_REP_LEN + REP_LEN_LDS_SIZE; // 1596
+constexpr uint32_t kRepHigh = 256;                 // HBM part: entries [0, 256) = rep-length high tree (index = tree slot)
 // The reference's literal coder has 0x300 probs per literal state (state.go:4,49): 0x100 for the
 // plain 8-bit tree and 0x200 used only by the FIRST literal after a match ("matched literal",
 // decompress.go:59-114).  The plain part stays in the LDS model; the matched part lives in an
@@ -39,7 +44,8 @@ constexpr uint32_t kLitPlain = 0x100;   // per literal state, in LDS at P_LIT
 constexpr uint32_t kLitMatched = 0x200; // per literal state, in HBM: index (matchBit << 8) + symbol
 
 static inline constexpr uint32_t num_probs(uint32_t lc_plus_lp) { return P_LIT + (kLitPlain << lc_plus_lp); }
-static inline constexpr uint32_t num_matched_probs(uint32_t lc_plus_lp) { return kLitMatched << lc_plus_lp; }
+// the model's HBM part: the rep-length high tree, then the matched-literal tables
+static inline constexpr uint32_t num_matched_probs(uint32_t lc_plus_lp) { return kRepHigh + (kLitMatched << lc_plus_lp); }
 
 constexpr uint32_t kMaxLdsBytes = 160u * 1024u; // MI355X LDS per CU
 constexpr uint32_t kWave = 64;

@@ -347,19 +347,21 @@ __device__ __forceinline__ uint32_t rc_core(uint32_t &range, uint32_t &code, uin
         }                                                                                         \
     } while (0)
 
-#define BIT_NN(IDX, BITV)                                                                         \
+#define BIT_NN_IN(ARR, IDX, BITV)                                                                 \
     do {                                                                                          \
         const uint32_t i_ = (IDX);                                                                \
-        uint32_t p_ = RFL(probs[i_]);                                                             \
+        uint32_t p_ = RFL((ARR)[i_]);                                                             \
         (BITV) = rc_core(d.range, d.code, p_);                                                    \
-        probs[i_] = (uint16_t)p_; /* all 64 lanes, same address, same value */                    \
+        (ARR)[i_] = (uint16_t)p_; /* all 64 lanes, same address, same value */                    \
     } while (0)
+#define BIT_NN(IDX, BITV) BIT_NN_IN(probs, IDX, BITV)
 
-#define BIT(IDX, B)                                                                               \
+#define BIT_IN(ARR, IDX, B)                                                                       \
     do {                                                                                          \
-        BIT_NN(IDX, B);                                                                           \
+        BIT_NN_IN(ARR, IDX, B);                                                                   \
         NORMALIZE();                                                                              \
     } while (0)
+#define BIT(IDX, B) BIT_IN(probs, IDX, B)
 
 // Where a tree node lives.  The reference indexes a bit tree by m = 1 b0 b1 .. (decided bits after a
 // leading 1).  This build stores node m at tree_slot(m): the same leading 1 followed by the
@@ -369,16 +371,17 @@ __device__ __forceinline__ uint32_t rc_core(uint32_t &range, uint32_t &code, uin
 __device__ __forceinline__ uint32_t tree_slot(uint32_t m, uint32_t level) { return m ^ ((1u << level) - 1); }
 
 // forward bit tree (bit_tree_decoder.go:18-40): M keeps the leading 1
-#define TREE(BASE, NB, M)                                                                         \
+#define TREE_IN(ARR, BASE, NB, M)                                                                 \
     do {                                                                                          \
         (M) = 1;                                                                                  \
         _Pragma("unroll 1") for (uint32_t k_ = 0; k_ < (NB); k_++)                                \
         {                                                                                         \
             uint32_t tb_;                                                                         \
-            BIT((BASE) + tree_slot((M), k_), tb_);                                                \
+            BIT_IN(ARR, (BASE) + tree_slot((M), k_), tb_);                                        \
             (M) = ((M) << 1) | tb_;                                                               \
         }                                                                                         \
     } while (0)
+#define TREE(BASE, NB, M) TREE_IN(probs, BASE, NB, M)
 
 // reverse bit tree (bit_tree_decoder.go:42-70)
 #define RTREE(BASE, NB, SYM)                                                                      \
@@ -395,7 +398,8 @@ __device__ __forceinline__ uint32_t tree_slot(uint32_t m, uint32_t level) { retu
     } while (0)
 
 // lenDecoder.Decode (len_decoder.go:34-60; decompress.go:218-429,870-1123)
-#define LEN_DECODE(LBASE, LEN)                                                                    \
+// HIGH_ARR / HIGH_BASE: where the coder's high tree lives (len: LDS model; rep-len: the model's HBM part, xlz_format.h)
+#define LEN_DECODE(LBASE, HIGH_ARR, HIGH_BASE, LEN)                                               \
     do {                                                                                          \
         uint32_t c_, m__;                                                                         \
         BIT((LBASE) + LEN_CHOICE, c_);                                                            \
@@ -408,7 +412,7 @@ __device__ __forceinline__ uint32_t tree_slot(uint32_t m, uint32_t level) { retu
                 TREE((LBASE) + LEN_MID + (pos_state << 3), 3, m__);                               \
                 (LEN) = m__;                                                                      \
             } else {                                                                              \
-                TREE((LBASE) + LEN_HIGH, 8, m__);                                                 \
+                TREE_IN(HIGH_ARR, HIGH_BASE, 8, m__);                                             \
                 (LEN) = 16 + m__ - 256;                                                           \
             }                                                                                     \
         }                                                                                         \
@@ -443,7 +447,7 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
         uint32_t symbol = 1;
         if (d.state >= 7) { // matched literal :59-114: probs[((1 + matchBit) << 8) + symbol] of the
                             // reference's table = mprobs[(matchBit << 8) + symbol] of this state
-            uint16_t *mp = mprobs + kLitMatched * lit_state;
+            uint16_t *mp = mprobs + kRepHigh + kLitMatched * lit_state;
             uint32_t mb = d.match_byte;
             uint32_t level = 0;
             do {
@@ -479,7 +483,7 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
         d.rep3 = d.rep2;
         d.rep2 = d.rep1;
         d.rep1 = d.rep0; // :216
-        LEN_DECODE(P_LEN, length);
+        LEN_DECODE(P_LEN, probs, P_LEN + LEN_HIGH, length);
         d.state = d.state < 7 ? 7 : 10; // stateUpdateMatch :431
         const uint32_t len_state = length > 3 ? 3 : length;
         uint32_t pos_slot;
@@ -562,7 +566,7 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
                 NORMALIZE();
             }
         }
-        LEN_DECODE(P_REP_LEN, length);
+        LEN_DECODE(P_REP_LEN, mprobs, 0u, length);
         d.state = d.state < 7 ? 8 : 11; // stateUpdateRep :933,1027,1103
         length += kMatchMinLen;
     }
@@ -592,8 +596,11 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
 }
 
 #undef NORMALIZE
+#undef BIT_NN_IN
 #undef BIT_NN
+#undef BIT_IN
 #undef BIT
+#undef TREE_IN
 #undef TREE
 #undef RTREE
 #undef LEN_DECODE
@@ -607,7 +614,7 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
 // ================================================================================
 static_assert(P_IS_MATCH == 0 && P_IS_REP == 192 && P_IS_REP_G0 == 204 && P_IS_REP_G1 == 216 && P_IS_REP_G2 == 228 &&
                   P_IS_REP0_LONG == 240 && P_POS_SLOT == 432 && P_POS_DEC == 688 && P_ALIGN == 804 && P_LEN == 820 &&
-                  P_REP_LEN == 1336 && P_LIT == 1852 && LEN_LOW == 4 && LEN_MID == 132 && LEN_HIGH == 260,
+                  P_REP_LEN == 1336 && P_LIT == 1596 && LEN_LOW == 4 && LEN_MID == 132 && LEN_HIGH == 260 && kRepHigh == 256,
               "tools/gen_fastpath.py hard-codes the probability layout");
 
 enum : uint32_t { FX_LIMIT = 0, FX_ERR = 1, FX_MARKER = 2, FX_COPY = 3 };
@@ -840,9 +847,9 @@ __device__ __forceinline__ void reload_context(Dec &d, const uint8_t *__restrict
 __device__ __forceinline__ void mprobs_reset(uint16_t *__restrict__ mprobs, uint32_t n, uint32_t lane)
 {
     uint4 *w = reinterpret_cast<uint4 *>(mprobs);
-    const uint32_t nw = n / 8; // 8 probs per 16 bytes; n is a multiple of 512
+    const uint32_t nw = n / 8; // 8 probs per 16 bytes; n is a multiple of 256
     const uint4 v = make_uint4(kProbInitPair, kProbInitPair, kProbInitPair, kProbInitPair);
-    for (uint32_t base = 0; base < nw; base += kWave) w[base + lane] = v;
+    for (uint32_t base = 0; base < nw; base += kWave) w[min(base + lane, nw - 1)] = v;
 }
 
 __device__ __forceinline__ void state_reset(Dec &d, uint16_t *probs, uint16_t *__restrict__ mprobs, uint32_t lc_lp,

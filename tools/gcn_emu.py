@@ -550,11 +550,11 @@ class Machine:
             self.lds[a[i]] = int(d[i]) & 0xFF
             self.lds[a[i] + 1] = (int(d[i]) >> 8) & 0xFF
 
-    def _gaddr(self, o_addr, o_base):
-        return self.rv(o_addr).astype(np.int64), self.mem[o_base[1]]
+    def _gaddr(self, o_addr, o_base, mods=None):
+        return self.rv(o_addr).astype(np.int64) + int((mods or {}).get("offset", 0)), self.mem[o_base[1]]
 
-    def _late_load(self, o, width):
-        a, buf = self._gaddr(o[1], o[2])
+    def _late_load(self, o, width, mods=None):
+        a, buf = self._gaddr(o[1], o[2], mods)
         if o[0][1] in self.pending:
             raise Halt("`%s`: a second load into %s while one is in flight" % (self.ins[self.pc][3], o[0][1]))
         self.vm.append((o[0][1], a, buf, width, self._mask_arr(self.exec)))
@@ -562,8 +562,8 @@ class Machine:
 
     def i_global_load_ubyte(self, o, mods):
         if self.strict_waits:
-            return self._late_load(o, 1)
-        a, buf = self._gaddr(o[1], o[2])
+            return self._late_load(o, 1, mods)
+        a, buf = self._gaddr(o[1], o[2], mods)
         em = self._mask_arr(self.exec)
         val = np.zeros(64, dtype=np.uint64)
         for i in np.nonzero(em)[0]:
@@ -572,8 +572,8 @@ class Machine:
 
     def i_global_load_ushort(self, o, mods):
         if self.strict_waits:
-            return self._late_load(o, 2)
-        a, buf = self._gaddr(o[1], o[2])
+            return self._late_load(o, 2, mods)
+        a, buf = self._gaddr(o[1], o[2], mods)
         em = self._mask_arr(self.exec)
         val = np.zeros(64, dtype=np.uint64)
         for i in np.nonzero(em)[0]:
@@ -581,13 +581,13 @@ class Machine:
         self.wv(o[0], val)
 
     def i_global_store_byte(self, o, mods):
-        a, buf = self._gaddr(o[0], o[2])
+        a, buf = self._gaddr(o[0], o[2], mods)
         d = self.rv(o[1])
         for i in np.nonzero(self._mask_arr(self.exec))[0]:
             buf[a[i]] = int(d[i]) & 0xFF
 
     def i_global_store_short(self, o, mods):
-        a, buf = self._gaddr(o[0], o[2])
+        a, buf = self._gaddr(o[0], o[2], mods)
         d = self.rv(o[1])
         for i in np.nonzero(self._mask_arr(self.exec))[0]:
             buf[a[i]] = int(d[i]) & 0xFF

@@ -59,7 +59,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 # probability-table layout: must match xlz_format.h (checked by static_asserts in the .hip)
 P_IS_MATCH, P_IS_REP, P_IS_REP_G0, P_IS_REP_G1, P_IS_REP_G2, P_IS_REP0_LONG = 0, 192, 204, 216, 228, 240
-P_POS_SLOT, P_POS_DEC, P_ALIGN, P_LEN, P_REP_LEN, P_LIT = 432, 688, 804, 820, 1336, 1852
+P_POS_SLOT, P_POS_DEC, P_ALIGN, P_LEN, P_REP_LEN, P_LIT = 432, 688, 804, 820, 1336, 1596
+REP_HIGH_BYTES = 512  # the rep-length coder's high tree: the first 256 entries of the model's HBM part (xlz_format.h: kRepHigh)
 LEN_CHOICE, LEN_CHOICE2, LEN_LOW, LEN_MID, LEN_HIGH = 0, 1, 4, 132, 260
 
 # head gather lanes (the per-lane address constants are built in xlz_kernel.hip: head_vectors)
@@ -80,8 +81,13 @@ H_IS_MATCH, H_IS_REP, H_G0, H_G1, H_G2, H_REP0_LONG, H_LEN_C, H_LEN_C2, H_REP_C,
 # the first five measured once on the hardware (+6.6 % on incompressible data, +0.9 % on text, profiles/r02/layout_scan.md):
 # `--variant next` switches all of them on
 NEXT_VARIANT = {"slot0", "vprev", "rmov", "nopos", "l7blk", "warel", "vreps"}
+# round 3 (profiles/r03/ab_wsb.txt, ab_latency_variants.txt): wsb adopted (+1.0 % text, +0.4 % cfg3 shape); measured and NOT
+# adopted: dbr / dbrw (branchy decisions: -25 % scalar instructions, -7 % on incompressible data: a taken branch costs more
+# than the two scalar instructions it saves), scode (the literal's decisions entirely scalar: +1 scalar instruction per level,
+# -6 % on incompressible data -- that data IS bound by the scalar port), hsb (scalar bounds for the head decisions: -0.6 %)
+ROUND3_VARIANT = {"wsb"}
 DEFAULT_VARIANT = {"lgather", "hdpp", "flim", "cflag", "tuc", "vperm", "rlhoist", "bralign", "stub32", "head32", "pktl64"}
-VARIANT = set(DEFAULT_VARIANT) | NEXT_VARIANT   # round 3: the prepared variants are the committed loop
+VARIANT = set(DEFAULT_VARIANT) | NEXT_VARIANT | ROUND3_VARIANT   # round 3: the prepared variants are the committed loop
 
 
 def hdpp_lane(j):
@@ -133,12 +139,25 @@ def L(name):
     return ".L%s_%%=" % name
 
 
+def hsb():
+    """hsb: the head decisions (isMatch, isRep, ..., the length coders' choice bits) form their bound on the scalar side
+    too (the lane read fetches the probability, s_lshr + s_mul in front of the compare): the range's chain no longer
+    goes through the vector side to become a bound (cf. wsb)"""
+    return "hsb" in VARIANT and "litrun" not in VARIANT
+
+
+def head_src():
+    return "v40" if hsb() else "v55"
+
+
 def bounds(src, dst="v55"):
     """dst = (range >> 11) * p for all 64 probabilities of VGPR `src` -- entirely on the VALU (the
     scalar port is the bottleneck).  The lane select of a later v_readlane then picks the BOUND.
     gfx940-family hazard: that v_readlane must not be the very next instruction (one wait state
     between a VALU write of a VGPR and a v_readlane of it; the assembler does not insert it
     inside inline asm) -- callers put independent work in between."""
+    if src == "v40" and hsb():
+        return  # (the head probabilities are read as they are; hbit multiplies on the scalar side)
     emit("v_lshrrev_b32 %s, 11, %%[range]\nv_mul_u32_u24 %s, %s, %s" % (dst, dst, dst, src))
 
 
@@ -244,16 +263,22 @@ def nchk(prefix=None, pick=None, mid=None, late_test=False, rreg=None):
         if rreg:
             stub_reg[k] = rreg
     stubs.append(k)
+    if SCODE[0]:
+        stub_scode.add(k)
 
 
 stub_reg = {}  # stub -> the SGPR that holds the range at its site (rmov), default %[range]
+stub_scode = set()   # stubs of a walk whose CODE lives in s87 (scode)
+SCODE = [False]      # a scode walk is being generated
 
 
 def emit_stubs():
     for k in stubs:
         label(k)
         rr = stub_reg.get(k, "%[range]")
-        if "vperm" in VARIANT:  # code = code << 8 | next byte in ONE byte permute (v13 = the selector), no scalar mask
+        if k in stub_scode:  # the code is in s87 during this walk (s81: the normalisation test's dead result)
+            emit("s_lshl_b32 %s, %s, 8\ns_lshl_b32 s87, s87, 8\ns_and_b32 s81, %%[cur], 0xff\ns_or_b32 s87, s87, s81" % (rr, rr))
+        elif "vperm" in VARIANT:  # code = code << 8 | next byte in ONE byte permute (v13 = the selector), no scalar mask
             emit("s_lshl_b32 %s, %s, 8\nv_perm_b32 v29, v29, %%[cur], v13" % (rr, rr))
         else:
             emit("s_lshl_b32 %s, %s, 8\ns_and_b32 s80, %%[cur], 0xff\nv_lshl_or_b32 v29, v29, 8, s80" % (rr, rr))
@@ -353,8 +378,8 @@ def head_update(lane, bit):
     emit("v_sub_u32 v63, v40, v63\nv_cndmask_b32 v40, v40, v63, vcc")
 
 
-def head_pick(lane):
-    return lambda: emit("v_readlane_b32 s80, v55, %d" % lane)
+def head_pick(lane, src=None):
+    return lambda: emit("v_readlane_b32 s80, %s, %d" % (src or head_src(), lane))
 
 
 def hbit(lane, one, stage=0, next_head=None, breg="s80", keep=False):
@@ -367,7 +392,9 @@ def hbit(lane, one, stage=0, next_head=None, breg="s80", keep=False):
     if stage < 1:
         bounds("v40")
     if stage < 2:
-        emit("v_readlane_b32 %s, v55, %d" % (breg, lane))
+        emit("v_readlane_b32 %s, %s, %d" % (breg, head_src(), lane))
+    if hsb():
+        emit("s_lshr_b32 s81, %%[range], 11\ns_mul_i32 %s, s81, %s" % (breg, breg))
     emit("v_cmp_gt_u32 vcc, %s, v29\ns_cbranch_vccz %s" % (breg, one))
     if not keep:  # keep (rmov): the new range stays in `breg`; the literal's first level reads it there
         emit("s_mov_b32 %%[range], %s" % breg)
@@ -415,6 +442,14 @@ def walk(nbits, blocks, early_exit=None, filler="s_nop 0"):
     filler: independent instruction(s) of the caller, placed in the wait state between the first
     VALU product and its lane read."""
     assert nbits <= 6
+    if "wsb" in VARIANT and lgather():
+        # wsb: scalar bound as in the 8-level walks (the probability comes with the lane read, s_lshr + s_mul form the
+        # bound): two scalar instructions more per level than the VALU product, but the range's dependent chain crosses
+        # between the scalar and the vector side twice per level instead of four times -- the waves are bound by that
+        # chain's latency, not by the issue ports (bench.py roofline.issue: 78 % of a lone wave's speed at 16 per CU)
+        emit(filler)
+        walk_rec(nbits, blocks, early_exit=early_exit)
+        return
     level_prefix(0, blocks)
     emit(filler)
     emit("v_readlane_b32 s80, v55, 1\n" + slot_init())
@@ -505,6 +540,20 @@ def level_rec(k=None, rin="%[range]"):
         emit("s_lshr_b32 s80, %s, 11\ns_mul_i32 s80, s80, s86" % rin)
         decide_branchy(k, rin)
         return
+    if SCODE[0]:
+        # scode: the decision entirely on the scalar side -- code - bound with its borrow in SCC, two selects -- one
+        # scalar instruction more and two vector ones less than the VALU compare, and the range's dependent chain no
+        # longer crosses to the vector side and back through VCC
+        emit("""
+        s_lshr_b32 s80, RIN, 11
+        s_mul_i32 s80, s80, s86
+        s_sub_u32 s81, RIN, s80
+        s_sub_u32 s83, s87, s80
+        s_cselect_b32 %[range], s80, s81
+        s_cselect_b32 s87, s87, s83
+        """.replace("RIN", rin))
+        slot_step(k)
+        return
     emit("s_lshr_b32 s80, %s, 11\ns_mul_i32 s80, s80, s86" % rin)
     if k is not None and not lgather():
         emit("v_writelane_b32 v54, s86, %d" % k)
@@ -512,10 +561,14 @@ def level_rec(k=None, rin="%[range]"):
     slot_step(k)
 
 
-def walk_rec(nbits, blocks, entries=None, range0=None):
+def walk_rec(nbits, blocks, entries=None, range0=None, early_exit=None):
     """walk() for the 8-level trees (scalar bound: the probability is read with v_readlane, the bound formed
     with s_lshr / s_mul).  entries = label prefix: entered at level k >= 1 through <prefix>k with s88 set."""
     hoist = "rlhoist" in VARIANT and (not entries or "pwhoist" in VARIANT)
+    scode = "scode" in VARIANT and lgather() and not entries and nbits == 8 and blocks is LIT_BLOCKS and not early_exit
+    if scode:
+        SCODE[0] = True
+        emit("v_readfirstlane_b32 s87, v29")
     if not entries:
         if "flim" in VARIANT and blocks is LIT_BLOCKS:  # (the packet head set s88 = 1 in a wait state)
             emit("v_readlane_b32 s86, %s, 1" % blocks[0])
@@ -536,6 +589,8 @@ def walk_rec(nbits, blocks, entries=None, range0=None):
             # slots 128..255 of the last level lie in blocks[2] (first decided bit 1) or blocks[3] (bit 0: the slot's
             # complemented bit 6 is set), and VCC still holds level 0's borrow = that complemented bit in every lane:
             # one select now replaces two lane reads + a bit test + a scalar select at level 7
+            if scode:  # (the decision left its outcome in SCC only; slot_step(0) keeps SCC)
+                emit("s_cselect_b64 vcc, -1, 0")
             emit("v_cndmask_b32 v62, %s, %s, vcc" % (blocks[2], blocks[3]))
         if hoist and k + 1 < nbits:
             # the next level's probability is read in front of the normalisation branch: the lane read's result
@@ -551,10 +606,19 @@ def walk_rec(nbits, blocks, entries=None, range0=None):
             emit("s_cbranch_scc0 %s" % L(kk))
             label(kk + "b")  # (the stub changes neither the slot nor the probability read for it)
             stubs.append(kk)
+            if scode:
+                stub_scode.add(kk)
+            if early_exit:
+                emit("s_cmp_eq_u32 %s, %d\ns_cbranch_scc1 %s" % (early_exit[0], k + 1, early_exit[1]))
             continue
         nchk()
         if k + 1 < nbits and not entries:
+            if early_exit:
+                emit("s_cmp_eq_u32 %s, %d\ns_cbranch_scc1 %s" % (early_exit[0], k + 1, early_exit[1]))
             fetch_level(k + 1, blocks, merged)
+    if scode:
+        SCODE[0] = False
+        emit("v_mov_b32 v29, s87")
 
 
 def walk8(blocks, entries=None):
@@ -681,7 +745,7 @@ def len_request(base):
 def len_pick(lane_c):
     """bounds("v40") was emitted at least one instruction ago: read the bound of the length
     coder's first decision (head lane lane_c)"""
-    emit("v_readlane_b32 s80, v55, %d" % lane_c)
+    emit("v_readlane_b32 s80, %s, %d" % (head_src(), lane_c))
 
 
 def posslot_request(static):
@@ -721,21 +785,55 @@ def len_decode_rest(tag, base, lane_c, lane_c2, posslot):
     emit("s_branch %s" % L(tag + "end"))
     label(tag + "hi")
     hbit_one(lane_c2)
-    emit("""
-    ds_read_u16 v43, v56 offset:%d
-    ds_read_u16 v44, v56 offset:%d
-    ds_read_u16 v45, v56 offset:%d
-    ds_read_u16 v46, v56 offset:%d
-    v_mov_b32 v58, %d
-    s_waitcnt lgkmcnt(0)
-    """ % ((base + LEN_HIGH) * 2, (base + LEN_HIGH) * 2 + 128, (base + LEN_HIGH) * 2 + 256, (base + LEN_HIGH) * 2 + 384,
-           (base + LEN_HIGH) * 2))
+    hbm = base == P_REP_LEN  # the rep-length coder's high tree lives in the model's HBM part (xlz_format.h: kRepHigh)
+    if hbm:
+        # (vmcnt(0) also waits for a pending match copy's load: its data is then simply there earlier)
+        emit("""
+        global_load_ushort v43, v56, %[mptr]
+        global_load_ushort v44, v56, %[mptr] offset:128
+        global_load_ushort v45, v56, %[mptr] offset:256
+        global_load_ushort v46, v56, %[mptr] offset:384
+        v_mov_b32 v58, 0
+        s_waitcnt vmcnt(0)
+        """)
+    else:
+        emit("""
+        ds_read_u16 v43, v56 offset:%d
+        ds_read_u16 v44, v56 offset:%d
+        ds_read_u16 v45, v56 offset:%d
+        ds_read_u16 v46, v56 offset:%d
+        v_mov_b32 v58, %d
+        s_waitcnt lgkmcnt(0)
+        """ % ((base + LEN_HIGH) * 2, (base + LEN_HIGH) * 2 + 128, (base + LEN_HIGH) * 2 + 256, (base + LEN_HIGH) * 2 + 384,
+               (base + LEN_HIGH) * 2))
     walk_rec(8, ["v43", "v44", "v45", "v46"])
     emit("s_andn2_b32 s89, 0xff, s88\ns_add_u32 s89, s89, 16")
     if posslot:
         posslot_request(True)
-    tree_update_rec(8, "v58")
+    if hbm:
+        tree_update_rec_hbm("v58")
+    else:
+        tree_update_rec(8, "v58")
     emit("s_branch %s" % L(tag + "end"))
+
+
+def tree_update_rec_hbm(base):
+    """tree_update_rec for an 8-level tree in the model's HBM part (%[mptr] + base): the eight probabilities the walk met
+    are gathered from there (lane k = level k; the other lanes address entry 0, a tree slot no walk visits), updated
+    in one vector operation and stored back"""
+    emit("""
+    v_lshrrev_b32 v60, v19, s88
+    v_lshl_add_u32 v60, v60, 1, %s
+    v_cndmask_b32_e64 v60, 0, v60, s[76:77]
+    global_load_ushort v54, v60, %%[mptr]
+    v_bfe_u32 v61, s88, v18, 1
+    v_mul_u32_u24 v61, 0x7e1, v61
+    s_waitcnt vmcnt(0)
+    v_sub_u32 v61, v54, v61
+    v_ashrrev_i32 v61, 5, v61
+    v_sub_u32 v61, v54, v61
+    global_store_short v60, v61, %%[mptr]
+    """ % base)
 
 
 wstubs = []
@@ -782,18 +880,18 @@ def packet_limits(head_lane, breg="s80"):
     if "flim" in VARIANT:
         emit("""
         s_cmp_gt_i32 AREL, s99
-        v_readlane_b32 %s, v55, %d
+        v_readlane_b32 %s, HSRC, %d
         s_cbranch_scc1 %s
-        """.replace("AREL", "s90" if "warel" in VARIANT else "%%[arel]") % (breg, head_lane, L("x0")))
+        """.replace("AREL", "s90" if "warel" in VARIANT else "%%[arel]").replace("HSRC", head_src()) % (breg, head_lane, L("x0")))
         emit(slot_init())  # (a wait state between the lane read and the compare that uses its result)
         return
     emit("""
     s_cmp_gt_u32 %%[arel], %%[arel_lim]
     s_cbranch_scc1 %s
-    v_readlane_b32 %s, v55, %d
+    v_readlane_b32 %s, HSRC, %d
     s_cmp_ge_u32 %%[pos], %%[pos_lim]
     s_cbranch_scc1 %s
-    """ % (L("x0"), breg, head_lane, L("x0")))
+    """.replace("HSRC", head_src()) % (L("x0"), breg, head_lane, L("x0")))
 
 
 def emit_wstubs():
@@ -1003,7 +1101,7 @@ def sec_literal_run():
     nchk()
     emit("s_waitcnt lgkmcnt(0)")
     bounds("v40")
-    emit("s_nop 0\nv_readlane_b32 s80, v55, %d\ns_branch %s" % (H_IS_REP, L("match2")))
+    emit("s_nop 0\nv_readlane_b32 s80, %s, %d\ns_branch %s" % (head_src(), H_IS_REP, L("match2")))
 
 
 def sec_packet_general():
@@ -1048,7 +1146,7 @@ def sec_packet_general():
     v_lshl_or_b32 v60, v61, 8, v60
     v_add_u32 v61, %d, v39
     v_add_lshl_u32 v57, v60, v61, 1
-    global_load_ushort v54, v57, %%[mptr]
+    global_load_ushort v54, v57, %%[mptr] offset:512
     s_waitcnt vmcnt(0)
     """ % ((-P_LIT * 2) & 0xffffffff))
     # matched levels: the eight candidate probabilities are lanes 0..7 of v54, so the bound of
@@ -1059,7 +1157,7 @@ def sec_packet_general():
         decide()
         slot_step(k)
         if k < 7:
-            nchk(prefix=lambda: bounds("v54"), pick=head_pick(k + 1))
+            nchk(prefix=lambda: bounds("v54"), pick=head_pick(k + 1, src="v55"))
         else:
             nchk()
         if k < 7:  # still on matchByte's path?  s88 == (0x1ff ^ mb) >> (7 - k)  (complemented bits)
@@ -1094,13 +1192,13 @@ def sec_packet_general():
     if lgather():  # (v60 is masked already)
         emit("""
         v_cndmask_b32 v57, 0, v57, vcc
-        global_store_short v57, v61, %[mptr]
+        global_store_short v57, v61, %[mptr] offset:512
         ds_write_b16 v60, v61
         """)
     else:
         emit("""
         v_cndmask_b32 v57, 0, v57, vcc
-        global_store_short v57, v61, %[mptr]
+        global_store_short v57, v61, %[mptr] offset:512
         v_cndmask_b32 v60, v60, v38, vcc
         v_cndmask_b32 v60, v38, v60, s[76:77]
         ds_write_b16 v60, v61
