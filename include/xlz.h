@@ -130,7 +130,7 @@ int xlz_ctx_batching_stats(xlz_ctx *ctx, uint64_t *batches, uint64_t *streams);
  * BREAK-EVEN: one wave decodes one unit (a stream; an LZMA2 dictionary-reset unit) at
  * 4-6 MB/s and the chip holds 4096 of them, so a call with few units is slower than the
  * host's own cores: measured on 1 MiB text streams, 64 units 0.34 GiB/s (16 host cores:
- * 1.26), 256 units 1.35 (1.23), 1024 units 5.1, 4096 units 16.9.  Below about 250 units
+ * 1.27), 256 units 1.37 (1.28), 1024 units 5.2, 4096 units 17.2.  Below about 250 units
  * per 16 host cores decode on the CPU, or gather more streams first.   */
 int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_result *results);
 
