@@ -85,7 +85,8 @@ NEXT_VARIANT = {"slot0", "vprev", "rmov", "nopos", "l7blk", "warel", "vreps"}
 # adopted: dbr / dbrw (branchy decisions: -25 % scalar instructions, -7 % on incompressible data: a taken branch costs more
 # than the two scalar instructions it saves), scode (the literal's decisions entirely scalar: +1 scalar instruction per level,
 # -6 % on incompressible data -- that data IS bound by the scalar port), hsb (scalar bounds for the head decisions: -0.6 %)
-ROUND3_VARIANT = {"wsb"}
+# lwait: the next literal's block reads stay in flight across the isMatch decision (+0.3 .. +0.6 %, profiles/r03/ab_lwait.txt)
+ROUND3_VARIANT = {"wsb", "lwait"}
 DEFAULT_VARIANT = {"lgather", "hdpp", "flim", "cflag", "tuc", "vperm", "rlhoist", "bralign", "stub32", "head32", "pktl64"}
 VARIANT = set(DEFAULT_VARIANT) | NEXT_VARIANT | ROUND3_VARIANT   # round 3: the prepared variants are the committed loop
 
@@ -999,6 +1000,8 @@ def plain_literal(run_entry=None, range0=None):
         if "lit8" in VARIANT:
             gather8(LIT_BLOCKS)
     else:
+        if "lwait" in VARIANT:
+            emit("s_waitcnt lgkmcnt(0)")
         walk_rec(8, LIT_BLOCKS, range0=range0)
         if lgather():
             rec_gather_issue("v39", masked=False)
@@ -1018,7 +1021,10 @@ def sec_packet_after_literal():
     # state < 7, no copy pending, literal blocks requested: the three tests of the general
     # packet head are known
     label("pktl")
-    emit("s_waitcnt lgkmcnt(0)")
+    # lwait: both ways here end with the next literal's four block reads as their YOUNGEST LDS operations (literal_context);
+    # LDS returns in order, so lgkmcnt(4) says the head gather is back while the blocks are still on their way -- their
+    # round trip then overlaps the isMatch decision; the literal waits for them in front of its first level (plain_literal)
+    emit("s_waitcnt lgkmcnt(%d)" % (4 if "lwait" in VARIANT else 0))
     bounds("v40")
     if "rmov" in VARIANT:
         # the isMatch bound is read into s82 and STAYS there as the new range when the bit is 0: the literal's first

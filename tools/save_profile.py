@@ -64,6 +64,10 @@ entry = {
         "branch_per_decoded_byte": round(mean("SQ_INSTS_BRANCH") / decoded, 3),
         # SQ_WAVE_CYCLES counts in quad-cycles per wave: x4 / (slots x kernel cycles) = average slot occupancy
         "slot_occupancy": round(mean("SQ_WAVE_CYCLES") * 4 / (grid * kernel_ms / 1e3 * CLK), 4),
+        # where a resident wave's time goes: the three counters add up to SQ_WAVE_CYCLES
+        "wave_time": {"executing_an_instruction": round(mean("SQ_ACTIVE_INST_ANY") / mean("SQ_WAVE_CYCLES"), 3),
+                      "in_s_waitcnt": round(mean("SQ_WAIT_ANY") / mean("SQ_WAVE_CYCLES"), 3),
+                      "waiting_to_issue": round(mean("SQ_WAIT_INST_ANY") / mean("SQ_WAVE_CYCLES"), 3)},
         "budget": "measured ceilings per CU cycle: 0.97 SALU, 1.28 VALU (tools/ubench/mix2.hip); "
                   "clock %.1f GHz, %d CUs, kernel_ms %.3f" % (CLK / 1e9, CUS, kernel_ms),
         "source": dest + "_pmc.csv",
