@@ -1234,8 +1234,19 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     };
     std::thread th_up, th_down;
     if (S > 1) {
-        th_up = std::thread(uploader);
-        th_down = std::thread(downloader);
+        try {
+            th_up = std::thread(uploader);
+            th_down = std::thread(downloader);
+        } catch (...) { // no thread to be had: stop what has started and fail the call, do not terminate the process
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                abort_all = true;
+            }
+            cv.notify_all();
+            if (th_up.joinable()) th_up.join();
+            for (xlz_batch *b : sub) xlz_batch_destroy(b);
+            return XLZ_ERR_DEVICE;
+        }
     }
     // this thread: launch sub-batch k as soon as it is uploaded (queued behind k-1 on the stream), then collect k-1
     int st = XLZ_OK;
