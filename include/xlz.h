@@ -125,7 +125,7 @@ int xlz_ctx_batching_stats(xlz_ctx *ctx, uint64_t *batches, uint64_t *streams);
  * streams (reader1_test.go:76-80).  One bad stream never fails the batch: the return
  * value is XLZ_OK unless the call itself could not run; per-stream outcomes are in
  * results[i].  Thread-safe across contexts; calls on one context are serialised.
- * A call of several wave rounds (>= 8192 streams and >= 2 GiB of output) is cut into up
+ * A call of several wave rounds (>= 8192 streams and >= 1 GiB of output) is cut into up
  * to eight sub-batches whose upload, decode and download overlap.
  * BREAK-EVEN: one wave decodes one unit (a stream; an LZMA2 dictionary-reset unit) at
  * 4-6 MB/s and the chip holds 4096 of them, so a call with few units is slower than the

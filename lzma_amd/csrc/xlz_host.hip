@@ -1141,7 +1141,8 @@ extern "C" int xlz_ctx_last_call_stats(xlz_ctx *ctx, xlz_call_stats *out)
 }
 
 // Where a call of several wave rounds is cut into sub-batches whose upload, decode and download overlap: equal
-// shares of the output, each at least one wave round of streams and about 1 GiB, at most eight.  One sub-batch =
+// shares of the output, each at least one wave round of streams and half a GiB, at most eight (what stays exposed is
+// the first sub-batch's upload and the last one's download: the smaller they are, the less).  One sub-batch =
 // the plain sequence (a single wave round has nothing to overlap: every stream needs the whole launch).
 static void plan_sub_batches(const xlz_stream_desc *streams, size_t n, std::vector<size_t> &cuts)
 {
@@ -1149,7 +1150,7 @@ static void plan_sub_batches(const xlz_stream_desc *streams, size_t n, std::vect
     uint64_t total = 0;
     for (size_t i = 0; i < n; i++) total += streams[i].out_cap;
     const size_t k_round = 4096; // streams of one wave round (16 waves on each of 256 CUs)
-    size_t n_sub = std::min<size_t>(std::min<size_t>(8, n / k_round), (size_t)(total >> 30));
+    size_t n_sub = std::min<size_t>(std::min<size_t>(8, n / k_round), (size_t)(total >> 29));
     if (n_sub >= 2) {
         uint64_t acc = 0;
         size_t next = 1;
