@@ -211,6 +211,15 @@ def decide_branchy(k, rin="%[range]"):
     s_mov_b32 %[range], s80
     """.replace("ONE", L(one)))
     emit("s_mov_b32 s88, 3" if first else "s_lshl1_add_u32 s88, s88, 1")
+    if "dbrs" in VARIANT:
+        # dbrs: the bit-1 outcome lies right behind the bit-0 one: every outcome takes ONE short forward branch (12
+        # bytes) instead of none / two far ones
+        emit("s_branch %s" % L(join))
+        label(one)
+        emit("v_subrev_u32 v29, s80, v29\ns_sub_u32 %%[range], %s, s80" % rin)
+        emit("s_mov_b32 s88, 2" if first else "s_lshl_b32 s88, s88, 1")
+        label(join)
+        return
     label(join)
 
     def out_of_line(one=one, join=join, first=first, rin=rin):
