@@ -1,7 +1,7 @@
 """Dev tool (GPU box): time several builds of libxlz.so on the same corpora in ONE process.
 Every library is loaded with its own ctypes handle; a corpus is generated once and decoded by each.
     python tools/ab_bench.py name=path/to/lib.so [name=...] [--fams T,R,S] [--steps 3]
-Workloads (all 4096 or more streams so that the launch fills the chip): T = cfg2-T shape (1 MiB text, preset 6,
+Workloads (all 4096 or more streams so that the launch fills the chip; M = mixed segments, Z = long repeats): T = cfg2-T shape (1 MiB text, preset 6,
 1024 distinct x 4), R = cfg2-R shape (512 distinct x 8), S = cfg3 shape (64 KiB text, 8192 distinct x 8).
 Prints decompressed GiB/s from HIP events on the kernel's stream; every variant's output is checked (SHA-256)."""
 import ctypes, hashlib, os, sys, time
@@ -11,7 +11,7 @@ import corpus
 from lzma_amd import _native as N
 
 WORK = {"T": ("T", 1024, 4, 1 << 20, 6), "R": ("R", 512, 8, 1 << 20, 0), "S": ("T", 8192, 8, 65536, 0),
-        "M": ("M", 1024, 4, 1 << 20, 0)}
+        "M": ("M", 1024, 4, 1 << 20, 0), "Z": ("Z", 256, 16, 1 << 20, 0)}
 
 
 def load(path):
