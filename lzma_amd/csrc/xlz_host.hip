@@ -745,7 +745,7 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
         hipMemcpy(d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess &&
         hipMemsetAsync(ctx->queue, 0, 256, ctx->stream) == hipSuccess) {
         LaunchParams p;
-    memset(&p, 0, sizeof p); // (ready, epochs, ...: off unless set below)
+        memset(&p, 0, sizeof p); // (epochs, order_base, ...: off unless set below)
         p.in_arena = b->d_in;
         p.out_arena = b->d_out;
         p.units = d_units;
@@ -1733,8 +1733,7 @@ int sessions_launch(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs, bool big)
     if (hipMemcpyAsync(d_units, units.data(), n * sizeof(Unit), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
         hipMemsetAsync(ctx->queue, 0, 256, ctx->stream) == hipSuccess) {
         LaunchParams p;
-    memset(&p, 0, sizeof p); // (ready, epochs, ...: off unless set below)
-        memset(&p, 0, sizeof p);
+        memset(&p, 0, sizeof p); // (epochs, order_base, ...: off unless set below)
         p.in_arena = nullptr; // units carry absolute device addresses
         p.out_arena = nullptr;
         p.units = d_units;
