@@ -2,6 +2,7 @@
 # rocprofv3 passes over ONE bench.py config (run on the GPU box via gpurun).
 #   tools/profile_bench.sh <tag> <config> [extra bench args]     config: cfg3 (default), cfg2-T, cfg2-R, cfg4, cfg5, ...
 # 1) --kernel-trace --stats  2) --pmc FETCH_SIZE  3) --pmc WRITE_SIZE  4) SQ instruction mix  5) SQ issue activity
+# 6) VmemLatency / LdsLatency
 # Counter passes are separate runs and never combined with tracing (pool rule).  The program after
 # `--` is python3 itself (no env / shell hop: the profiler has initialised the GPU by then).
 set -u
@@ -16,6 +17,8 @@ rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.p
 rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py $ARGS > $O/write.json 2> $O/write.err || exit 1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/sq --output-format csv -- python3 $R/bench.py $ARGS > $O/sq.json 2> $O/sq.err || exit 1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_IFETCH SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $O/sq2 --output-format csv -- python3 $R/bench.py $ARGS > $O/sq2.json 2> $O/sq2.err || exit 1
+# 6) average latency of the vector-memory and LDS instructions (derived metrics; optional: a failure here does not fail the run)
+rocprofv3 --pmc VmemLatency LdsLatency -d $O/lat --output-format csv -- python3 $R/bench.py $ARGS > $O/lat.json 2> $O/lat.err || echo "latency pass failed (see lat.err)"
 rm -f /tmp/xlz_corpus_cache/xlz_corpus_${CFG}_*.pkl
 python3 $R/tools/summarize_prof.py $O > $O/summary.md
 cat $O/summary.md

@@ -29,7 +29,7 @@ if d:
           "`--stats` average is over all of them." % ", ".join("%.2f" % x for x in d))
 print("\n## PMC (per launch of xlz_decode_kernel, summed over the device)\n")
 vals = collections.defaultdict(list)
-for sub in ("fetch", "write", "sq", "sq2"):
+for sub in ("fetch", "write", "sq", "sq2", "lat"):
     for r in kernel_rows(sub, "*counter_collection.csv"):
         if "xlz_decode" in r["Kernel_Name"]:
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
