@@ -580,6 +580,20 @@ class Machine:
             val[i] = buf[a[i]] | (buf[a[i] + 1] << 8)
         self.wv(o[0], val)
 
+    def i_global_load_dword(self, o, mods):
+        """(only as a prefetch whose result nobody reads: the destination is simply left alone, also in strict mode --
+        two of them may be in flight at once)"""
+        a, buf = self._gaddr(o[1], o[2], mods)
+        em = self._mask_arr(self.exec)
+        for i in np.nonzero(em)[0]:
+            assert 0 <= a[i] and a[i] + 4 <= len(buf), "prefetch outside the output range: %d" % a[i]
+
+    def i_v_max_i32(self, o, m):
+        a, b = self.rv(o[1]).astype(np.int64), self.rv(o[2]).astype(np.int64)
+        a = np.where(a >= 2**31, a - 2**32, a)
+        b = np.where(b >= 2**31, b - 2**32, b)
+        self.wv(o[0], (np.maximum(a, b) & 0xFFFFFFFF).astype(np.uint64))
+
     def i_global_store_byte(self, o, mods):
         a, buf = self._gaddr(o[0], o[2], mods)
         d = self.rv(o[1])

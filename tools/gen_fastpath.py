@@ -1308,6 +1308,24 @@ def sec_match():
         # entered after the bit is done
         nchk(mid="s_nop 0\nv_cndmask_b32 v29, v29, v55, vcc\nv_addc_co_u32 v33, vcc, v33, v33, vcc")
     emit("v_readfirstlane_b32 s84, v33\ns_lshl_b32 s84, s84, 4")
+    if "pref" in VARIANT:
+        # (measured: -1.5 % on text, profiles/r03/ab_pref.txt -- the copy's source latency is not what the waves wait
+        #  for.  A build with this switch needs "v26", "v27" in the clobber list of lzma_fast_loop.)
+        # pref: everything of the distance but its four align bits is known here, four decisions (~400 cycles) before the copy
+        # can ask for its source: one 256-byte load (discarded: v27) pulls the source's cache lines in now -- a match
+        # source is a miss of L2 more often than not (4096 live windows of 64 KiB against 32 MiB of L2; VmemLatency 430
+        # cycles on text, profiles/r03).  The offset is clamped (unsigned) to the output position: whatever a damaged
+        # stream makes of the distance -- beyond the start of the unit, or wrapped far beyond its end -- the load stays
+        # inside [out, out + pos + 4).
+        assert nopos()
+        emit("""
+        s_add_u32 s81, s93, s84
+        v_subrev_u32 v26, s81, v17
+        v_lshl_add_u32 v26, %[vlane], 2, v26
+        v_add_u32 v26, -20, v26
+        v_min_u32 v26, v17, v26
+        global_load_dword v27, v26, %[outp]
+        """)  # (v27 is written by nothing else: a prefetch still in flight cannot disturb the next one's address in v26)
     # reverse tree over alignDecoderProbs (:579-625): M = 1 b0 b1 b2 b3
     walk(4, ["v35"], filler="s_add_u32 s93, s93, s84\nv_mov_b32 v58, %d" % (P_ALIGN * 2))
     tree_update(4, ["v35"])
