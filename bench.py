@@ -19,7 +19,8 @@ At N = 1 the same JSON line also carries
   * `configs`: every other BASELINE configuration measured in the same process on the same GPU
     (--side-steps each): cfg2-T (configs[1]: 4096 x 1 MiB), cfg2-T-p6 (the same plaintext behind
     liblzma preset 6: rounds 1 and 2's headline), cfg2-R (incompressible, the shape of the reference's
-    randomfile.dat benchmark), cfg4 (ONE raw LZMA2 stream of 4096 dictionary-reset units), cfg5 (8192
+    randomfile.dat benchmark), cfg4 (ONE raw LZMA2 stream of 4096 dictionary-reset units), cfg4-R (the same with
+    incompressible segments: stored chunks only, the shape of randomfile.dat.lzma2), cfg5 (8192
     streams, lc2/lp1/pb1, 8 MiB dictionary), cfg5-wrap (24 MiB streams whose 8 MiB window wraps).
     All corpora use ONE encoder setting (ENC_FAST) so that the configs can be compared; every config
     has its own `roofline` (incl. `issue`: the instruction-issue and lone-wave-latency bounds this
@@ -71,13 +72,17 @@ CONFIGS = {
                    baseline="configs[1], incompressible family (literal-only, the shape of randomfile.dat.lzma)"),
     "cfg4": dict(fmt="lzma2", family="T", streams=1, segments=4096, size=256 << 10, dict=65536, lc=3, lp=0, pb=2,
                  enc=ENC_FAST, baseline="configs[3]: one large LZMA2 stream, 4096 dictionary-reset units"),
+    "cfg4-R": dict(fmt="lzma2", family="R", streams=1, segments=4096, size=256 << 10, dict=65536, lc=3, lp=0, pb=2,
+                   enc=ENC_FAST, baseline="configs[3], incompressible variant: stored chunks only, the shape of the reference's "
+                                          "own LZMA2 benchmark file randomfile.dat.lzma2 (reader2_test.go:31-36) -- the one sub-path "
+                                          "that is a plain copy"),
     "cfg5": dict(fmt="lzma1", family="T", streams=8192, size=2 << 20, dict=8 << 20, lc=2, lp=1, pb=1, enc=ENC_FAST,
                  baseline="configs[4]: 8192 LZMA1 streams, lc=2/lp=1/pb=1, 8 MiB dict"),
     "cfg5-wrap": dict(fmt="lzma1", family="F", streams=64, size=24 << 20, dict=8 << 20, lc=2, lp=1, pb=1, enc=ENC_FAST,
                       baseline="configs[4] variant: 24 MiB streams, the 8 MiB window wraps, distances up to 8 MiB"),
 }
 HEADLINES = ["cfg3", "cfg3-heavy"]
-SIDE = ["cfg2-T", "cfg2-T-p6", "cfg2-R", "cfg4", "cfg5", "cfg5-wrap"]
+SIDE = ["cfg2-T", "cfg2-T-p6", "cfg2-R", "cfg4", "cfg4-R", "cfg5", "cfg5-wrap"]
 EXTRAS = ["h2h", "sweep", "xz", "lone"]   # lone: the 64-unit launches behind roofline.issue.latency_bound
 SWEEP_COUNTS = [64, 256, 1024]  # (4096 is cfg2-T itself)
 

@@ -370,20 +370,36 @@ void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint
 {
     size_t pos = 0, unit_start = 0;
     uint64_t out = 0, unit_out = 0;
-    size_t cand_pos = 0; // pending split: a stored chunk reset the dictionary here
-    uint64_t cand_out = 0;
-    bool cand = false;
-    bool seen_lzma = false, cand_seen_lzma = false, unit_seen_lzma = false; // an LZMA chunk before: here / the candidate / the unit
+    // pending splits: stored chunks that reset the dictionary.  A unit may start at one iff the first LZMA chunk behind
+    // it (if any) brings new properties -- a chunk without them continues the model that LZMA chunks in FRONT of the
+    // stored ones left (the state is carried across stored chunks, reader2.go:155-167).  So candidates wait for the next
+    // LZMA chunk: new properties make all of them cuts, none does; the end of the stream makes them cuts too (nothing
+    // depends on a model any more: a run of stored chunks -- the shape of the reference's own LZMA2 benchmark file,
+    // randomfile.dat.lzma2 -- is then copied by one wave per dictionary reset instead of one wave for all of it).
+    struct Cand {
+        size_t pos;
+        uint64_t out;
+        bool seen_lzma;
+    };
+    std::vector<Cand> cands;
+    bool seen_lzma = false, unit_seen_lzma = false; // an LZMA chunk before: here / the unit
     auto cut = [&](size_t at, uint64_t at_out, bool lzma_before) {
         units.push_back({(uint32_t)unit_start, (uint32_t)(at - unit_start), unit_out, at_out - unit_out, unit_seen_lzma});
         unit_start = at;
         unit_out = at_out;
         unit_seen_lzma = lzma_before;
     };
+    auto cut_at_candidates = [&] {
+        for (const Cand &c : cands)
+            if (c.pos != unit_start) cut(c.pos, c.out, c.seen_lzma);
+        cands.clear();
+    };
+    bool ended = false; // the walk reached the end of the stream (or of the input) without leaving the format
     while (pos < len) {
         const uint8_t c = in[pos];
         if (c == 0 || (c >= 3 && c < 0x80)) { // end of stream (reader2.go:175-199)
             pos++;
+            ended = true;
             break;
         }
         const bool stored = c < 3;
@@ -393,12 +409,7 @@ void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint
         uint32_t unc = ((uint32_t)in[pos + 1] << 8) | in[pos + 2];
         if (stored) {
             unc += 1;
-            if (c == 1 && pos != 0) {
-                cand = true;
-                cand_pos = pos;
-                cand_out = out;
-                cand_seen_lzma = seen_lzma;
-            }
+            if (c == 1 && pos != 0) cands.push_back({pos, out, seen_lzma});
             const size_t body = std::min<size_t>(unc, len - pos - hl);
             pos += hl + body;
             out += body;
@@ -410,14 +421,19 @@ void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint
             const uint8_t props = in[pos + 5];
             if (props >= 225) break; // the walker reports ErrIncorrectProperties here
             max_lc_lp = std::max<uint32_t>(max_lc_lp, (props % 9) + (props / 9) % 5);
-            if (sub == 7 && pos != 0 && pos != unit_start) cut(pos, out, seen_lzma);
-            else if (cand && cand_pos != unit_start) cut(cand_pos, cand_out, cand_seen_lzma);
+            if (sub == 7 && pos != 0 && pos != unit_start) {
+                cut_at_candidates();
+                if (pos != unit_start) cut(pos, out, seen_lzma);
+            } else {
+                cut_at_candidates();
+            }
         }
         seen_lzma = true;
-        cand = false; // a compressed chunk without new props keeps the model: no cut
+        cands.clear(); // a compressed chunk without new props keeps the model: no cut
         pos += hl + std::min(comp, len - pos - hl);
         out += unc;
     }
+    if (ended || pos >= len) cut_at_candidates(); // only stored chunks behind them
     units.push_back({(uint32_t)unit_start, (uint32_t)(len - unit_start), unit_out, out - unit_out, unit_seen_lzma});
 }
 

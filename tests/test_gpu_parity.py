@@ -381,6 +381,54 @@ def test_lzma2_many_small_units_share_one_output_range(ctx):
         assert got[0][0] == want
 
 
+def test_lzma2_runs_of_stored_chunks_split_at_their_dictionary_resets(ctx):
+    """The shape of the reference's own LZMA2 benchmark file (randomfile.dat.lzma2, reader2_test.go:31-36): stored
+    chunks only.  A stored chunk that resets the dictionary may start a unit when no LZMA chunk behind it continues an
+    earlier model (scan_lzma2): 60 incompressible segments are 60 units, not one wave copying everything; the same
+    segments with a compressed chunk WITHOUT new properties behind a stored reset must not be cut there -- both against
+    the oracle, and through a reader."""
+    from lzma_craft import Encoder, Window, lzma2_lzma_chunk, lzma2_stored, props_byte
+    segs = [corpus.plain("R", 1500 + i, 70_000 + 997 * (i % 7)) for i in range(60)]
+    blob = corpus.lzma2_concat(segs, dict_size=1 << 16, preset=0)
+    want = b"".join(segs)
+    assert blob[0] == 1 and blob.count(b"\x01", 0, 1) == 1          # stored, dictionary reset
+    b = lzma_amd.Batch(ctx, [Stream(blob, FMT_LZMA2_RAW, out_cap=len(want), dict_size=1 << 16)])
+    b.run()
+    res = b.results()
+    assert res[0][0] == len(want) and res[0][1] == 0 and res[0][2] == len(blob)
+    assert b.download(0, len(want)) == want
+    assert b.stats()[2] == 60                                       # units
+    b.close()
+    # mixed: text segments (0xE0 chunks), stored runs, and a crafted tail whose 0x80 chunk (no new properties) follows
+    # a stored reset: that candidate must NOT become a cut (the chunk continues the model of the chunks before)
+    segs2 = [corpus.plain("TR"[i % 2], 1600 + i, 50_000) for i in range(9)]
+    w = Window(1 << 16)
+    e = Encoder(3, 0, 2, 1 << 16, window=w)
+    for i in range(500):
+        e.literal(97 + i % 7)
+    e.match(100, 50)
+    tail = lzma2_lzma_chunk(0xE0, len(w.total), e.payload(), props_byte(3, 0, 2))
+    n0 = len(w.total)
+    w.reset()
+    for x in b"stored-after-reset":
+        w.put(x)
+    tail += lzma2_stored(b"stored-after-reset", dict_reset=True)
+    e.new_chunk()
+    n1 = len(w.total)
+    for i in range(300):
+        e.literal(65 + i % 5)
+    e.rep(0, 20)
+    tail += lzma2_lzma_chunk(0x80, len(w.total) - n1, e.payload()) + b"\x00"
+    blob2 = corpus.lzma2_concat(segs2, dict_size=1 << 16, preset=0)[:-1] + tail
+    want2 = oracle.lzma2_raw(blob2, 1 << 16, 1 << 20)
+    assert want2[1] == 0 and want2[0] == b"".join(segs2) + bytes(w.total)
+    got = _check_lzma2(ctx, [blob, blob2], [1 << 16, 1 << 16], [len(want), len(want2[0])])
+    assert got[0][0] == want and got[1] == want2
+    r, err = lzma_amd.NewReader2(ctx, blob, 1 << 16)
+    out, e2 = r.read_all(chunk=100_000)
+    assert e2 is None and out == want
+
+
 # ------------------------------------------- BASELINE-sized batches: size-independent properties ----
 def test_baseline_shape_roundtrip_and_idempotence(ctx):
     """4096 streams (the stream count of BASELINE config 2; 64 KiB each so the corpus builds in
