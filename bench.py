@@ -696,19 +696,29 @@ def main():
             sweep.append({"streams": k, "value": round(k * sp["size"] * 2 / GIB / tl, 4), "unit": "GiB/s", "kernel_ms": round(kms, 3),
                           "slot_occupancy": oc and oc["slot_occupancy"], "bit_exact": "all"})
     if "xz" in extras and xz is not None:
+        import numpy as np
         data, want = xz
-        t0 = time.perf_counter()
-        out = lzma_amd.xz_decode(ctx, data, verify=True)
-        t1 = time.perf_counter()
-        out = lzma_amd.xz_decode(ctx, data, verify=True)
-        dt = min(t1 - t0, time.perf_counter() - t1)
+        _, total = lzma_amd.xz_index(data)
+        out = np.zeros(total, dtype=np.uint8)   # the caller's buffer, touched (as in host_to_host)
+        times = []
+        for _ in range(3):   # the first call allocates the pinned pools
+            t0 = time.perf_counter()
+            n_out = lzma_amd.xz_decode_into(ctx, data, out, verify=True)
+            times.append((time.perf_counter() - t0, ctx.last_call_stats()))
+        dt, cs = min(times, key=lambda x: x[0])
+        cs_xz = {"pack_upload": round(cs["upload_ms"], 3), "decode": round(cs["decode_ms"], 3),
+                 "download_scatter": round(cs["download_ms"], 3),
+                 "index_and_check": round(dt * 1e3 - cs["upload_ms"] - cs["decode_ms"] - cs["download_ms"], 3),
+                 "note": "the three phases of the xlz_decode_batch call inside; index_and_check = the rest of the call (block "
+                         "index, CRC64 of every block on host threads)"}
+        out = out[:n_out]
         if hashlib.sha256(out).digest() != want:
             raise SystemExit("xz container: decoded bytes differ from the plaintext")
         containers = [{"name": "xz-blocks", "workload": "one .xz file of %d independently compressed 1 MiB blocks (LZMA2, 1 MiB "
-                       "dictionary, CRC64), %s; xlz_xz_decode: file in host memory -> decoded bytes in host memory, every block's "
-                       "CRC64 verified on the host" % (max(8, int(1024 * args.scale)), ENC_FAST_NAME),
+                       "dictionary, CRC64), %s; xlz_xz_decode called with the caller's buffers: file in host memory -> decoded bytes in "
+                       "host memory, every block's CRC64 verified on the host" % (max(8, int(1024 * args.scale)), ENC_FAST_NAME),
                        "value": round(len(out) / GIB / dt, 4), "unit": "GiB/s", "ms_per_call": round(dt * 1e3, 3),
-                       "compressed_bytes": len(data), "decoded_bytes": len(out), "bit_exact": "all", "calls": 2, "reported": "best call"}]
+                       "compressed_bytes": len(data), "decoded_bytes": len(out), "bit_exact": "all", "calls": 3, "reported": "best call", "phases_ms": cs_xz}]
         del out
 
     # ---- CPU legs after all GPU work: the host cores are quiet

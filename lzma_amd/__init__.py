@@ -468,15 +468,26 @@ def xz_decode(ctx, data, verify=True, max_size=None):
     _, total = xz_index(data)
     if max_size is not None and total > max_size:
         raise LzmaError(ERR_OUT_CAP, "xlz_xz_decode: the index announces %d bytes, max_size is %d" % (total, max_size))
-    buf = ctypes.create_string_buffer(data, len(data))
     out = ctypes.create_string_buffer(max(total, 1))
+    n = xz_decode_into(ctx, data, out, verify=verify)
+    return out.raw[:n]
+
+
+def xz_decode_into(ctx, data, out, verify=True):
+    """xlz_xz_decode with the caller's buffers and nothing else: `data` is read in place (bytes, or any object with the
+    buffer interface), the decoded bytes land in `out` (a writable buffer of at least the index's total: bytearray,
+    numpy array, ctypes array) -> number of bytes decoded.  What bench.py times for the container line."""
+    if not isinstance(data, bytes):
+        data = bytes(data)
+    src_ptr = ctypes.c_char_p(data)  # the library only reads it: no copy
+    dst = out if isinstance(out, ctypes.Array) else (ctypes.c_char * memoryview(out).nbytes).from_buffer(out)
     out_len = ctypes.c_uint64()
     unverified = ctypes.c_size_t()
-    st = N.lib().xlz_xz_decode(ctx._h, ctypes.cast(buf, ctypes.c_void_p), len(data), ctypes.cast(out, ctypes.c_void_p),
-                               total, ctypes.byref(out_len), 1 if verify else 0, ctypes.byref(unverified))
+    st = N.lib().xlz_xz_decode(ctx._h, ctypes.cast(src_ptr, ctypes.c_void_p), len(data), ctypes.cast(dst, ctypes.c_void_p),
+                               ctypes.sizeof(dst), ctypes.byref(out_len), 1 if verify else 0, ctypes.byref(unverified))
     if st != OK:
         raise LzmaError(st, "xlz_xz_decode")
-    return out.raw[: out_len.value]
+    return out_len.value
 
 
 # ---- .7z container front-end (include/xlz.h: xlz_7z_index / xlz_7z_decode) -------------------

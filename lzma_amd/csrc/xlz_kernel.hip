@@ -805,13 +805,65 @@ __device__ __forceinline__ void set_unpack_size(Dec &d, uint64_t u)
 
 // ---- LZMA2 framing (reader2.go:100-298), one wave walking the chunks of a unit ----
 // stored chunk body: window.ReadFrom + ReadPending (reader2.go:252-294, window.go:142-155)
+// This is the one sub-path that is a plain copy, i.e. bound by HBM and not by a dependent chain (the shape of
+// randomfile.dat.lzma2, reader2_test.go:31-36): 16 bytes per lane and kStoredGroups groups per lane in flight, 4 KiB per wave
+// and step.  The destination is brought to a 16-byte boundary first; the source then sits at any byte offset, so a group is
+// five ALIGNED dwords funnelled together with v_alignbyte (the shift is wave-uniform) -- no unaligned access, at most 4 bytes
+// read behind the chunk (the input window's own 256-byte loads read further, kArenaTailPad).  Lanes past the end repeat the
+// last byte / group: same address, same value, no divergent branch.
+struct __attribute__((aligned(4))) StoredQuad { uint32_t x, y, z, w; };
+#ifndef XLZ_STORED_GROUPS
+#define XLZ_STORED_GROUPS 4
+#endif
+constexpr uint32_t kStoredGroups = XLZ_STORED_GROUPS;
+
 __device__ __forceinline__ void stored_copy(const uint8_t *__restrict__ src, uint8_t *__restrict__ out, uint32_t pos,
                                             uint32_t n, uint32_t lane)
 {
-    // 64 bytes per step; lanes past the end re-copy the last byte (no divergent branch)
-    for (uint32_t base = 0; base < n; base += kWave) {
-        const uint32_t i = min(base + lane, n - 1);
-        out[pos + i] = src[i];
+    uint8_t *__restrict__ dst = out + pos;
+    const uint32_t head = min((uint32_t)(0 - (uint32_t)(uintptr_t)dst) & 15u, n);
+    if (head) {
+        const uint32_t i = min(lane, head - 1);
+        dst[i] = src[i];
+    }
+    const uint32_t groups = (n - head) >> 4;
+    if (groups) {
+        const uint8_t *s0 = src + head;
+        const uint32_t sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)s0 & 3u));
+        const uint8_t *sa = s0 - sh; // dword-aligned
+        uint8_t *d0 = dst + head;    // 16-byte-aligned
+        for (uint32_t base = 0; base < groups; base += kWave * kStoredGroups) {
+            StoredQuad q[kStoredGroups];
+            uint32_t e[kStoredGroups], g[kStoredGroups];
+#pragma unroll
+            for (uint32_t u = 0; u < kStoredGroups; u++) {
+                g[u] = min(base + u * kWave + lane, groups - 1);
+                const uint8_t *p = sa + (size_t)g[u] * 16;
+                q[u] = *(const StoredQuad *)p;
+                e[u] = *(const uint32_t *)(p + 16);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kStoredGroups; u++) {
+                uint4 o;
+                o.x = __builtin_amdgcn_alignbyte(q[u].y, q[u].x, sh);
+                o.y = __builtin_amdgcn_alignbyte(q[u].z, q[u].y, sh);
+                o.z = __builtin_amdgcn_alignbyte(q[u].w, q[u].z, sh);
+                o.w = __builtin_amdgcn_alignbyte(e[u], q[u].w, sh);
+#ifdef XLZ_STORED_NT
+                __builtin_nontemporal_store(o.x, (uint32_t *)(d0 + (size_t)g[u] * 16));
+                __builtin_nontemporal_store(o.y, (uint32_t *)(d0 + (size_t)g[u] * 16) + 1);
+                __builtin_nontemporal_store(o.z, (uint32_t *)(d0 + (size_t)g[u] * 16) + 2);
+                __builtin_nontemporal_store(o.w, (uint32_t *)(d0 + (size_t)g[u] * 16) + 3);
+#else
+                *(uint4 *)(d0 + (size_t)g[u] * 16) = o;
+#endif
+            }
+        }
+    }
+    const uint32_t done = head + (groups << 4);
+    if (n > done) {
+        const uint32_t i = done + min(lane, n - done - 1);
+        dst[i] = src[i];
     }
 }
 
