@@ -318,7 +318,8 @@ def roofline(name, cin, cout, units, kernel_ms, occ=None, lone=None):
     issue.update(issue_bounds(prof, cout, kernel_ms, lone, occ["slots"] if occ else None))
     if prof:
         r["traffic_from_profile"] = {"source": prof["source"], "kernel_rev": prof["kernel_rev"],
-                                     "fetch": prof["fetch_bytes_per_launch_raw"], "write": prof["write_bytes_per_launch"]}
+                                     "fetch": prof["fetch_bytes_per_launch_raw"], "write": prof["write_bytes_per_launch"],
+                                     "fetch_correction": prof.get("fetch_correction", 1)}
         if "issue" in prof:  # SQ instruction counters of the committed profile, per CU cycle
             issue["from_profile"] = prof["issue"]
     if issue:

@@ -394,7 +394,7 @@ int decode_folders(xlz_ctx *ctx, const uint8_t *file, const std::vector<xlz_7z_f
         size_t nu = 0;
         std::vector<int> bad(fo.size(), 0);
         const unsigned hw = std::thread::hardware_concurrency();
-        const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(hw ? hw : 1, 8), fo.size()));
+        const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(hw ? hw : 1, 16), fo.size()));
         auto work = [&](unsigned t) {
             for (size_t i = t; i < fo.size(); i += nth) {
                 const xlz_7z_folder &f = fo[i];

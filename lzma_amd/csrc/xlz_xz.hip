@@ -243,7 +243,7 @@ extern "C" int xlz_xz_decode(xlz_ctx *ctx, const uint8_t *file, size_t len, uint
     if (verify) {
         std::vector<int> bad(nb, 0);
         const unsigned hw = std::thread::hardware_concurrency();
-        const unsigned nth = (unsigned)std::min<size_t>(std::max<size_t>(1, std::min<unsigned>(hw ? hw : 1, 8)), std::max<size_t>(nb, 1));
+        const unsigned nth = (unsigned)std::min<size_t>(std::max<size_t>(1, std::min<unsigned>(hw ? hw : 1, 16)), std::max<size_t>(nb, 1));
         auto work = [&](unsigned t) {
             for (size_t i = t; i < nb; i += nth) {
                 const uint8_t *p = out + blk[i].uncomp_off;

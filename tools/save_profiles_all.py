@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import save_profile as SP
 
 KERNEL = "xlz::xlz_decode_kernel("
+WIDE_READS = {"cfg4-R"}   # configs whose launch is the stored-chunk copy: 16-byte-per-lane streaming reads (FETCH_SIZE x 2)
 
 
 def parse_command(text):
@@ -114,7 +115,7 @@ def main():
             w = csv.writer(g)
             w.writerow(SP.PMC_HEADER)
             w.writerows(rows_by[name])
-        entry = SP.make_entry(workload, rev, decoded, kernel_ms, grid_by[name], vals_by[name], pre)
+        entry = SP.make_entry(workload, rev, decoded, kernel_ms, grid_by[name], vals_by[name], pre, wide_reads=name in WIDE_READS)
         SP.register(name, entry)
         vals = vals_by[name]
         with open(pre + "_summary.md", "w") as g:
@@ -139,9 +140,15 @@ def main():
                 p("| %s | %.6g | %d |" % (k, sum(v) / len(v), len(v)))
             f = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]) * 1024
             wr = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"]) * 1024
-            p("\nHBM traffic per launch: FETCH_SIZE %.3f GB (raw, KiB units x1024; gfx950 reports half of wide streaming reads -- "
-              "the LZMA paths' reads are byte/dword gathers, uncalibrated; the stored-chunk copy of cfg4-R reads 16 bytes per lane), "
-              "WRITE_SIZE %.3f GB; algorithmic bytes per launch %.3f GB." % (f / 1e9, wr / 1e9, algo / 1e9))
+            if name in WIDE_READS:
+                p("\nHBM traffic per launch: FETCH_SIZE %.3f GB raw (KiB units x1024) = %.3f GB after the gfx950 correction (x 2: this "
+                  "launch is the stored-chunk copy, 16-byte-per-lane streaming reads; the corrected figure equals the compressed bytes "
+                  "the launch reads once), WRITE_SIZE %.3f GB; algorithmic bytes per launch %.3f GB."
+                  % (f / 1e9, 2 * f / 1e9, wr / 1e9, algo / 1e9))
+            else:
+                p("\nHBM traffic per launch: FETCH_SIZE %.3f GB (raw, KiB units x1024; gfx950 reports half of wide streaming reads -- "
+                  "this config's reads are byte / dword gathers, uncalibrated), WRITE_SIZE %.3f GB; algorithmic bytes per launch "
+                  "%.3f GB." % (f / 1e9, wr / 1e9, algo / 1e9))
         print("%-10s kernel_ms %.3f  fetch %.2f GB  write %.2f GB  algorithmic %.2f GB" % (name, kernel_ms, f / 1e9, wr / 1e9, algo / 1e9))
 
 
