@@ -271,14 +271,16 @@ def profile_for(name):
 SALU_PER_CU_CYCLE, VALU_PER_CU_CYCLE, CUS, CLOCK_HZ = 0.97, 1.28, 256, 2.4e9
 
 
-def issue_bounds(prof, out_bytes_per_launch, kernel_ms, lone, slots):
+def issue_bounds(prof, out_bytes_per_launch, kernel_ms, lone, slots, algo_bytes_per_launch=None):
     """The two bounds this kernel really runs against (the HBM roof is three orders of magnitude away):
       issue_bound    the CU's instruction ports: per decoded byte the kernel issues s scalar and v vector instructions
                      (SQ counters of the committed profile of THIS build and config), a CU issues at most 0.97 / 1.28 of
                      them per cycle -> CUs x clock / max(s / 0.97, v / 1.28) bytes per second;
       latency_bound  one wave's serial dependent chain: the rate of a LONE wave on this data (a live 64-unit launch, one
                      wave on 64 of 1024 SIMDs: nothing competes for issue) x the wave slots of the full launch.
-    frac_of_bound = achieved / min(both).  The kernel sits at the knee of the two with 16 waves per CU."""
+      hbm_bound      the contract's roof expressed in decoded bytes: 8 TB/s x decoded / algorithmic bytes.  Three orders of
+                     magnitude away for the LZMA paths; THE bound of a launch of stored LZMA2 chunks (cfg4-R: a plain copy).
+    frac_of_bound = achieved / min(all).  The LZMA kernel sits at the knee of the first two with 16 waves per CU."""
     achieved = out_bytes_per_launch / (kernel_ms / 1e3)
     r = {"achieved_decoded_GBps": round(achieved / 1e9, 3)}
     bounds = []
@@ -299,9 +301,17 @@ def issue_bounds(prof, out_bytes_per_launch, kernel_ms, lone, slots):
         r["latency_bound_GBps"] = round(lb / 1e9, 3)
         r["latency_bound_from"] = dict(lone, wave_slots=slots)
         bounds.append(lb)
+    names = (["issue"] if "issue_bound_GBps" in r else []) + (["latency"] if "latency_bound_GBps" in r else [])
+    if algo_bytes_per_launch:
+        hb = HBM_PEAK_GBS * 1e9 * out_bytes_per_launch / algo_bytes_per_launch
+        r["hbm_bound_GBps"] = round(hb / 1e9, 3)
+        bounds.append(hb)
+        names.append("hbm")
     if bounds:
-        r["frac_of_bound"] = round(achieved / min(bounds), 4)
-        r["binding"] = "issue" if len(bounds) == 2 and bounds[0] <= bounds[1] else ("latency" if len(bounds) == 2 else "only one bound known")
+        k = min(range(len(bounds)), key=lambda j: bounds[j])
+        r["frac_of_bound"] = round(achieved / bounds[k], 4)
+        r["binding"] = names[k]
+        r["bounds_known"] = names
     return r
 
 
@@ -315,7 +325,7 @@ def roofline(name, cin, cout, units, kernel_ms, occ=None, lone=None):
          "kernel": "xlz::xlz_decode_kernel", "kernel_ms": round(kernel_ms, 3),
          "algorithmic_bytes_per_launch": algo, "units_per_launch": units}
     issue = dict(occ) if occ else {}
-    issue.update(issue_bounds(prof, cout, kernel_ms, lone, occ["slots"] if occ else None))
+    issue.update(issue_bounds(prof, cout, kernel_ms, lone, occ["slots"] if occ else None, algo))
     if prof:
         r["traffic_from_profile"] = {"source": prof["source"], "kernel_rev": prof["kernel_rev"],
                                      "fetch": prof["fetch_bytes_per_launch_raw"], "write": prof["write_bytes_per_launch"],

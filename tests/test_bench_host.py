@@ -88,3 +88,8 @@ def test_issue_bounds_arithmetic():
     assert abs(r["latency_bound_GBps"] - 6e6 * 4096 / 1e9) < 0.01
     assert r["binding"] == "latency" and 0 < r["frac_of_bound"] < 1
     assert bench.issue_bounds(None, 1 << 30, 100.0, None, None) == {"achieved_decoded_GBps": round((1 << 30) / 0.1 / 1e9, 3)}
+    # a launch of stored chunks (a plain copy): the HBM roof in decoded bytes (8 TB/s x decoded / algorithmic) is what binds
+    r = bench.issue_bounds({"issue": {"salu_per_decoded_byte": 0.005, "valu_per_decoded_byte": 0.02}}, 1 << 30, 0.53,
+                           {"bytes_per_s_per_wave": 9e9}, 4096, 2 * (1 << 30) + 1000)
+    assert r["binding"] == "hbm" and abs(r["hbm_bound_GBps"] - 4000.0) < 1 and 0.4 < r["frac_of_bound"] < 0.6
+    assert r["bounds_known"] == ["issue", "latency", "hbm"]
