@@ -429,6 +429,45 @@ def test_lzma2_runs_of_stored_chunks_split_at_their_dictionary_resets(ctx):
     assert e2 is None and out == want
 
 
+def test_stored_chunks_of_every_length_and_alignment(ctx):
+    """The stored-chunk copy moves 16 bytes per lane between an ALIGNED destination and a source at any byte offset
+    (xlz_kernel.hip: stored_copy -- head bytes, 16-byte groups funnelled from aligned dwords, tail bytes).  Streams made
+    of stored chunks of 1 .. 65 536 bytes in shuffled order put every (source mod 4, destination mod 16, length mod 16)
+    combination in front of it, inside units (dictionary resets) and across them; plus an output capacity that ends
+    inside a chunk and sources cut short inside a chunk (window.ReadFrom delivers what is there, window.go:142-155)."""
+    import random
+    from lzma_craft import lzma2_stored
+    lens = [1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 18, 19, 31, 32, 33, 47, 48, 49, 63, 64, 65, 66, 100, 127, 128, 129, 255, 256, 257,
+            1023, 1024, 1025, 4093, 4096, 4099, 16383, 16385, 65535, 65536]
+    blobs, caps = [], []
+    for k in range(12):
+        rng = random.Random(9000 + k)
+        order = lens * 2
+        rng.shuffle(order)
+        data = corpus.plain("R", 9100 + k, sum(order))
+        blob, pos = b"", 0
+        for j, n in enumerate(order):
+            blob += lzma2_stored(data[pos:pos + n], dict_reset=(j == 0 or rng.random() < 0.15))
+            pos += n
+        blob += b"\x00"
+        blobs.append(blob)
+        caps.append(len(data))
+        if k % 3 == 1:   # the capacity ends inside a chunk (ERR_OUT_CAP after the bytes that fit)
+            blobs.append(blob)
+            caps.append(len(data) - rng.randrange(1, 70000))
+        if k % 3 == 2:   # the source ends inside a chunk
+            blobs.append(blob[: len(blob) - rng.randrange(2, 60000)])
+            caps.append(len(data))
+    got = _check_lzma2(ctx, blobs, [1 << 16] * len(blobs), caps)
+    assert got[0][1] == 0 and len(got[0][0]) == caps[0]
+    # the same through pull readers (sessions: the destination is a sliding device window)
+    for blob in blobs[:3]:
+        want = oracle.lzma2_raw(blob, 1 << 16, 8 << 20)
+        r, err = lzma_amd.NewReader2(ctx, blob, 1 << 16)
+        out, e2 = r.read_all(chunk=33_333)
+        assert e2 is None and out == want[0]
+
+
 # ------------------------------------------- BASELINE-sized batches: size-independent properties ----
 def test_baseline_shape_roundtrip_and_idempotence(ctx):
     """4096 streams (the stream count of BASELINE config 2; 64 KiB each so the corpus builds in
