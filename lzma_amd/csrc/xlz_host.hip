@@ -34,6 +34,9 @@ constexpr uint32_t kLzmaDicMin = 1u << 12;        // types.go:8
 constexpr uint64_t kUnknownSize = ~(uint64_t)0;   // state.go:135-151
 constexpr uint64_t kMaxUnitBytes = 0xFFFF0000ull; // 32-bit offsets inside a unit
 constexpr size_t kArenaAlign = 256;
+constexpr size_t kStoredUnitBytes = 256 * 1024; // scan_lzma2: a run of stored chunks is cut into units of at least this much (four
+                                               // or five of liblzma's chunks: finer units cost a launch of such units more in
+                                               // per-unit work than their evener tail gives back, profiles/r03/ab_stored_unit.txt)
 constexpr size_t kArenaTailPad = 1024; // the 256-byte input window may start near a unit's end
 constexpr size_t kOutTailPad = 64;    // wave_copy stores whole 64-lane rows: scratch bytes past a unit's end
 
@@ -366,6 +369,17 @@ struct Lz2Unit {
     bool have_reader; // an LZMA chunk precedes the unit: Reader2.lzmaReader exists (reader2.go:146-153)
 };
 
+// bytes a unit made of stored chunks alone should hold at least (XLZ_STORED_UNIT_KIB: development knob, 0 = cut runs of
+// stored chunks at dictionary resets only)
+uint64_t stored_unit_bytes()
+{
+    static const uint64_t v = [] {
+        const char *e = getenv("XLZ_STORED_UNIT_KIB");
+        return e ? (uint64_t)strtoull(e, nullptr, 10) << 10 : (uint64_t)kStoredUnitBytes;
+    }();
+    return v;
+}
+
 void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint32_t &max_lc_lp)
 {
     size_t pos = 0, unit_start = 0;
@@ -382,6 +396,18 @@ void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint
         bool seen_lzma;
     };
     std::vector<Cand> cands;
+    // Inside a run of stored chunks that nothing behind it reads -- the run ends at the next dictionary reset or at the
+    // end of the stream -- EVERY chunk boundary can start a unit: a stored chunk reads no history (window.ReadFrom,
+    // window.go:142-155) and leaves nothing but window bytes behind, which only a later LZMA chunk WITHOUT a
+    // dictionary reset could look at.  `marks` = the stored chunks behind the first pending candidate that do not reset
+    // the dictionary themselves; a pure run is cut at them whenever kStoredUnit bytes have gathered (one incompressible
+    // file inside one LZMA2 stream is then copied by thousands of waves, not by one).
+    struct Mark {
+        size_t pos;
+        uint64_t out;
+    };
+    std::vector<Mark> marks;
+    const uint64_t stored_unit = stored_unit_bytes();
     bool seen_lzma = false, unit_seen_lzma = false; // an LZMA chunk before: here / the unit
     auto cut = [&](size_t at, uint64_t at_out, bool lzma_before) {
         units.push_back({(uint32_t)unit_start, (uint32_t)(at - unit_start), unit_out, at_out - unit_out, unit_seen_lzma});
@@ -389,10 +415,21 @@ void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint
         unit_out = at_out;
         unit_seen_lzma = lzma_before;
     };
-    auto cut_at_candidates = [&] {
-        for (const Cand &c : cands)
+    // last_pure: the run behind the LAST candidate ends here too (end of the stream, or an LZMA chunk that resets the
+    // dictionary); otherwise an LZMA chunk that keeps the dictionary follows it and must find the run in its own unit
+    auto cut_at_candidates = [&](bool last_pure) {
+        size_t mi = 0;
+        for (size_t i = 0; i < cands.size(); i++) {
+            const Cand &c = cands[i];
             if (c.pos != unit_start) cut(c.pos, c.out, c.seen_lzma);
+            const size_t region_end = i + 1 < cands.size() ? cands[i + 1].pos : (size_t)-1;
+            const bool pure = i + 1 < cands.size() || last_pure;
+            for (; mi < marks.size() && marks[mi].pos < region_end; mi++)
+                if (pure && stored_unit && marks[mi].pos > c.pos && marks[mi].out - unit_out >= stored_unit)
+                    cut(marks[mi].pos, marks[mi].out, c.seen_lzma);
+        }
         cands.clear();
+        marks.clear();
     };
     bool ended = false; // the walk reached the end of the stream (or of the input) without leaving the format
     while (pos < len) {
@@ -409,7 +446,10 @@ void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint
         uint32_t unc = ((uint32_t)in[pos + 1] << 8) | in[pos + 2];
         if (stored) {
             unc += 1;
-            if (c == 1 && pos != 0) cands.push_back({pos, out, seen_lzma});
+            if (c == 1 || pos == 0) // (the stream's first chunk starts a unit anyway: a candidate that is never a cut)
+                cands.push_back({pos, out, seen_lzma});
+            else if (!cands.empty())
+                marks.push_back({pos, out});
             const size_t body = std::min<size_t>(unc, len - pos - hl);
             pos += hl + body;
             out += body;
@@ -422,18 +462,19 @@ void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint
             if (props >= 225) break; // the walker reports ErrIncorrectProperties here
             max_lc_lp = std::max<uint32_t>(max_lc_lp, (props % 9) + (props / 9) % 5);
             if (sub == 7 && pos != 0 && pos != unit_start) {
-                cut_at_candidates();
+                cut_at_candidates(true);
                 if (pos != unit_start) cut(pos, out, seen_lzma);
             } else {
-                cut_at_candidates();
+                cut_at_candidates(sub == 7);
             }
         }
         seen_lzma = true;
         cands.clear(); // a compressed chunk without new props keeps the model: no cut
+        marks.clear();
         pos += hl + std::min(comp, len - pos - hl);
         out += unc;
     }
-    if (ended || pos >= len) cut_at_candidates(); // only stored chunks behind them
+    if (ended || pos >= len) cut_at_candidates(true); // only stored chunks behind them
     units.push_back({(uint32_t)unit_start, (uint32_t)(len - unit_start), unit_out, out - unit_out, unit_seen_lzma});
 }
 

@@ -381,6 +381,20 @@ def test_lzma2_many_small_units_share_one_output_range(ctx):
         assert got[0][0] == want
 
 
+def _stored_units(blob, unit=256 << 10):
+    """units of an LZMA2 stream made of stored chunks alone, by scan_lzma2's rule: a cut at every chunk that resets the
+    dictionary and at every other chunk once `unit` bytes have gathered since the last cut"""
+    pos, units, acc = 0, 1, 0
+    while blob[pos] in (1, 2):
+        n = ((blob[pos + 1] << 8) | blob[pos + 2]) + 1
+        if pos and (blob[pos] == 1 or acc >= unit):
+            units, acc = units + 1, 0
+        acc += n
+        pos += 3 + n
+    assert blob[pos] == 0
+    return units
+
+
 def test_lzma2_runs_of_stored_chunks_split_at_their_dictionary_resets(ctx):
     """The shape of the reference's own LZMA2 benchmark file (randomfile.dat.lzma2, reader2_test.go:31-36): stored
     chunks only.  A stored chunk that resets the dictionary may start a unit when no LZMA chunk behind it continues an
@@ -397,7 +411,9 @@ def test_lzma2_runs_of_stored_chunks_split_at_their_dictionary_resets(ctx):
     res = b.results()
     assert res[0][0] == len(want) and res[0][1] == 0 and res[0][2] == len(blob)
     assert b.download(0, len(want)) == want
-    assert b.stats()[2] == 60                                       # units
+    # units: a run of stored chunks that nothing reads is cut at every dictionary reset (and wherever 256 KiB have gathered:
+    # never inside these 70 KB segments)
+    assert b.stats()[2] == _stored_units(blob) == 60
     b.close()
     # mixed: text segments (0xE0 chunks), stored runs, and a crafted tail whose 0x80 chunk (no new properties) follows
     # a stored reset: that candidate must NOT become a cut (the chunk continues the model of the chunks before)
@@ -466,6 +482,71 @@ def test_stored_chunks_of_every_length_and_alignment(ctx):
         r, err = lzma_amd.NewReader2(ctx, blob, 1 << 16)
         out, e2 = r.read_all(chunk=33_333)
         assert e2 is None and out == want[0]
+
+
+def test_runs_of_stored_chunks_are_cut_at_every_chunk_unless_a_later_chunk_reads_them(ctx):
+    """scan_lzma2: inside a run of stored chunks that ends at a dictionary reset or at the end of the stream every chunk
+    boundary may start a unit (a stored chunk reads no history, window.go:142-155): ONE incompressible stream -- 0x01 once,
+    then 0x02 chunks, what xz writes for a random file -- is copied by a wave per 256 KiB.  An LZMA chunk that keeps the
+    dictionary (0xC0: new properties, state reset, NO dictionary reset) reads the stored bytes in front of it through its
+    matches: its run must stay in its unit.  All against the oracle; the unit counts say which cut was made."""
+    from lzma_craft import Encoder, Window, lzma2_lzma_chunk, lzma2_stored, props_byte
+    data = corpus.plain("R", 7700, 1_000_003)
+    chunks = [data[i:i + 65536] for i in range(0, len(data), 65536)]
+    pure = b"".join(lzma2_stored(c, dict_reset=(j == 0)) for j, c in enumerate(chunks)) + b"\x00"
+    b = lzma_amd.Batch(ctx, [Stream(pure, FMT_LZMA2_RAW, out_cap=len(data), dict_size=1 << 16)])
+    b.run()
+    res = b.results()
+    assert res[0] == (len(data), 0, len(pure)) and b.download(0, len(data)) == data
+    assert len(chunks) == 16 and b.stats()[2] == _stored_units(pure) == 4   # a cut wherever 256 KiB have gathered
+    b.close()
+    # stored run, then an LZMA chunk WITHOUT dictionary reset whose matches copy stored bytes from up to 65 000 back
+    w = Window(1 << 16)
+    head = data[:600_000]
+    blob = b""
+    for j in range(0, len(head), 65536):
+        blob += lzma2_stored(head[j:j + 65536], dict_reset=(j == 0))
+    for x in head:
+        w.put(x)
+    e = Encoder(3, 0, 2, 1 << 16, window=w)
+    n0 = len(w.total)
+    e.match(65_000, 273)
+    e.match(40_000, 100)
+    for i in range(40):
+        e.literal(48 + i % 10)
+    e.match(65_536, 17)
+    e.rep(1, 30)
+    kept = blob + lzma2_lzma_chunk(0xC0, len(w.total) - n0, e.payload(), props_byte(3, 0, 2)) + b"\x00"
+    want = bytes(w.total)
+    o = oracle.lzma2_raw(kept, 1 << 16, len(want) + 100)
+    assert o[1] == 0 and o[0] == want
+    b = lzma_amd.Batch(ctx, [Stream(kept, FMT_LZMA2_RAW, out_cap=len(want), dict_size=1 << 16)])
+    b.run()
+    assert b.results()[0] == (len(want), 0, len(kept)) and b.download(0, len(want)) == want
+    assert b.stats()[2] == 1                       # the run is read by the chunk behind it: one unit
+    b.close()
+    # the same run in front of a chunk that DOES reset the dictionary (0xE0), and a second pure run behind that chunk
+    e2 = Encoder(3, 0, 2, 1 << 16)
+    for i in range(300):
+        e2.literal(97 + i % 13)
+    e2.match(200, 60)
+    tail_data = corpus.plain("R", 7701, 150_000)
+    cut = blob + lzma2_lzma_chunk(0xE0, 360, e2.payload(), props_byte(3, 0, 2))
+    for j in range(0, len(tail_data), 65536):
+        cut += lzma2_stored(tail_data[j:j + 65536], dict_reset=(j == 0))
+    cut += b"\x00"
+    o = oracle.lzma2_raw(cut, 1 << 16, 1 << 20)
+    assert o[1] == 0 and o[0][:600_000] == head and o[0][600_360:] == tail_data
+    got = _check_lzma2(ctx, [pure, kept, cut], [1 << 16] * 3, [len(data), len(want), len(o[0])])
+    assert got[2][0] == o[0]
+    b = lzma_amd.Batch(ctx, [Stream(cut, FMT_LZMA2_RAW, out_cap=len(o[0]), dict_size=1 << 16)])
+    b.run()
+    assert b.results()[0][1] == 0 and b.stats()[2] == 3 + 1 + 1   # ten stored chunks in three units, the LZMA chunk, the run behind it
+    b.close()
+    # readers: the parallel refill path takes the finer units too
+    r, err = lzma_amd.NewReader2(ctx, pure, 1 << 16)
+    out, e3 = r.read_all(chunk=77_777)
+    assert e3 is None and out == data
 
 
 # ------------------------------------------- BASELINE-sized batches: size-independent properties ----

@@ -70,7 +70,11 @@ def test_sessions_move_their_input_and_output_windows(ctx, case):
         r, err = lzma_amd.NewReader1(ctx, corpus.compress_alone(p, dict_size=1 << 16, preset=0))
     elif case == "lzma2-random-9MiB":
         p = corpus.plain("R", 6002, 9 << 20)   # stored chunks only, like randomfile.dat.lzma2
-        r, err = lzma_amd.NewReader2(ctx, corpus.compress_raw_lzma2(p, dict_size=1 << 16, preset=0), 1 << 16)
+        blob = corpus.compress_raw_lzma2(p, dict_size=1 << 16, preset=0)
+        # (from a file object, in pieces: with the whole stream at hand a run of stored chunks is a batch of units of its
+        #  own -- test_a_stored_stream_at_hand_is_read_through_parallel_units -- and the session's windows never move)
+        import io
+        r, err = lzma_amd.NewReader2(ctx, io.BytesIO(blob), 1 << 16, piece=1 << 20)
     elif case == "lzma2-text-24MiB":
         p = corpus.plain("M", 6003, 24 << 20)  # compressed chunks and stored chunks mixed, ~16 MiB of input
         r, err = lzma_amd.NewReader2(ctx, corpus.compress_raw_lzma2(p, dict_size=1 << 20, preset=0), 1 << 20)
@@ -94,6 +98,21 @@ def test_sessions_move_their_input_and_output_windows(ctx, case):
     assert h.digest() == hashlib.sha256(p).digest()
     refills, whole, _ = r.stats()
     assert whole == 0 and refills >= len(p) >> 20
+
+
+def test_a_stored_stream_at_hand_is_read_through_parallel_units(ctx):
+    """NewReader2 on ONE stream of stored chunks (what xz writes for an incompressible file: 0x01 once, then 0x02 chunks)
+    whose bytes are all at hand: the host scan cuts the run at its chunks (nothing behind them reads the window), so the
+    refills decode runs of whole units through the batch path -- a wave per chunk -- instead of walking 9 MiB with one
+    wave: two refills (64 MiB of output at most each would be one; the first announces the plan), no whole-stream decode."""
+    p = corpus.plain("R", 6002, 9 << 20)
+    blob = corpus.compress_raw_lzma2(p, dict_size=1 << 16, preset=0)
+    r, err = lzma_amd.NewReader2(ctx, blob, 1 << 16)
+    assert err is None
+    out, e = r.read_all(chunk=1 << 20)
+    assert e is None and out == p
+    refills, whole, _ = r.stats()
+    assert whole == 0 and refills <= 3
 
 
 def test_reader_errors_arrive_after_the_bytes_before_them(ctx):
