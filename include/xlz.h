@@ -147,7 +147,8 @@ typedef struct xlz_call_stats {
     double kernel_span_ms; /* first wave's start to last wave's end of the main launch (device clock) */
     double slot_occupancy; /* busy wave time / (wave_slots x kernel span): 1.0 = every slot busy throughout */
     uint64_t streams;      /* n of the call                                                          */
-    uint64_t units;        /* work units of the main launch (streams; LZMA2: dictionary-reset units) */
+    uint64_t units;        /* work units of the main launch (streams; LZMA2: dictionary-reset units and
+                              256 KiB pieces of runs of stored chunks)                               */
     uint32_t wave_slots;   /* resident single-wave workgroups of the launch                          */
     uint32_t sub_batches;  /* > 1: the call ran as a pipeline (upload k+1 / decode k / download k-1); then
                               upload_ms = until the first sub-batch was on the device, decode_ms = first
