@@ -256,6 +256,23 @@ int xlz_reader_stats(const xlz_reader *r, uint64_t *refills, uint64_t *whole_dec
 int xlz_decode_batch_multi(xlz_ctx *const *ctxs, size_t n_ctx, const xlz_stream_desc *streams,
                            size_t n, xlz_result *results);
 
+/* ---- the unit plan of a raw LZMA2 stream (host only, no GPU needed) ------------------------
+ * What a decode of `in` as XLZ_FMT_LZMA2_RAW launches: the stream is cut where a chunk starts
+ * that depends on nothing before it (Reader2.startChunk, reader2.go:100-173: a dictionary reset
+ * with new properties; a stored chunk that resets the dictionary when no LZMA chunk behind it
+ * continues an earlier model; every 256 KiB inside a run of stored chunks that ends at a dictionary
+ * reset or at the end of the stream) -- one wave per unit.  Fills at most `max_units` entries,
+ * *n_units = the number of units (XLZ_ERR_OUT_CAP when larger than max_units > 0; pass
+ * max_units = 0 to count).  Offsets are trusted from the chunk headers: a stream whose real
+ * decode leaves them is decoded again as ONE unit after the launch.                          */
+typedef struct xlz_lzma2_unit {
+    uint64_t in_off, in_len;   /* bytes of `in` the unit walks                                   */
+    uint64_t out_off, out_len; /* where its output goes and how much its headers announce        */
+    uint32_t have_reader;      /* an LZMA chunk precedes it in the stream (Reader2.lzmaReader)   */
+    uint32_t reserved;
+} xlz_lzma2_unit;
+int xlz_lzma2_units(const uint8_t *in, size_t len, xlz_lzma2_unit *units, size_t max_units, size_t *n_units);
+
 /* ---- .xz container front-end ----------------------------
  * Outside the reference (which has no container code): an .xz file is a list of independent
  * blocks, each ONE raw LZMA2 stream with its own dictionary -- what NewReader2(in, dictSize)

@@ -443,6 +443,21 @@ def NewLZMA2DecompressorForSevenZip(ctx, props, unpack_size, readers):
     return _sevenzip(N.lib().xlz_new_lzma2_decompressor_for_sevenzip, ctx, props, unpack_size, readers)
 
 
+def lzma2_units(data):
+    """The unit plan of a raw LZMA2 stream (xlz_lzma2_units; host only): list of dicts (in_off, in_len, out_off,
+    out_len, have_reader) -- what a decode of `data` as FMT_LZMA2_RAW launches, one wave per unit."""
+    data = bytes(data)
+    n = ctypes.c_size_t()
+    st = N.lib().xlz_lzma2_units(data, len(data), None, 0, ctypes.byref(n))
+    if st != OK:
+        raise LzmaError(st, "xlz_lzma2_units")
+    units = (N.Lzma2Unit * max(n.value, 1))()
+    st = N.lib().xlz_lzma2_units(data, len(data), units, n.value, ctypes.byref(n))
+    if st != OK:
+        raise LzmaError(st, "xlz_lzma2_units")
+    return [{f: getattr(units[k], f) for f, _ in N.Lzma2Unit._fields_ if f != "reserved"} for k in range(n.value)]
+
+
 # ---- .xz container front-end (include/xlz.h: xlz_xz_index / xlz_xz_decode) -------------------
 def xz_index(data):
     """Block index of an .xz file: list of dicts (comp_off, comp_len, uncomp_off, uncomp_len,

@@ -45,6 +45,7 @@ EXPORTS = [
     "xlz_new_lzma_decompressor_for_sevenzip", "xlz_new_lzma2_decompressor_for_sevenzip",
     "xlz_reader_read", "xlz_reader_close", "xlz_reader_free", "xlz_xz_index", "xlz_xz_decode",
     "xlz_decode_batch_multi", "xlz_batch_unit_trace", "xlz_reader_stats", "xlz_batch_launch_info", "xlz_reader_reset", "xlz_reader_reopen", "xlz_reader_expect_more", "xlz_reader_feed", "xlz_reader_feed_eof", "xlz_7z_index", "xlz_7z_decode",
+    "xlz_lzma2_units",
 ]
 
 
@@ -87,6 +88,17 @@ class XzBlock(ctypes.Structure):
         ("check_off", ctypes.c_uint64),
         ("dict_size", ctypes.c_uint32),
         ("check_type", ctypes.c_uint32),
+    ]
+
+
+class Lzma2Unit(ctypes.Structure):
+    _fields_ = [
+        ("in_off", ctypes.c_uint64),
+        ("in_len", ctypes.c_uint64),
+        ("out_off", ctypes.c_uint64),
+        ("out_len", ctypes.c_uint64),
+        ("have_reader", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
     ]
 
 
@@ -184,6 +196,7 @@ def lib():
     L.xlz_batch_unit_trace.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]
     L.xlz_decode_batch_multi.argtypes = [ctypes.POINTER(vp), sz, ctypes.POINTER(StreamDesc), sz, ctypes.POINTER(Result)]
     L.xlz_xz_index.argtypes = [vp, sz, ctypes.POINTER(XzBlock), sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint64)]
+    L.xlz_lzma2_units.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(Lzma2Unit), sz, ctypes.POINTER(sz)]
     L.xlz_7z_index.argtypes = [vp, vp, sz, ctypes.POINTER(SzFolder), sz, ctypes.POINTER(sz), ctypes.POINTER(SzSubstream), sz,
                                ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint64)]
     L.xlz_7z_decode.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(ctypes.c_uint64), i32, ctypes.POINTER(sz)]

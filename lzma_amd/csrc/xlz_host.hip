@@ -478,6 +478,28 @@ void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint
     units.push_back({(uint32_t)unit_start, (uint32_t)(len - unit_start), unit_out, out - unit_out, unit_seen_lzma});
 }
 
+} // namespace
+
+extern "C" int xlz_lzma2_units(const uint8_t *in, size_t len, xlz_lzma2_unit *units, size_t max_units, size_t *n_units)
+{
+    if ((!in && len) || !n_units || (!units && max_units)) return XLZ_ERR_BAD_ARG;
+    std::vector<Lz2Unit> lu;
+    uint32_t mx = 0;
+    scan_lzma2(in, len, lu, mx);
+    *n_units = lu.size();
+    for (size_t k = 0; k < lu.size() && k < max_units; k++) {
+        units[k].in_off = lu[k].in_start;
+        units[k].in_len = lu[k].in_len;
+        units[k].out_off = lu[k].out_start;
+        units[k].out_len = lu[k].expect_out;
+        units[k].have_reader = lu[k].have_reader ? 1u : 0u;
+        units[k].reserved = 0;
+    }
+    return max_units && lu.size() > max_units ? XLZ_ERR_OUT_CAP : XLZ_OK;
+}
+
+namespace {
+
 int batch_free(xlz_batch *b)
 {
     if (!b) return XLZ_OK;

@@ -1,0 +1,135 @@
+"""CPU: the unit plan of a raw LZMA2 stream (xlz_lzma2_units = the host scan scan_lzma2 behind every LZMA2 decode):
+where a stream is cut into units that one wave each decodes concurrently.  A wrong cut is a silent data race on the
+GPU (a unit reading window bytes another unit has not written yet), so the rule is pinned here without a GPU:
+hand-computed plans for the shapes that matter, and two safety invariants on random chunk sequences --
+  (1) history: an LZMA chunk that keeps the dictionary (control < 0xE0) sits in the same unit as every chunk back to
+      the latest dictionary reset in front of it (Reader2.startChunk, reader2.go:100-173; window.go:135-140);
+  (2) model: an LZMA chunk without new properties (control < 0xC0) sits in the same unit as the LZMA chunk before it
+      (the state is carried across chunks, stored ones included, reader2.go:155-167).
+The scan reads chunk HEADERS only, so the payloads here are arbitrary bytes."""
+import random
+
+import lzma_amd
+
+UNIT = 256 << 10
+
+
+def stored(n, reset):
+    return bytes([1 if reset else 2]) + (n - 1).to_bytes(2, "big") + bytes(n)
+
+
+def lzma(ctrl, unc, comp, props=0x5D):
+    u = unc - 1
+    h = bytes([ctrl | (u >> 16), (u >> 8) & 0xFF, u & 0xFF]) + (comp - 1).to_bytes(2, "big")
+    if ctrl >= 0xC0:
+        h += bytes([props])
+    return h + bytes(comp)
+
+
+def plan(chunks):
+    blob = b"".join(chunks) + b"\x00"
+    units = lzma_amd.lzma2_units(blob)
+    # the units tile the input and the output
+    assert units[0]["in_off"] == 0 and units[0]["out_off"] == 0
+    for a, b in zip(units, units[1:]):
+        assert a["in_off"] + a["in_len"] == b["in_off"] and a["out_off"] + a["out_len"] == b["out_off"]
+    assert units[-1]["in_off"] + units[-1]["in_len"] == len(blob)
+    return blob, units
+
+
+def starts(chunks):
+    pos, out = [], 0
+    for c in chunks:
+        pos.append(out)
+        out += len(c)
+    return pos
+
+
+def test_hand_computed_plans():
+    # ONE run of stored chunks, one dictionary reset (what xz writes for an incompressible file): a unit per 256 KiB
+    _, u = plan([stored(65536, j == 0) for j in range(16)])
+    assert [x["out_len"] for x in u] == [UNIT] * 4
+    # liblzma's stored chunks hold a little less than 64 KiB: five of them until 256 KiB have gathered
+    _, u = plan([stored(60_500, j == 0) for j in range(11)])
+    assert [x["out_len"] for x in u] == [5 * 60_500, 5 * 60_500, 60_500]
+    # segments that each reset the dictionary (cfg4-R): a unit per segment, no finer
+    _, u = plan([stored(65536, j % 4 == 0) for j in range(16)])
+    assert [x["out_len"] for x in u] == [UNIT] * 4
+    # a run in front of an LZMA chunk that KEEPS the dictionary (0xC0: new properties, state reset): the chunk's matches
+    # may read the stored bytes -- one unit
+    _, u = plan([stored(65536, j == 0) for j in range(10)] + [lzma(0xC0, 5000, 2000)])
+    assert len(u) == 1
+    # ... in front of one that resets the dictionary (0xE0): the run is cut (256 KiB + 256 KiB + the rest), the chunk
+    # starts a unit, the run behind it is a unit of its own (its first chunk resets the dictionary)
+    _, u = plan([stored(65536, j == 0) for j in range(10)] + [lzma(0xE0, 360, 100)] + [stored(50_000, j == 0) for j in range(3)])
+    assert [x["out_len"] for x in u] == [UNIT, UNIT, 2 * 65536, 360, 150_000]
+    assert [x["have_reader"] for x in u] == [0, 0, 0, 0, 1]
+    # a stored dictionary reset in front of an LZMA chunk WITHOUT new properties: the chunk continues the model of the
+    # LZMA chunk in front of the stored one -- no cut
+    _, u = plan([lzma(0xE0, 9000, 3000), stored(1000, True), lzma(0x80, 700, 300)])
+    assert len(u) == 1
+    # ... with new properties: the model starts over, the stored reset starts a unit
+    _, u = plan([lzma(0xE0, 9000, 3000), stored(1000, True), lzma(0xC0, 700, 300)])
+    assert [x["out_len"] for x in u] == [9000, 1700] and u[1]["have_reader"] == 1
+    # independent segments (cfg4): a unit each
+    _, u = plan([lzma(0xE0, 2000 + k, 900) for k in range(7)])
+    assert len(u) == 7
+    # stored chunks BEHIND an LZMA chunk without a reset of their own stay with it (nothing marks them as a run start)
+    _, u = plan([lzma(0xE0, 9000, 3000)] + [stored(65536, False) for _ in range(12)])
+    assert len(u) == 1
+    # count only
+    n = lzma_amd.ctypes.c_size_t()
+    blob = b"".join(stored(65536, j == 0) for j in range(16)) + b"\x00"
+    assert lzma_amd.N.lib().xlz_lzma2_units(blob, len(blob), None, 0, lzma_amd.ctypes.byref(n)) == 0 and n.value == 4
+    one = (lzma_amd.N.Lzma2Unit * 1)()
+    assert lzma_amd.N.lib().xlz_lzma2_units(blob, len(blob), one, 1, lzma_amd.ctypes.byref(n)) == lzma_amd.ERR_OUT_CAP
+
+
+def test_no_cut_ever_separates_a_chunk_from_what_it_depends_on():
+    rng = random.Random(20261004)
+    for _ in range(3000):
+        chunks, kinds = [], []   # kinds: ("S", reset) / ("L", ctrl)
+        for _ in range(rng.randrange(1, 24)):
+            r = rng.random()
+            if r < 0.55:
+                reset = rng.random() < 0.25
+                n = rng.choice([1, 700, 30_000, 60_500, 65536])
+                chunks.append(stored(n, reset))
+                kinds.append(("S", reset))
+            else:
+                ctrl = rng.choice([0x80, 0x80, 0xA0, 0xC0, 0xE0, 0xE0])
+                chunks.append(lzma(ctrl, rng.randrange(1, 200_000), rng.randrange(1, 40_000)))
+                kinds.append(("L", ctrl))
+        blob, units = plan(chunks)
+        pos = starts(chunks)
+        unit_of = []
+        for p in pos:   # the unit each chunk starts in
+            k = max(j for j, u in enumerate(units) if u["in_off"] <= p)
+            unit_of.append(k)
+        ustarts = {u["in_off"] for u in units}
+        for p in ustarts:
+            assert p in pos, "a unit starts inside a chunk"
+        last_reset, last_lzma = 0, None   # chunk index of the latest dictionary reset / LZMA chunk
+        for i, (k, v) in enumerate(kinds):
+            if (k == "S" and v) or (k == "L" and v == 0xE0) or i == 0:
+                last_reset = i
+            if k == "L":
+                if v < 0xE0:     # (1) keeps the dictionary: its history back to the latest reset is in its unit
+                    assert unit_of[last_reset] == unit_of[i], (kinds, i)
+                if v < 0xC0 and last_lzma is not None:   # (2) keeps the model of the LZMA chunk before it
+                    assert unit_of[last_lzma] == unit_of[i], (kinds, i)
+                last_lzma = i
+            # a unit never starts at a stored chunk that keeps the dictionary unless its run is read by nothing:
+            if i and pos[i] in ustarts and k == "S" and not v:
+                j = i
+                while j < len(kinds) and kinds[j] == ("S", False):
+                    j += 1
+                assert j == len(kinds) or kinds[j] == ("S", True) or kinds[j] == ("L", 0xE0), (kinds, i)
+
+
+def test_damaged_headers_do_not_derail_the_scan():
+    # a truncated header, properties >= 225, an end marker in the middle: the scan stops cutting, the units still tile the input
+    for blob in (stored(65536, True)[:-100], stored(70, True) + b"\x01\x00", lzma(0xE0, 500, 100, props=230) + stored(5, True) + b"\x00",
+                 stored(9, True) + b"\x00" + stored(9, True) + b"\x00", b"", b"\x00", b"\x7f"):
+        units = lzma_amd.lzma2_units(blob)
+        assert units[0]["in_off"] == 0 and sum(u["in_len"] for u in units) == len(blob)
