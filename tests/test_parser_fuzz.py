@@ -22,3 +22,8 @@ def test_mutated_xz_files_parse_or_fail_cleanly(xlz_so):
 def test_mutated_7z_archives_parse_or_fail_cleanly(xlz_so):
     n, ok = _tool().fuzz_7z(3.0, 2026)
     assert n > 1000 and 0 < ok < n
+
+
+def test_lzma2_unit_plans_tile_whatever_the_headers_say():
+    n, units = _tool().fuzz_lzma2_units(3.0, 2026)
+    assert n > 200 and units >= n

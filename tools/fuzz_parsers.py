@@ -1,5 +1,5 @@
-"""Mutation fuzz of the HOST-ONLY container parsers (xlz_xz_index, xlz_7z_index without an encoded header):
-no GPU needed.  Valid .xz files (liblzma) and hand-built .7z archives (tests/sevenzip_craft.py) are truncated,
+"""Mutation fuzz of the HOST-ONLY parsers (xlz_xz_index, xlz_7z_index without an encoded header, xlz_lzma2_units -- the
+chunk-header scan behind every raw LZMA2 decode): no GPU needed.  Valid .xz files (liblzma) and hand-built .7z archives (tests/sevenzip_craft.py) are truncated,
 bit-flipped, overwritten near their ends / inside the 7z end header (its CRCs fixed up so that the parser
 gets that far).  A parse must either fail with a status or describe byte ranges inside the file.
 Under AddressSanitizer (CPU build only; the pool refuses GPU ASan):
@@ -133,8 +133,41 @@ def fuzz_7z(seconds, seed):
     return n, ok
 
 
+def fuzz_lzma2_units(seconds, seed):
+    """-> (inputs, units planned).  Raw LZMA2 streams written by liblzma (text: LZMA chunks; random data: stored chunks;
+    concatenations with dictionary resets) and random chunk-header sequences, mutated: the plan's units must tile the
+    input exactly, whatever the bytes say."""
+    import corpus
+    rnd = random.Random(seed)
+    xs = []
+    for fam, n in (("T", 300_000), ("R", 200_000), ("M", 400_000), ("Z", 100_000)):
+        xs.append(corpus.compress_raw_lzma2(corpus.plain(fam, seed + n, n), dict_size=1 << 16, preset=0))
+    xs.append(corpus.lzma2_concat([corpus.plain("TR"[i % 2], seed + i, 70_000) for i in range(6)], dict_size=1 << 16, preset=0))
+    t_end = time.time() + seconds
+    n = units = 0
+    while time.time() < t_end:
+        if rnd.random() < 0.5:
+            b = bytes(_mutate(rnd, rnd.choice(xs), tail_from=0))
+        else:   # headers only: control bytes of every kind with random sizes, bodies mostly missing
+            b = bytearray()
+            for _ in range(rnd.randrange(1, 12)):
+                c = rnd.choice([0, 1, 2, 3, 0x7F, 0x80, 0x9F, 0xA0, 0xC0, 0xE0, 0xFF, rnd.randrange(256)])
+                b += bytes([c]) + bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 6)))
+                if rnd.random() < 0.3:
+                    b += bytes(rnd.randrange(1, 70000))
+            b = bytes(b)
+        n += 1
+        plan = lzma_amd.lzma2_units(b)
+        assert plan[0]["in_off"] == 0 and sum(u["in_len"] for u in plan) == len(b), (len(b), plan[:3])
+        for u, v in zip(plan, plan[1:]):
+            assert u["in_off"] + u["in_len"] == v["in_off"] and u["out_off"] + u["out_len"] == v["out_off"]
+        units += len(plan)
+    return n, units
+
+
 if __name__ == "__main__":
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     print("xz_index: %d inputs, %d parsed" % fuzz_xz(secs, seed))
     print("7z_index: %d inputs, %d parsed" % fuzz_7z(secs, seed))
+    print("lzma2_units: %d inputs, %d units planned" % fuzz_lzma2_units(secs, seed))
