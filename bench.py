@@ -23,8 +23,8 @@ At N = 1 the same JSON line also carries
     incompressible segments: stored chunks only, the shape of randomfile.dat.lzma2), cfg5 (8192
     streams, lc2/lp1/pb1, 8 MiB dictionary), cfg5-wrap (24 MiB streams whose 8 MiB window wraps).
     All corpora use ONE encoder setting (ENC_FAST) so that the configs can be compared; every config
-    has its own `roofline` (incl. `issue`: the instruction-issue and lone-wave-latency bounds this
-    kernel really runs against) and `cpu_baseline`; every decoded byte is compared with the
+    has its own `roofline` (incl. `issue`: the instruction-issue and lone-wave-latency bounds the LZMA
+    paths really run against, and the HBM roof in decoded bytes, which binds the stored-chunk config) and `cpu_baseline`; every decoded byte is compared with the
     plaintext's SHA-256;
   * `host_to_host`: cfg3 and cfg2-T through xlz_decode_batch -- host buffers in, host buffers out,
     PCIe included, with the phase times (what a Go caller of the drop-in sees; never `value`);
