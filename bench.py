@@ -15,22 +15,29 @@ the MAX of the timed region and a 24-byte SUM of bookkeeping.  value = bytes of 
 max-rank time.  (`--headline cfg3-heavy`: the same batch with 1 MiB per stream, SURVEY 8d's optional
 heavy variant for an 8-GPU node -- 8 x 8192 streams of 64 KiB are only two wave rounds per GPU.)
 
-At N = 1 the same JSON line also carries
+The LAST line of stdout is ONE compact JSON object (< 4 KB: tests/test_bench_host.py) -- metric / value / config /
+roofline / cpu_baseline for the headline plus one row per side config.  Everything else goes to a sidecar file,
+`bench_detail.json` (--detail-out; also copied under gpurun_out/ when that directory exists), and a summary to stderr:
   * `configs`: every other BASELINE configuration measured in the same process on the same GPU
-    (--side-steps each): cfg2-T (configs[1]: 4096 x 1 MiB), cfg2-T-p6 (the same plaintext behind
-    liblzma preset 6: rounds 1 and 2's headline), cfg2-R (incompressible, the shape of the reference's
+    (--side-steps each): cfg2-T (configs[1]: 4096 x 1 MiB), cfg2-R (incompressible, the shape of the reference's
     randomfile.dat benchmark), cfg4 (ONE raw LZMA2 stream of 4096 dictionary-reset units), cfg4-R (the same with
     incompressible segments: stored chunks only, the shape of randomfile.dat.lzma2), cfg5 (8192
-    streams, lc2/lp1/pb1, 8 MiB dictionary), cfg5-wrap (24 MiB streams whose 8 MiB window wraps).
+    streams, lc2/lp1/pb1, 8 MiB dictionary), cfg5-wrap (24 MiB streams whose 8 MiB window wraps); on request
+    (--configs) cfg2-T-p6, the same plaintext as cfg2-T behind liblzma preset 6 (rounds 1 and 2's headline).
     All corpora use ONE encoder setting (ENC_FAST) so that the configs can be compared; every config
     has its own `roofline` (incl. `issue`: the instruction-issue and lone-wave-latency bounds the LZMA
-    paths really run against, and the HBM roof in decoded bytes, which binds the stored-chunk config) and `cpu_baseline`; every decoded byte is compared with the
-    plaintext's SHA-256;
+    paths really run against, and the HBM roof in decoded bytes, which binds the stored-chunk config) and
+    `cpu_baseline`; every decoded byte is compared with the plaintext's SHA-256;
   * `host_to_host`: cfg3 and cfg2-T through xlz_decode_batch -- host buffers in, host buffers out,
     PCIe included, with the phase times (what a Go caller of the drop-in sees; never `value`);
   * `stream_count_sweep`: 64 / 256 / 1024 / 4096 streams of cfg2-T with the CPU baseline beside each:
     one wave decodes one stream, so a small batch leaves the chip idle -- the break-even is stated;
   * `containers`: a multi-block .xz file through xlz_xz_decode (host to host, CRC64 verified).
+
+The corpora are compressed by a pool of worker processes forked BEFORE anything touches the GPU.  Only the headline's
+corpus is waited for up front; the side corpora are compressed while the GPU legs run, but never inside the headline's
+timed region or a host-timed (PCIe-inclusive) leg: the pool is drained before those, and side configs report the
+HIP-event time of their launches.
 
 `roofline` prices the decode kernel against HBM bandwidth with algorithmic bytes (compressed bytes
 read once + decoded bytes written once), timed with HIP events on the kernel's own stream.
@@ -82,7 +89,8 @@ CONFIGS = {
                       baseline="configs[4] variant: 24 MiB streams, the 8 MiB window wraps, distances up to 8 MiB"),
 }
 HEADLINES = ["cfg3", "cfg3-heavy"]
-SIDE = ["cfg2-T", "cfg2-T-p6", "cfg2-R", "cfg4", "cfg4-R", "cfg5", "cfg5-wrap"]
+SIDE = ["cfg2-T", "cfg2-R", "cfg4", "cfg4-R", "cfg5", "cfg5-wrap"]   # default side list (cfg2-T-p6: on request, its preset-6 corpus takes 40 s)
+SIDE_ALL = SIDE + ["cfg2-T-p6"]
 EXTRAS = ["h2h", "sweep", "xz", "lone"]   # lone: the 64-unit launches behind roofline.issue.latency_bound
 SWEEP_COUNTS = [64, 256, 1024]  # (4096 is cfg2-T itself)
 
@@ -147,27 +155,53 @@ def _gen_lzma2_segment(job):
     return c[:-1], p
 
 
-def make_corpus(pool, spec, base_seed, indices=None):
-    """-> (compressed streams, sha256 digests of their plaintext) for the stream indices asked
-    (default: all).  Stream i depends only on (base_seed, i): every rank of a multi-GPU run can
-    make its own shard of the ONE seeded batch."""
+class PendingCorpus:
+    """A corpus whose compression jobs have been handed to the pool (ProcessPoolExecutor.map submits every job at
+    once and yields the results in order); result() waits for them."""
+
+    def __init__(self, spec, parts):
+        self.spec, self.parts, self.done = spec, parts, None
+        self.t0 = time.time()
+
+    def result(self):
+        if self.done is None:
+            if self.spec["fmt"] == "lzma1":
+                res = list(self.parts)
+                self.done = [r[0] for r in res], [r[1] for r in res]
+            else:
+                comp, dig = [], []
+                for it in self.parts:  # few big streams: the jobs are the segments of one stream
+                    parts = list(it)
+                    h = hashlib.sha256()
+                    for _, pl in parts:
+                        h.update(pl)
+                    comp.append(b"".join(c for c, _ in parts) + b"\x00")
+                    dig.append(h.digest())
+                self.done = comp, dig
+            self.parts = None
+            self.seconds = time.time() - self.t0
+        return self.done
+
+
+def start_corpus(pool, spec, base_seed, indices=None):
+    """Hands the compression jobs of a corpus to the pool and returns at once (PendingCorpus).  Stream i depends
+    only on (base_seed, i): every rank of a multi-GPU run can make its own shard of the ONE seeded batch."""
     kw = dict(dict_size=spec["dict"], lc=spec["lc"], lp=spec["lp"], pb=spec["pb"], preset=spec["enc"])
     idx = list(range(spec["streams"])) if indices is None else list(indices)
     if spec["fmt"] == "lzma1":
         jobs = [(spec["family"], base_seed + i, spec["size"], kw) for i in idx]
         chunk = max(1, min(64, len(jobs) // 256))
-        res = list(pool.map(_gen_lzma1, jobs, chunksize=chunk))
-        return [r[0] for r in res], [r[1] for r in res]
-    comp, dig = [], []
-    for i in idx:  # few big streams: parallel over the segments of one stream
+        return PendingCorpus(spec, pool.map(_gen_lzma1, jobs, chunksize=chunk))
+    its = []
+    for i in idx:
         jobs = [(spec["family"], (base_seed + i) * 4099 + k, spec["size"], kw) for k in range(spec["segments"])]
-        parts = list(pool.map(_gen_lzma2_segment, jobs, chunksize=max(1, min(16, len(jobs) // 256))))
-        h = hashlib.sha256()
-        for _, pl in parts:
-            h.update(pl)
-        comp.append(b"".join(c for c, _ in parts) + b"\x00")
-        dig.append(h.digest())
-    return comp, dig
+        its.append(pool.map(_gen_lzma2_segment, jobs, chunksize=max(1, min(16, len(jobs) // 256))))
+    return PendingCorpus(spec, its)
+
+
+def make_corpus(pool, spec, base_seed, indices=None):
+    """-> (compressed streams, sha256 digests of their plaintext) for the stream indices asked (default: all)."""
+    return start_corpus(pool, spec, base_seed, indices).result()
 
 
 # ---------------------------------------------------------------- GPU leg ----
@@ -179,25 +213,41 @@ def make_batch(lzma_amd, ctx, spec, comp):
     return lzma_amd.Batch(ctx, [lzma_amd.Stream(c, out_cap=osz) for c in comp])
 
 
+EVENT_SLOTS = 64  # xlz_ctx_event_record slots (include/xlz.h)
+
+
 def timed_steps(ctx, batch, steps, warmup, sync, barrier=None):
-    """W untimed warm-up steps, then exactly K steps between barriers; -> (wall s, kernel ms/step)."""
+    """W untimed warm-up steps, then exactly K steps between barriers; -> (wall s, kernel ms/step, per-step ms list).
+    HIP events on the kernel's own stream: one in front of the first step and one behind every step (as many as
+    the context has slots for), so that the MEDIAN step is reported beside the mean."""
     for _ in range(warmup):
         batch.run()
     batch.sync()
     if barrier:
         barrier()
     sync()
+    per_step = steps <= EVENT_SLOTS - 1
     t0 = time.perf_counter()
     ctx.event_record(0)
-    for _ in range(steps):
+    for k in range(steps):
         batch.run()
-    ctx.event_record(1)
+        if per_step and k + 1 < steps:
+            ctx.event_record(k + 1)
+    ctx.event_record(steps if per_step else 1)
     batch.sync()
     sync()
     t_local = time.perf_counter() - t0
     if barrier:
         barrier()
-    return t_local, ctx.event_elapsed_ms(0, 1) / max(1, steps)  # HIP events on the kernel's stream
+    last = steps if per_step else 1
+    each = [ctx.event_elapsed_ms(k, k + 1) for k in range(steps)] if per_step else []
+    return t_local, ctx.event_elapsed_ms(0, last) / max(1, steps), each
+
+
+def median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return None if n == 0 else xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
 
 
 def verify_all(batch, n, osz, digests, tag):
@@ -367,6 +417,8 @@ def cpu_baseline(spec, comp, digests, threads, target_s):
         outs, sts, dt = oracle.decode_batch_mt(sample, [out], 1, fmt=2, dict_size=spec["dict"], timing=True)
         assert sts[0] == 0 and outs[0][1] == out
         return {"value": round(out / GIB / dt, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
+                "sample_short": "first %d of %d segments (%d MiB) in %.1f s on ONE thread (a Reader2 is one goroutine); C restatement of "
+                                "the Go reference (oracle/xlz_oracle.c); Go toolchain absent" % (want, spec["segments"], out >> 20, dt),
                 "sample": "the first %d of the stream's %d segments (%d MiB decoded) in %.2f s; ONE thread: the "
                           "reference's Reader2 is a single goroutine and cannot decode the units of one stream "
                           "concurrently; C restatement of the Go reference (oracle/xlz_oracle.c, gcc -O2); Go toolchain "
@@ -387,6 +439,8 @@ def cpu_baseline(spec, comp, digests, threads, target_s):
     return {"value": round(n_sample * osz / GIB / dt, 4), "unit": "GiB/s", "cores": min(threads, n_sample), "kind": "port",
             "per_core_mib_s": round(per_core, 1),
             "go_toolchain_on_this_box": bool(shutil.which("go") or shutil.which("gccgo")),  # probed every run
+            "sample_short": "%d of %d streams (%d MiB) in %.1f s, one stream per thread on %d host threads; C restatement of the Go "
+                            "reference (oracle/xlz_oracle.c, gcc -O2); Go toolchain absent" % (n_sample, n, n_sample * osz >> 20, dt, min(threads, n_sample)),
             "sample": "%d of the %d streams (%d MiB decoded) in %.2f s of decode wall time; C restatement of the Go "
                       "reference's algorithm (oracle/xlz_oracle.c, gcc -O2), one stream per thread on %d host CPUs "
                       "(%.0f MiB/s per core; the reference publishes 42.59 MiB/s on tar data and 16.47 MB/s on random "
@@ -445,14 +499,95 @@ def _gen_xz_block(job):
     return lzma.compress(p, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC64, filters=filt), p
 
 
+def _warm(_):
+    time.sleep(0.05)
+    return os.getpid()
+
+
+def short_cpu(cpu):
+    """the cpu_baseline object of the compact line: the contract's fields, the sample in one sentence"""
+    if not cpu:
+        return None
+    r = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "per_core_mib_s") if k in cpu}
+    r["sample"] = cpu.get("sample_short") or cpu.get("sample", "")[:200]
+    return r
+
+
+def compact_line(full, detail_path=None):
+    """The ONE line the driver parses (the round-3 line had grown to 32 KB and was not parsed): the
+    contract's keys, the headline's config / roofline / cpu_baseline, one row per side config.  `full` is the detail
+    record (what rounds 1-3 printed); everything not copied here stays in the sidecar file."""
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data")
+    line = {k: full.get(k) for k in keys}
+    cfg = full["config"]
+    line["config"] = {k: cfg.get(k) for k in ("workload", "streams_total", "streams_largest_shard", "bytes_per_stream",
+                                              "compression_ratio", "bit_exact", "parallelism", "kernel_rev")}
+
+    def rf_short(rf):
+        r = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "kernel_ms_median",
+                                    "algorithmic_bytes_per_launch", "units_per_launch")}
+        iss = rf.get("issue") or {}
+        for k in ("frac_of_bound", "binding", "issue_bound_GBps", "latency_bound_GBps", "hbm_bound_GBps", "slot_occupancy"):
+            if k in iss:
+                r[k] = iss[k]
+        fp = iss.get("from_profile") or {}
+        if "instructions_per_decoded_byte" in fp:
+            r["instructions_per_decoded_byte"] = fp["instructions_per_decoded_byte"]
+        if rf.get("note"):
+            r["note"] = rf["note"]
+        return r
+    line["roofline"] = rf_short(full["roofline"])
+    line["cpu_baseline"] = short_cpu(full.get("cpu_baseline"))
+    rows = []
+    for c in full.get("configs") or []:
+        iss = c["roofline"].get("issue") or {}
+        cpu = c.get("cpu_baseline") or {}
+        rows.append({"name": c["name"], "value": c["value"], "kernel_ms": c["kernel_ms"], "frac": c["roofline"]["frac"],
+                     "frac_of_bound": iss.get("frac_of_bound"), "binding": iss.get("binding"),
+                     "cpu": cpu.get("value"), "cpu_cores": cpu.get("cores")})
+    if rows:
+        line["configs"] = rows
+        line["configs_unit"] = "GiB/s decoded, device-resident, every byte verified; cpu = the oracle on cpu_cores host threads"
+    if full.get("host_to_host"):
+        line["host_to_host"] = {x["name"]: x["value"] for x in full["host_to_host"]}
+    sw = full.get("stream_count_sweep")
+    if isinstance(sw, dict):
+        line["break_even_streams"] = sw.get("break_even_streams")
+    if full.get("containers"):
+        line["xz_1024_blocks_host_to_host"] = full["containers"][0]["value"]
+    if full.get("timing"):
+        line["bench_wall_s"] = full["timing"].get("total_s")
+    if detail_path:
+        line["detail"] = detail_path
+    return line
+
+
+def write_detail(full, path):
+    """the full record (what rounds 1-3 printed as one 32 KB line) next to the bench; a copy under gpurun_out/ when
+    that directory exists, so that a gpurun call brings it home"""
+    written = []
+    go = os.path.join(ROOT, "gpurun_out")
+    inside = os.path.abspath(path).startswith(os.path.abspath(go) + os.sep)
+    for p in [path] + ([os.path.join(go, os.path.basename(path))] if os.path.isdir(go) and not inside else []):
+        try:
+            with open(p, "w") as f:
+                json.dump(full, f, indent=1)
+            written.append(p)
+        except OSError as e:
+            log("bench_detail: cannot write %s: %r" % (p, e))
+    return written
+
+
 def main():
+    t_main0 = time.time()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--side-steps", type=int, default=3, help="timed steps of each entry of `configs` (1 warm-up)")
     ap.add_argument("--configs", default="all",
-                    help="N=1: comma list of side configs to run (%s), 'all' or 'none'" % ",".join(SIDE))
+                    help="N=1: comma list of side configs to run (%s), 'all' (= %s) or 'none'" % (",".join(SIDE_ALL), ",".join(SIDE)))
     ap.add_argument("--extras", default="all", help="N=1: comma list of %s, 'all' or 'none'" % ",".join(EXTRAS))
     ap.add_argument("--headline", default="cfg3", choices=list(CONFIGS),
                     help="the ONE workload reported as `value` at every N (cfg3; cfg3-heavy for big nodes; any other "
@@ -465,6 +600,8 @@ def main():
     ap.add_argument("--side-cpu-target-s", type=float, default=4.0)
     ap.add_argument("--corpus-cache", default="", help="dev (profiling passes): keep generated corpora in this directory and reuse them")
     ap.add_argument("--allow-xlz-so", action="store_true", help="dev: accept a library swapped in with XLZ_SO (recorded in the line)")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where rank 0 writes the full record (every config's roofline.issue, host_to_host, sweep, containers, library)")
     args = ap.parse_args()
     if os.environ.get("XLZ_SO") and not args.allow_xlz_so:
         raise SystemExit("bench.py: XLZ_SO is set (%s): the numbers would belong to another library than the tree's; "
@@ -492,41 +629,81 @@ def main():
         side.append("cfg2-T")   # (their corpus)
     names = [head] + side
 
-    # ---- synthetic corpora, generated BEFORE anything touches the GPU (the generator forks
-    # worker processes; a process that has initialised HIP must not fork workers)
+    # ---- synthetic corpora.  The pool's workers are ALL forked here, before anything touches the GPU (a process that has
+    # initialised HIP must not fork); jobs can be handed to them at any time afterwards.
     ncpu = effective_cpus()
     workers = max(1, min((os.cpu_count() or 1) // max(1, min(world, 8)), 64))
-    corp = {}
-    xz = None
-    t_gen0 = time.time()
-    with ProcessPoolExecutor(max_workers=workers) as pool:
-        for name in names:
-            spec = specs[name]
+    pool = ProcessPoolExecutor(max_workers=workers)
+    pids = set(pool.map(_warm, range(workers)))   # the first submit forks the workers (fork context: all of them at once)
+    log("[rank %d] %d corpus workers forked (%d host CPUs usable)" % (rank, len(pids), ncpu))
+    corp, pending, wait_s = {}, {}, {}
+
+    def cache_path(name):
+        return os.path.join(args.corpus_cache, "xlz_corpus_%s_%g_%d_%d.pkl" % (name, args.scale, world, rank)) if args.corpus_cache else ""
+
+    def start(name):
+        if name in corp or name in pending:
+            return
+        spec = specs[name]
+        cache = cache_path(name)
+        if cache and os.path.exists(cache):
+            import pickle
+            corp[name] = pickle.load(open(cache, "rb"))
+            wait_s[name] = 0.0
+        elif name == head:
+            # strong scaling: ONE batch (seed 1), this rank's shard of it (N = 1: all of it)
+            weights = [out_size_of(spec)] * spec["streams"]
+            pending[name] = start_corpus(pool, spec, 1, multigpu.partition_by_weight(weights, world)[rank])
+        else:
+            pending[name] = start_corpus(pool, spec, 1)
+
+    def get(name):
+        """the corpus, waiting for its jobs if they are still running"""
+        if name not in corp:
+            start(name)
             t0 = time.time()
-            cache = os.path.join(args.corpus_cache, "xlz_corpus_%s_%g_%d_%d.pkl" % (name, args.scale, world, rank)) if args.corpus_cache else ""
-            if cache and os.path.exists(cache):
-                import pickle
-                comp, dig = pickle.load(open(cache, "rb"))
-            elif name == head:
-                # strong scaling: ONE batch (seed 1), this rank's shard of it (N = 1: all of it)
-                weights = [out_size_of(spec)] * spec["streams"]
-                shard = multigpu.partition_by_weight(weights, world)[rank]
-                comp, dig = make_corpus(pool, spec, 1, shard)
-            else:
-                comp, dig = make_corpus(pool, spec, 1)
-            if cache and not os.path.exists(cache):
+            corp[name] = pending.pop(name).result()
+            wait_s[name] = round(time.time() - t0, 1)
+            cache = cache_path(name)
+            if cache:
                 import pickle
                 os.makedirs(args.corpus_cache, exist_ok=True)
-                pickle.dump((comp, dig), open(cache, "wb"), protocol=4)
-            corp[name] = (comp, dig)
-            log("[rank %d] corpus %s: %d streams x %d B, ratio %.3f, generated in %.1f s with %d workers"
-                % (rank, name, len(comp), out_size_of(spec), sum(map(len, comp)) / (len(comp) * out_size_of(spec)),
-                   time.time() - t0, workers))
-        if "xz" in extras:
-            t0 = time.time()
-            xz = xz_file(pool, max(8, int(1024 * args.scale)), 1 << 20)
-            log("[rank %d] corpus xz: %d bytes in %.1f s" % (rank, len(xz[0]), time.time() - t0))
-    gen_s = time.time() - t_gen0
+                pickle.dump(corp[name], open(cache, "wb"), protocol=4)
+            comp = corp[name][0]
+            log("[rank %d] corpus %s: %d streams x %d B, ratio %.3f, waited %.1f s for it (%d workers)"
+                % (rank, name, len(comp), out_size_of(specs[name]), sum(map(len, comp)) / (len(comp) * out_size_of(specs[name])),
+                   wait_s[name], workers))
+        return corp[name]
+
+    def drain():
+        """wait until the pool is idle: nothing compresses inside the headline's timed region or a host-timed leg"""
+        for name in list(pending):
+            get(name)
+        if xz_pending[0] is not None:
+            xz_get()
+
+    xz_pending, xz_done = [None], [None]
+
+    def xz_start():
+        if "xz" in extras and xz_pending[0] is None and xz_done[0] is None:
+            blocks = max(8, int(1024 * args.scale))
+            xz_pending[0] = pool.map(_gen_xz_block, [(9000 + i, 1 << 20) for i in range(blocks)], chunksize=max(1, blocks // 256))
+
+    def xz_get():
+        if xz_done[0] is None and xz_pending[0] is not None:
+            res = list(xz_pending[0])
+            xz_pending[0] = None
+            h = hashlib.sha256()
+            for _, pl in res:
+                h.update(pl)
+            xz_done[0] = (b"".join(c for c, _ in res), h.digest())
+        return xz_done[0]
+
+    t_gen0 = time.time()
+    get(head)
+    gen_head_s = time.time() - t_gen0
+    for name in side[:2]:   # compressed while torch is imported, HIP initialised and the headline uploaded
+        start(name)
 
     import torch
     import torch.distributed as dist
@@ -576,14 +753,16 @@ def main():
                 "unit_ms_median": round(float(np.median(dur)) * 1e3, 3),
                 "source": "live: a launch of the config's first %d units alone (one wave each, the rest of the chip idle)" % len(dur)}
 
-    def gpu_leg(name, steps, warmup, with_lone=True):
+    def gpu_leg(name, steps, warmup, with_lone=True, quiet_host=False):
         spec = specs[name]
-        comp, dig = corp[name]
+        comp, dig = get(name)
         osz = out_size_of(spec)
         t0 = time.time()
         batch = make_batch(lzma_amd, ctx, spec, comp)
         log("[rank %d] %s: batch created + uploaded in %.1f s" % (rank, name, time.time() - t0))
-        t_local, kernel_ms = timed_steps(ctx, batch, steps, warmup, torch.cuda.synchronize, barrier if world > 1 else None)
+        if quiet_host:
+            drain()
+        t_local, kernel_ms, each = timed_steps(ctx, batch, steps, warmup, torch.cuda.synchronize, barrier if world > 1 else None)
         verify_all(batch, len(comp), osz, dig, "rank %d %s" % (rank, name))
         cin, cout, units = batch.stats()
         occ = occupancy(batch, kernel_ms)
@@ -593,7 +772,7 @@ def main():
             np.savez_compressed(args.trace_out + name + ".npz", t_start=t0_, t_end=t1_, in_len=il_)
         batch.close()
         lone = lone_leg(name) if with_lone and "lone" in extras and spec["streams"] * spec.get("segments", 1) > 64 else None
-        return t_local, kernel_ms, cin, cout, units, occ, lone
+        return t_local, kernel_ms, cin, cout, units, occ, lone, each
 
     def cpu_leg(name, target_s):
         if args.no_cpu_baseline or rank != 0 or world != 1:   # contract: rank 0 at N = 1 only
@@ -654,7 +833,11 @@ def main():
 
     # ------------------------------------------------------------ the headline: one workload at every N ----
     spec = specs[head]
-    t_local, kernel_ms, cin, cout, units, occ, lone = gpu_leg(head, args.steps, args.warmup)
+    t_head0 = time.time()
+    t_local, kernel_ms, cin, cout, units, occ, lone, each = gpu_leg(head, args.steps, args.warmup, quiet_host=True)
+    for name in side[2:]:   # the rest of the corpora: compressed while the side legs run (their launches are timed by HIP events)
+        start(name)
+    xz_start()
     t_max = multigpu.max_over_ranks(t_local, dist, device=red_dev)
     n_max = multigpu.max_over_ranks(float(len(corp[head][0])), dist, device=red_dev)
     sums = [float(len(corp[head][0])), float(cin), float(cout)]
@@ -667,8 +850,14 @@ def main():
     total_out = spec["streams"] * out_size_of(spec) * args.steps
     head_res = {
         "value": round(total_out / GIB / t_max, 4), "ms_per_step": round(t_max / args.steps * 1e3, 3),
+        "ms_per_step_median": round(median(each), 3) if each else None,
         "roofline": roofline(head, cin, cout, units, kernel_ms, occ, lone),
     }
+    if each:
+        head_res["roofline"]["kernel_ms_median"] = round(median(each), 3)
+        head_res["roofline"]["kernel_ms_steps"] = [round(x, 3) for x in each]
+    log("[headline] %s: value %.4f GiB/s, ms_per_step %.3f (median step %s ms), kernel_ms %.3f, roofline.frac %.6f"
+        % (head, head_res["value"], head_res["ms_per_step"], head_res["ms_per_step_median"], kernel_ms, head_res["roofline"]["frac"]))
     if world > 1:
         # achieved / kernel_ms / units are rank 0's shard; the committed PMC passes profiled the WHOLE batch on one GPU, so
         # their byte counts do not describe this launch: traffic is scaled by the shard's share of the algorithmic bytes
@@ -681,21 +870,33 @@ def main():
             rf["traffic_from_profile"]["scaled_by"] = round(share, 6)
             rf["traffic_from_profile"]["note"] = ("profiled on the whole batch at N = 1; traffic = that figure x this shard's "
                                                   "share of the algorithmic bytes")
+    head_leg_s = time.time() - t_head0
 
     # ------------------------------------------------------------ N = 1: the other configs and the extras ----
     results = {}
+    t_side0 = time.time()
     for name in side:
         sp = specs[name]
         steps, warmup = args.side_steps, 1
-        tl, kms, ci, co, un, oc, ln = gpu_leg(name, steps, warmup)
+        tl, kms, ci, co, un, oc, ln, ea = gpu_leg(name, steps, warmup)
         n = len(corp[name][0])
         results[name] = {
             "name": name, "baseline_config": sp["baseline"], "workload": workload_text(name, sp),
-            "value": round(n * out_size_of(sp) * steps / GIB / tl, 4), "unit": "GiB/s", "steps": steps, "warmup": warmup,
-            "ms_per_step": round(tl / steps * 1e3, 3), "kernel_ms": round(kms, 3),
+            # the HIP-event time of the launches: corpora of later configs are being compressed on the host meanwhile
+            "value": round(n * out_size_of(sp) / GIB / (kms / 1e3), 4), "unit": "GiB/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(kms, 3), "ms_per_step_wall": round(tl / steps * 1e3, 3), "kernel_ms": round(kms, 3),
+            "kernel_ms_median": round(median(ea), 3) if ea else None,
+            "timed_with": "HIP events on the kernel's stream around the timed steps",
             "streams": n, "bytes_per_stream": out_size_of(sp), "compression_ratio": round(ci / co, 4),
             "bit_exact": "all", "roofline": roofline(name, ci, co, un, kms, oc, ln),
         }
+        log("[side] %s: %.4f GiB/s, kernel_ms %.3f, roofline.frac %.6f" % (name, results[name]["value"], kms, results[name]["roofline"]["frac"]))
+    side_legs_s = time.time() - t_side0
+    drain()    # from here on the host is quiet: the host-timed legs and the CPU baselines
+    pool.shutdown()
+    gen_s = time.time() - t_gen0
+    xz = xz_done[0]
+    t_extra0 = time.time()
     h2h, sweep, containers = None, None, None
     if "h2h" in extras:
         h2h = [h2h_leg(n) for n in dict.fromkeys([head, "cfg2-T"]) if n in corp]
@@ -710,7 +911,7 @@ def main():
             if k >= len(comp):
                 continue
             b = make_batch(lzma_amd, ctx, sp, comp[:k])
-            tl, kms = timed_steps(ctx, b, 2, 1, torch.cuda.synchronize)
+            tl, kms, _ = timed_steps(ctx, b, 2, 1, torch.cuda.synchronize)
             oc = occupancy(b, kms)
             verify_all(b, k, sp["size"], dig[:k], "sweep %d" % k)
             b.close()
@@ -741,8 +942,10 @@ def main():
                        "value": round(len(out) / GIB / dt, 4), "unit": "GiB/s", "ms_per_call": round(dt * 1e3, 3),
                        "compressed_bytes": len(data), "decoded_bytes": len(out), "bit_exact": "all", "calls": 3, "reported": "best call", "phases_ms": cs_xz}]
         del out
+    extras_s = time.time() - t_extra0
 
     # ---- CPU legs after all GPU work: the host cores are quiet
+    t_cpu0 = time.time()
     cpu_head = cpu_leg(head, args.cpu_target_s)
     for name in side:
         results[name]["cpu_baseline"] = cpu_leg(name, args.side_cpu_target_s)
@@ -790,12 +993,14 @@ def main():
             sanity = liblzma_sanity(corp[head][0], out_size_of(spec), ncpu)
         except Exception as e:  # a sanity line must never fail the bench
             log("liblzma sanity line skipped: %r" % (e,))
+    cpu_legs_s = time.time() - t_cpu0
     if world > 1:
         barrier()
     if rank == 0:
-        line = {
+        full = {
             "metric": "decompressed GiB/s (aggregate batch)", "value": head_res["value"], "unit": "GiB/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": head_res["ms_per_step"], "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": head_res["ms_per_step"],
+            "ms_per_step_median": head_res["ms_per_step_median"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload_text(head, spec, per_gpu=False) + "; ONE seeded batch split by stream over %d GPU%s"
                        % (world, "" if world == 1 else "s"),
@@ -805,14 +1010,24 @@ def main():
                        "corpus_generation_s": round(gen_s, 1), "kernel_rev": lib_info["kernel_id"], "library": lib_info},
             "roofline": head_res["roofline"],
             "cpu_baseline": cpu_head,
+            "timing": {"total_s": round(time.time() - t_main0, 1), "headline_corpus_s": round(gen_head_s, 1),
+                       "waited_for_corpora_s": wait_s, "headline_leg_s": round(head_leg_s, 1), "side_legs_s": round(side_legs_s, 1),
+                       "extras_s": round(extras_s, 1), "cpu_legs_s": round(cpu_legs_s, 1),
+                       "note": "side corpora are compressed by the worker pool while the GPU legs run (never inside the headline's timed "
+                               "region, a host-timed leg or a CPU baseline)"},
         }
         if world == 1:
-            line["cpu_sanity_liblzma"] = sanity
-            line["host_to_host"] = h2h
-            line["stream_count_sweep"] = sweep
-            line["containers"] = containers
-            line["configs"] = [results[n] for n in side if n in results]
-        print(json.dumps(line), flush=True)
+            full["cpu_sanity_liblzma"] = sanity
+            full["host_to_host"] = h2h
+            full["stream_count_sweep"] = sweep
+            full["containers"] = containers
+            full["configs"] = [results[n] for n in side if n in results]
+        written = write_detail(full, args.detail_out)
+        line = compact_line(full, os.path.relpath(written[0], ROOT) if written else None)
+        log("[bench] value %.4f %s  ms_per_step %.3f  n_gpus %d  roofline.frac %.6f  cpu_baseline %s  (%.0f s; detail: %s)"
+            % (line["value"], line["unit"], line["ms_per_step"], world, line["roofline"]["frac"],
+               line["cpu_baseline"] and line["cpu_baseline"]["value"], time.time() - t_main0, ", ".join(written) or "not written"))
+        print(json.dumps(line, separators=(",", ":")), flush=True)
     if world > 1:
         dist.destroy_process_group()
     ctx.close()

@@ -14,7 +14,9 @@
  *
  * The library reads ONE environment variable, a debugging aid: XLZ_DEBUG (any
  * value) prints failed HIP calls and the phase times of xlz_decode_batch to
- * stderr.  Nothing tunes the decode.
+ * stderr.  Nothing tunes the decode.  (An A/B build made with -DXLZ_DEV_KNOBS also reads
+ * XLZ_STORED_UNIT_KIB, the least size of a unit of stored LZMA2 chunks; the shipped build
+ * does not contain that code.)
  *
  * file:line citations are into the reference repository.
  */
@@ -107,7 +109,7 @@ void xlz_ctx_destroy(xlz_ctx *ctx);
 int xlz_ctx_device(const xlz_ctx *ctx);
 
 /* HIP events on the context's stream, for callers that time a region of enqueued work
- * (bench.py): slot 0..7.  elapsed_ms waits for event `b`.                           */
+ * (bench.py): slot 0..63.  elapsed_ms waits for event `b`.                           */
 int xlz_ctx_event_record(xlz_ctx *ctx, int slot);
 int xlz_ctx_event_elapsed_ms(xlz_ctx *ctx, int slot_a, int slot_b, float *ms);
 

@@ -63,6 +63,8 @@ static void batcher_shutdown(Batcher *bt); // defined next to the readers
 //  * input: one grow-only pinned image, packed by several host threads, one async H2D copy;
 //  * output: a ring of pinned buffers; D2H copies of arena chunks run on their own stream while
 //    host threads scatter the chunks that have arrived into the callers' buffers.
+constexpr int kEventSlots = 64; // xlz_ctx_event_record: enough for one event per timed step of bench.py
+
 struct HostPipe {
     static constexpr int kRing = 4;
     static constexpr size_t kRingBytes = 64u << 20;
@@ -83,7 +85,7 @@ struct xlz_ctx {
     hipStream_t stream = nullptr;
     uint32_t *queue = nullptr; // work-queue head, re-zeroed on the stream before each launch
     uint32_t *prio_tab = nullptr; // LaunchParams.prio_tab: one word per hardware wave slot, zero when idle
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[kEventSlots] = {};
     std::mutex mu;
     HostPipe pipe;
     xlz_call_stats last_call = {}; // of the most recent xlz_decode_batch on this context (xlz_ctx_last_call_stats)
@@ -275,6 +277,7 @@ extern "C" void xlz_ctx_destroy(xlz_ctx *c)
         if (c->pipe.ring_ev[i]) (void)hipEventDestroy(c->pipe.ring_ev[i]);
     }
     if (c->pipe.copy_stream) (void)hipStreamDestroy(c->pipe.copy_stream);
+    if (c->pipe.up_stream) (void)hipStreamDestroy(c->pipe.up_stream);
     for (hipEvent_t e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -285,7 +288,7 @@ extern "C" int xlz_ctx_device(const xlz_ctx *c) { return c ? c->device : -1; }
 
 extern "C" int xlz_ctx_event_record(xlz_ctx *c, int slot)
 {
-    if (!c || slot < 0 || slot >= 8) return XLZ_ERR_BAD_ARG;
+    if (!c || slot < 0 || slot >= kEventSlots) return XLZ_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     if (!c->ev[slot]) HIP_TRY(hipEventCreate(&c->ev[slot]));
@@ -295,7 +298,7 @@ extern "C" int xlz_ctx_event_record(xlz_ctx *c, int slot)
 
 extern "C" int xlz_ctx_event_elapsed_ms(xlz_ctx *c, int a, int b, float *ms)
 {
-    if (!c || !ms || a < 0 || a >= 8 || b < 0 || b >= 8 || !c->ev[a] || !c->ev[b]) return XLZ_ERR_BAD_ARG;
+    if (!c || !ms || a < 0 || a >= kEventSlots || b < 0 || b >= kEventSlots || !c->ev[a] || !c->ev[b]) return XLZ_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(c->ev[b]));
     HIP_TRY(hipEventElapsedTime(ms, c->ev[a], c->ev[b]));
@@ -369,15 +372,22 @@ struct Lz2Unit {
     bool have_reader; // an LZMA chunk precedes the unit: Reader2.lzmaReader exists (reader2.go:146-153)
 };
 
-// bytes a unit made of stored chunks alone should hold at least (XLZ_STORED_UNIT_KIB: development knob, 0 = cut runs of
-// stored chunks at dictionary resets only)
+// bytes a unit made of stored chunks alone should hold at least.  The shipped library uses kStoredUnitBytes and reads
+// nothing from the environment here; an A/B build (-DXLZ_DEV_KNOBS, tools/ab_stored_unit.sh) takes XLZ_STORED_UNIT_KIB
+// (0 = cut runs of stored chunks at dictionary resets only; clamped to 1 GiB).
 uint64_t stored_unit_bytes()
 {
+#ifdef XLZ_DEV_KNOBS
     static const uint64_t v = [] {
         const char *e = getenv("XLZ_STORED_UNIT_KIB");
-        return e ? (uint64_t)strtoull(e, nullptr, 10) << 10 : (uint64_t)kStoredUnitBytes;
+        if (!e) return (uint64_t)kStoredUnitBytes;
+        unsigned long long k = strtoull(e, nullptr, 10);
+        return (uint64_t)(k > (1u << 20) ? (1u << 20) : k) << 10;
     }();
     return v;
+#else
+    return kStoredUnitBytes;
+#endif
 }
 
 void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint32_t &max_lc_lp)

@@ -93,3 +93,82 @@ def test_issue_bounds_arithmetic():
                            {"bytes_per_s_per_wave": 9e9}, 4096, 2 * (1 << 30) + 1000)
     assert r["binding"] == "hbm" and abs(r["hbm_bound_GBps"] - 4000.0) < 1 and 0.4 < r["frac_of_bound"] < 0.6
     assert r["bounds_known"] == ["issue", "latency", "hbm"]
+
+
+def _stub_roofline(name):
+    """a roofline object as bench.roofline() builds it, every optional part present (the round-3 line carried all of
+    this for eight configs and grew to 32 KB; the driver could not parse it)"""
+    return {"bound": "hbm", "achieved": 22.414, "peak": 8000.0, "unit": "GB/s", "frac": 0.002802, "traffic": 41688374897.0,
+            "kernel": "xlz::xlz_decode_kernel", "kernel_ms": 270.123, "kernel_ms_median": 270.001, "kernel_ms_steps": [270.1] * 20,
+            "algorithmic_bytes_per_launch": 6059123456, "units_per_launch": 65536,
+            "traffic_from_profile": {"source": "profiles/r04/%s_pmc.csv" % name, "kernel_rev": "0123456789ab", "fetch": 1.0, "write": 2.0,
+                                     "fetch_correction": 1},
+            "issue": {"slot_occupancy": 0.9512, "slots": 5120, "lds_bytes_per_slot": 7416, "units": 65536, "rounds": 12.8,
+                      "launch_span_ms": 270.0, "unit_ms": {"min": 1.0, "p50": 20.0, "p90": 22.0, "p99": 25.0, "max": 30.0},
+                      "corr_queue_key_vs_time": 0.23, "source": "x" * 150, "achieved_decoded_GBps": 15.9, "issue_bound_GBps": 19.8,
+                      "issue_bound_from": {"salu_per_decoded_byte": 30.2, "note": "y" * 300}, "latency_bound_GBps": 23.6,
+                      "latency_bound_from": {"note": "z" * 300}, "hbm_bound_GBps": 5664.1, "frac_of_bound": 0.8012,
+                      "binding": "issue", "bounds_known": ["issue", "latency", "hbm"],
+                      "from_profile": {"instructions_per_decoded_byte": 69.7, "budget": "w" * 200}}}
+
+
+def test_the_bench_line_is_compact_and_round_trips():
+    """the LAST stdout line must be one small JSON object with value / config (naming cfg3) / roofline /
+    cpu_baseline; everything else lives in the sidecar"""
+    import json
+    cpu = {"value": 1.0213, "unit": "GiB/s", "cores": 16, "kind": "port", "per_core_mib_s": 65.4, "go_toolchain_on_this_box": False,
+           "sample_short": "s" * 180, "sample": "t" * 500}
+    spec = bench.CONFIGS["cfg3"]
+    full = {"metric": "decompressed GiB/s (aggregate batch)", "value": 14.7654, "unit": "GiB/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+            "ms_per_step": 270.913, "ms_per_step_median": 270.8, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": bench.workload_text("cfg3", spec, per_gpu=False) + "; ONE seeded batch split by stream over 1 GPU",
+                       "streams_total": 65536, "streams_largest_shard": 65536, "bytes_per_stream": 65536, "compression_ratio": 0.4098,
+                       "bit_exact": "all", "parallelism": "one batch sharded by stream x1 (partition_by_weight), no collective",
+                       "corpus_generation_s": 100.0, "kernel_rev": "0123456789ab", "library": {"path": "p" * 100, "sha256": "0" * 64}},
+            "roofline": _stub_roofline("cfg3"), "cpu_baseline": cpu, "cpu_sanity_liblzma": dict(cpu),
+            "timing": {"total_s": 180.0},
+            "host_to_host": [{"name": n, "value": 12.5, "phases_ms": {"note": "n" * 300}} for n in ("cfg3", "cfg2-T", "cfg2-T x4")],
+            "stream_count_sweep": {"points": [{"streams": k, "cpu_baseline": dict(cpu)} for k in (64, 256, 1024, 4096)],
+                                   "break_even_streams": 256, "note": "n" * 200},
+            "containers": [{"name": "xz-blocks", "value": 4.31, "workload": "w" * 300}],
+            "configs": [{"name": n, "workload": bench.workload_text(n, bench.CONFIGS[n]), "baseline_config": bench.CONFIGS[n]["baseline"],
+                         "value": 17.2412, "kernel_ms": 232.123, "roofline": _stub_roofline(n), "cpu_baseline": dict(cpu)}
+                        for n in bench.SIDE_ALL]}
+    assert len(json.dumps(full)) > 20000          # the detail record is the big one ...
+    line = bench.compact_line(full, "bench_detail.json")
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 4096, len(text)            # ... the printed line is not
+    assert "\n" not in text
+    back = json.loads(text)
+    assert back == line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert back["config"]["workload"].startswith("cfg3") and "65536" in back["config"]["workload"]
+    assert "model" not in back["config"] and back["config"]["kernel_rev"] == "0123456789ab"
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch",
+              "units_per_launch", "frac_of_bound", "binding"):
+        assert k in back["roofline"], k
+    assert abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-5
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in back["cpu_baseline"], k
+    assert [c["name"] for c in back["configs"]] == bench.SIDE_ALL
+    assert all(set(c) == {"name", "value", "kernel_ms", "frac", "frac_of_bound", "binding", "cpu", "cpu_cores"} for c in back["configs"])
+    # an N > 1 line (no side configs, no cpu baseline) is a valid line too
+    multi = dict(full, n_gpus=8, cpu_baseline=None, configs=None, host_to_host=None, stream_count_sweep=None, containers=None)
+    small = bench.compact_line(multi)
+    assert small["cpu_baseline"] is None and "configs" not in small and len(json.dumps(small)) < 2500
+
+
+def test_corpora_can_be_started_early_and_collected_later():
+    """bench.py hands every corpus to the pool before the GPU is touched and collects it when its leg begins"""
+    with ProcessPoolExecutor(max_workers=2) as pool:
+        a = bench.start_corpus(pool, _tiny("cfg2-T", streams=6, size=9000), 1)
+        b = bench.start_corpus(pool, _tiny("cfg4", segments=5, size=7000), 1)
+        cb, db = b.result()
+        ca, da = a.result()
+        assert a.result() is a.done   # a second call does not wait again
+    assert len(ca) == 6 and len(cb) == 1
+    assert hashlib.sha256(lzma.decompress(ca[3], format=lzma.FORMAT_ALONE)).digest() == da[3]
+    assert bench.median([3.0, 1.0, 2.0]) == 2.0 and bench.median([4.0, 1.0, 2.0, 3.0]) == 2.5 and bench.median([]) is None

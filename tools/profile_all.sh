@@ -9,8 +9,8 @@
 # dispatch lists into configs (every leg is warm-up + steps launches, in the order of the command line).
 set -u
 : "${GRAFT_REPO_ROOT:?run this on the GPU box through gpurun (GRAFT_REPO_ROOT is set there)}"
-TAG=${1:-r03all}
-SIDE=${2:-cfg2-T,cfg2-T-p6,cfg2-R,cfg4,cfg4-R,cfg5,cfg5-wrap}
+TAG=${1:-r04all}
+SIDE=${2:-cfg2-T,cfg2-R,cfg4,cfg4-R,cfg5,cfg5-wrap}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 ARGS="--headline cfg3 --configs $SIDE --extras none --steps 3 --warmup 1 --side-steps 3 --no-cpu-baseline --corpus-cache /tmp/xlz_corpus_cache"
@@ -18,7 +18,7 @@ echo "bench args: $ARGS" > $O/command.txt
 run() { # name, rocprofv3 options
     local n=$1; shift
     echo "[profile_all] pass $n: $(date +%T)"
-    rocprofv3 "$@" -d $O/$n --output-format csv -- python3 $R/bench.py $ARGS > $O/$n.json 2> $O/$n.err || { tail -5 $O/$n.err; exit 1; }
+    rocprofv3 "$@" -d $O/$n --output-format csv -- python3 $R/bench.py $ARGS --detail-out $O/$n.json > $O/$n.line 2> $O/$n.err || { tail -5 $O/$n.err; exit 1; }
 }
 run kt --kernel-trace --stats
 run fetch --pmc FETCH_SIZE

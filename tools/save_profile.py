@@ -99,7 +99,7 @@ def main():
     w = csv.writer(open(dest + "_pmc.csv", "w"))
     w.writerow(PMC_HEADER)
     w.writerows(rows)
-    line = json.loads(open(src + "/kt.json").read().strip().splitlines()[-1])
+    line = json.load(open(src + "/kt.json"))   # bench.py --detail-out: the full record
     assert line["config"]["kernel_rev"] == bench.kernel_rev(), "the profile was taken on another build than lzma_amd/libxlz.so"
     decoded = line["config"]["streams_total"] * line["config"]["bytes_per_stream"]
     entry = make_entry(line["config"]["workload"], line["config"]["kernel_rev"], decoded, line["roofline"]["kernel_ms"],

@@ -51,7 +51,7 @@ def main():
     os.makedirs(dest, exist_ok=True)
     command = open(os.path.join(src, "command.txt")).read().strip()
     legs = parse_command(command)
-    lines = {p: json.loads(open(os.path.join(src, p + ".json")).read().strip().splitlines()[-1]) for p in ("kt", "fetch", "write", "sq", "sq2")}
+    lines = {p: json.load(open(os.path.join(src, p + ".json"))) for p in ("kt", "fetch", "write", "sq", "sq2")}   # bench.py --detail-out: the full record
     line = lines["kt"]
     rev = line["config"]["kernel_rev"]
     assert rev == bench.kernel_rev(), "the profile was taken on another build than lzma_amd/libxlz.so"

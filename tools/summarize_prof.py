@@ -13,7 +13,7 @@ print("command: `python3 bench.py %s`\n" % open(os.path.join(O, "command.txt")).
 for name in ("kt", "fetch", "write", "sq", "sq2"):
     p = os.path.join(O, name + ".json")
     if os.path.exists(p) and os.path.getsize(p):
-        j = json.loads(open(p).read().strip().splitlines()[-1])
+        j = json.load(open(p))   # bench.py --detail-out
         print("- %s pass bench line: value %.3f %s, roofline.kernel_ms %.3f, achieved %.3f GB/s" % (
             name, j["value"], j["unit"], j["roofline"]["kernel_ms"], j["roofline"]["achieved"]))
         algo = j["roofline"]["algorithmic_bytes_per_launch"]
