@@ -251,6 +251,10 @@ void xlz_reader_free(xlz_reader *r);
  * cases above), compressed bytes uploaded so far -- for tests of the one-pass property     */
 int xlz_reader_stats(const xlz_reader *r, uint64_t *refills, uint64_t *whole_decodes,
                      uint64_t *in_uploaded);
+/* device memory the reader holds right now: its sliding output window, and the image of the
+ * reference's uncleared window buffer (dictSize bytes; window.go:135-140) -- 0 until the stream's
+ * first dictionary reset behind a non-empty epoch, i.e. for nearly every stream                 */
+int xlz_reader_memory(const xlz_reader *r, uint64_t *window_bytes, uint64_t *image_bytes);
 
 /* Multi-GPU form of xlz_decode_batch: one context per GPU; the batch is
  * split by stream (balanced by out_cap), every context decodes its shard on its own host

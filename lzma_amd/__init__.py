@@ -342,6 +342,13 @@ class _Reader:
         N.lib().xlz_reader_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
         return a.value, b.value, c.value
 
+    def memory(self):
+        """(bytes of the sliding output window on the device, bytes of the window image -- 0 until the stream's first
+        dictionary reset behind a non-empty epoch) -- xlz_reader_memory"""
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        N.lib().xlz_reader_memory(self._h, ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
     def Close(self):
         """readCloser.Close (readcloser.go:16-28)."""
         st = N.lib().xlz_reader_close(self._h)
@@ -446,13 +453,17 @@ def NewLZMA2DecompressorForSevenZip(ctx, props, unpack_size, readers):
 def lzma2_units(data):
     """The unit plan of a raw LZMA2 stream (xlz_lzma2_units; host only): list of dicts (in_off, in_len, out_off,
     out_len, have_reader) -- what a decode of `data` as FMT_LZMA2_RAW launches, one wave per unit."""
-    data = bytes(data)
+    if hasattr(data, "ctypes"):   # a numpy array (uint8, contiguous): planned in place, whatever its size
+        ptr, size = ctypes.c_char_p(data.ctypes.data), data.size
+    else:
+        data = bytes(data)
+        ptr, size = data, len(data)
     n = ctypes.c_size_t()
-    st = N.lib().xlz_lzma2_units(data, len(data), None, 0, ctypes.byref(n))
+    st = N.lib().xlz_lzma2_units(ptr, size, None, 0, ctypes.byref(n))
     if st != OK:
         raise LzmaError(st, "xlz_lzma2_units")
     units = (N.Lzma2Unit * max(n.value, 1))()
-    st = N.lib().xlz_lzma2_units(data, len(data), units, n.value, ctypes.byref(n))
+    st = N.lib().xlz_lzma2_units(ptr, size, units, n.value, ctypes.byref(n))
     if st != OK:
         raise LzmaError(st, "xlz_lzma2_units")
     return [{f: getattr(units[k], f) for f, _ in N.Lzma2Unit._fields_ if f != "reserved"} for k in range(n.value)]

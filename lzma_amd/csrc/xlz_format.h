@@ -108,7 +108,10 @@ enum : uint32_t {
     AUX_GROW = 8,       // paused in front of an LZMA2 chunk whose properties need a larger model than the unit's state
                         // block holds: lc+lp wanted in bits 8..11
     AUX_GROW_SHIFT = 8,
-    AUX_GROW_MASK = 0xF00
+    AUX_GROW_MASK = 0xF00,
+    AUX_SHADOW = 16     // paused in front of an LZMA2 chunk that resets the dictionary behind a non-empty epoch while the
+                        // session has no window image yet: the host allocates it (dictSize bytes) and resumes -- a stream
+                        // whose only dictionary reset is its first chunk's never pays for one
 };
 
 // device-side status values = include/xlz.h

@@ -367,7 +367,7 @@ void plan_lzma_raw(const xlz_stream_desc &s, StreamPlan &pl, Unit &u, bool &has_
 // A stream whose real decode does not follow its headers is detected after the launch
 // (a unit's produced / consumed counts differ) and re-decoded as ONE unit.
 struct Lz2Unit {
-    uint32_t in_start, in_len;
+    uint64_t in_start, in_len; // 64-bit: xlz_lzma2_units plans streams of any size (the batch path holds a stream in 32 bits)
     uint64_t out_start, expect_out;
     bool have_reader; // an LZMA chunk precedes the unit: Reader2.lzmaReader exists (reader2.go:146-153)
 };
@@ -420,7 +420,7 @@ void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint
     const uint64_t stored_unit = stored_unit_bytes();
     bool seen_lzma = false, unit_seen_lzma = false; // an LZMA chunk before: here / the unit
     auto cut = [&](size_t at, uint64_t at_out, bool lzma_before) {
-        units.push_back({(uint32_t)unit_start, (uint32_t)(at - unit_start), unit_out, at_out - unit_out, unit_seen_lzma});
+        units.push_back({(uint64_t)unit_start, (uint64_t)(at - unit_start), unit_out, at_out - unit_out, unit_seen_lzma});
         unit_start = at;
         unit_out = at_out;
         unit_seen_lzma = lzma_before;
@@ -485,7 +485,7 @@ void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint
         out += unc;
     }
     if (ended || pos >= len) cut_at_candidates(true); // only stored chunks behind them
-    units.push_back({(uint32_t)unit_start, (uint32_t)(len - unit_start), unit_out, out - unit_out, unit_seen_lzma});
+    units.push_back({(uint64_t)unit_start, (uint64_t)(len - unit_start), unit_out, out - unit_out, unit_seen_lzma});
 }
 
 } // namespace
@@ -594,7 +594,7 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
                 Unit v = u;
                 const bool last = k + 1 == lu.size();
                 v.in_off = in_cursor + lu[k].in_start;
-                v.in_len = lu[k].in_len;
+                v.in_len = (uint32_t)lu[k].in_len; // (s.in_len <= kMaxUnitBytes: checked above)
                 v.out_off = out_cursor + std::min<uint64_t>(lu[k].out_start, s.out_cap);
                 const uint64_t room = s.out_cap > lu[k].out_start ? s.out_cap - lu[k].out_start : 0;
                 v.out_cap = (uint32_t)(last ? room : std::min<uint64_t>(room, lu[k].expect_out));
@@ -1502,12 +1502,13 @@ struct xlz_reader {
     bool is_closer = false;      // built by a *ForSevenZip constructor: wraps errors like readCloser
     int32_t status = XLZ_OK;
     int call_status = XLZ_OK;    // a device failure (not a stream status)
+    int step_status = XLZ_OK;    // of the launch that carried this reader in the last sessions_step (readers of the other launch keep theirs)
     uint64_t delivered = 0;      // decoded bytes handed to the chunk buffer so far
     Session *ss = nullptr;
     bool whole = false;          // fallback: decode the whole stream in one exact batch (see reader_whole)
     // batching: refills of concurrent readers are decoded by the context's batcher thread in one launch
     bool refill_pending = false;
-    uint64_t n_refills = 0, n_whole = 0;
+    uint64_t n_refills = 0, n_whole = 0, n_shadow = 0;
     bool pending_reset = false, pending_reopen = false; // (*Reader1).Reset / Reopen before the next refill
     // streaming input (xlz_reader_expect_more / _feed / _feed_eof): `in` holds the bytes from stream
     // offset in_base on; what the decoder has consumed is dropped at every feed
@@ -1636,15 +1637,10 @@ int session_open(xlz_reader *r)
         return XLZ_ERR_DEVICE;
     }
     if (u.kind == UNIT_LZMA2) {
-        // the window image for reads behind a dictionary reset: allocated like the reference's window (eagerly, zero
-        // filled: window.go:18-29); its address sits in the state header where the wave looks for it
-        const uint64_t addr_words_off = ss->off_state + (size_t)kStateShadowWord * 4;
-        if (hipMalloc(&ss->d_shadow, u.dict_size) != hipSuccess || hipMemset(ss->d_shadow, 0, u.dict_size) != hipSuccess) {
-            session_free(ss);
-            return XLZ_ERR_DEVICE;
-        }
-        const uint64_t addr = (uint64_t)ss->d_shadow;
-        if (hipMemcpy(ss->d_ctl + addr_words_off, &addr, 8, hipMemcpyHostToDevice) != hipSuccess) {
+        // the window image for reads behind a dictionary reset is allocated when the stream first needs one
+        // (session_make_shadow, asked for by the wave with AUX_SHADOW); until then the state header says "none"
+        const uint64_t none = 0;
+        if (hipMemcpy(ss->d_ctl + ss->off_state + (size_t)kStateShadowWord * 4, &none, 8, hipMemcpyHostToDevice) != hipSuccess) {
             session_free(ss);
             return XLZ_ERR_DEVICE;
         }
@@ -1742,6 +1738,25 @@ int session_grow_model(xlz_reader *r, uint32_t need, hipStream_t stream)
     return XLZ_OK;
 }
 
+// The wave stands in front of a dictionary reset that ends a non-empty epoch (AUX_SHADOW): from here on a copy may read
+// what earlier epochs left in the reference's uncleared window buffer (window.go:135-140).  The image is allocated now --
+// dictSize bytes, zero-filled like the reference's window (window.go:18-29) -- and its address goes into the state
+// header, where the resumed wave looks for it.  Streams whose only dictionary reset is their first chunk's (most of
+// them) never get here: through round 3 every NewReader2 paid dictSize bytes of HBM and a memset up front.
+int session_make_shadow(xlz_reader *r)
+{
+    Session *ss = r->ss;
+    if (ss->d_shadow) return XLZ_OK;
+    const size_t n = ss->unit.dict_size;
+    if (hipMalloc(&ss->d_shadow, n) != hipSuccess) return XLZ_ERR_DEVICE;
+    const uint64_t addr = (uint64_t)ss->d_shadow;
+    if (hipMemset(ss->d_shadow, 0, n) != hipSuccess ||
+        hipMemcpy(ss->d_ctl + ss->off_state + (size_t)kStateShadowWord * 4, &addr, 8, hipMemcpyHostToDevice) != hipSuccess)
+        return XLZ_ERR_DEVICE;
+    r->n_shadow++;
+    return XLZ_OK;
+}
+
 int sessions_launch(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs, bool big);
 
 // One refill of every reader in `all`: each reader's unit continues from its saved state and stops after about
@@ -1762,13 +1777,20 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &all)
             r->rd = 0;
             continue;
         }
-        if (st != XLZ_OK) return st; // the device failed: nothing was launched, pending Reset / Reopen flags are still set
+        if (st != XLZ_OK) { // the device failed: nothing was launched, pending Reset / Reopen flags are still set
+            for (xlz_reader *q : all) q->step_status = st;
+            return st;
+        }
         (r->ss->model_lc_lp > kMaxLcLpLds ? bigs : normal).push_back(r);
     }
-    int st = XLZ_OK;
-    if (!normal.empty()) st = sessions_launch(ctx, normal, false);
-    if (st == XLZ_OK && !bigs.empty()) st = sessions_launch(ctx, bigs, true);
-    return st;
+    // Two launches (LDS models, HBM models), two outcomes: the readers of a launch that succeeded have advanced
+    // and keep their bytes whatever happened to the other launch; only the failing launch's readers see the failure.
+    for (xlz_reader *r : all) r->step_status = XLZ_OK;
+    const int st_normal = normal.empty() ? XLZ_OK : sessions_launch(ctx, normal, false);
+    const int st_big = bigs.empty() ? XLZ_OK : sessions_launch(ctx, bigs, true);
+    for (xlz_reader *r : normal) r->step_status = st_normal;
+    for (xlz_reader *r : bigs) r->step_status = st_big;
+    return st_normal != XLZ_OK ? st_normal : st_big;
 }
 
 // ONE launch over prepared sessions of one kind (ctx->mu held, device set)
@@ -1866,6 +1888,7 @@ int sessions_launch(xlz_ctx *ctx, const std::vector<xlz_reader *> &rs, bool big)
                     continue;
                 }
             }
+            if (u.status == ST_PAUSED && (u.aux & AUX_SHADOW) && session_make_shadow(r) != XLZ_OK) st = XLZ_ERR_DEVICE;
             if (((u.aux & AUX_STALE) || u.status == ST_ERR_UNSUPPORTED) && r->streaming) {
                 // (no whole-stream fallback when the input is fed in pieces and dropped behind the decoder)
                 r->finished = true;
@@ -1968,12 +1991,12 @@ void batcher_loop(Batcher *bt)
             bt->pending.pop_front();
         }
         lk.unlock();
-        const int st = sessions_step(bt->ctx, work);
+        (void)sessions_step(bt->ctx, work); // (every reader carries the status of its own launch: step_status)
         lk.lock();
         bt->n_batches++;
         bt->n_streams += work.size();
         for (xlz_reader *r : work) {
-            if (st != XLZ_OK) r->call_status = st;
+            if (r->step_status != XLZ_OK) r->call_status = r->step_status;
             r->refill_pending = false;
         }
         bt->cv_done.notify_all();
@@ -2459,6 +2482,14 @@ extern "C" int xlz_reader_feed_eof(xlz_reader *r)
     if (!r->streaming) return XLZ_ERR_BAD_ARG;
     r->in_eof = true;
     r->need_input = false;
+    return XLZ_OK;
+}
+
+extern "C" int xlz_reader_memory(const xlz_reader *r, uint64_t *window_bytes, uint64_t *image_bytes)
+{
+    if (!r) return XLZ_ERR_BAD_ARG;
+    if (window_bytes) *window_bytes = r->ss ? r->ss->win_cap : 0;
+    if (image_bytes) *image_bytes = (r->ss && r->ss->d_shadow) ? r->ss->unit.dict_size : 0;
     return XLZ_OK;
 }
 

@@ -151,15 +151,18 @@ __device__ __forceinline__ uint32_t stale_byte(const uint8_t *__restrict__ out, 
 // write position has circular index window.pos - 1 - k (mod size; d.wpos IS the reference's wrapped window.pos, so this
 // holds even when the host has slid the epoch's start out of the buffer); the last min(epoch, dictSize) bytes are always
 // still in `out` (the host keeps dictSize bytes of history).
+// The bytes are contiguous in `out` and land on the circular range that ends at window.pos: two plain copies at most,
+// moved 16 bytes per lane like a stored chunk (stored_copy; round 3 moved one byte per lane and step).
+__device__ __forceinline__ void stored_copy(const uint8_t *__restrict__ src, uint8_t *__restrict__ out, uint32_t pos,
+                                            uint32_t n, uint32_t lane);
 __device__ __forceinline__ void shadow_update(Dec &d, const uint8_t *__restrict__ out, uint32_t lane)
 {
     const uint32_t n = min(d.pos - d.wbase, d.dict_size);
-    for (uint32_t base = 0; base < n; base += kWave) {
-        const uint32_t k = min(base + lane, n - 1); // byte out[pos - 1 - k]
-        int64_t ci = (int64_t)d.wpos - 1 - (int64_t)k; // k < size, wpos < size: one wrap at most
-        if (ci < 0) ci += d.dict_size;
-        d.shadow[ci] = out[d.pos - 1 - k];
-    }
+    const uint32_t start = d.wpos >= n ? d.wpos - n : d.wpos + d.dict_size - n; // circular index of out[pos - n]
+    const uint32_t first = min(n, d.dict_size - start);
+    const uint8_t *src = out + (d.pos - n);
+    stored_copy(src, d.shadow, start, first, lane);
+    if (n > first) stored_copy(src + first, d.shadow, 0, n - first, lane);
 }
 
 // dictionary reset (window.Reset): the epoch [wbase, pos) ends; remember it for stale reads
@@ -652,6 +655,9 @@ __device__ __forceinline__ HeadVec head_vectors(uint32_t lane)
     h.lit_next = upd_literal(lane < 12 ? lane : 0); // stateUpdateLiteral as a table: lane = old state
     h.hms = (hj >= 1 && hj <= 4) ? 2u : 0u; // indexed by state
     h.hm2 = (hj == 0 || hj == 5) ? 2u : 0u; // indexed by state2 = (state << 4) + posState
+#ifdef XLZ_HISS // A/B (--variant hiss): address = hc + state * (hms + 16 hm2) + posState * hm2
+    h.hms += 16u * h.hm2;
+#endif
     return h;
 }
 
@@ -662,7 +668,11 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_
     uint32_t exitc;
     uint32_t vlpm; // lp_mask in a VGPR: the literal context is computed on the VALU
     uint32_t vpm;  // pos_mask likewise (head gather addresses)
+#ifdef XLZ_LCTX // A/B (tools/gen_fastpath.py --variant lctx): the literal state is one bit field of lc + lp bits
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vlpm) : "s"(d.lc + (uint32_t)__builtin_popcount(d.lp_mask)));
+#else
     asm volatile("v_mov_b32 %0, %1" : "=v"(vlpm) : "s"(d.lp_mask));
+#endif
     asm volatile("v_mov_b32 %0, %1" : "=v"(vpm) : "s"(d.pos_mask));
     asm volatile(
 #include XLZ_FASTPATH_INC
@@ -979,6 +989,14 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
             }
         }
         if (c == 1 || sub == 7) {      // dictionary reset: window.Reset (:132-134, window.go:135-140)
+            if (w.resumable && !d.shadow && d.pos > d.wbase) {
+                // pull readers: the first dictionary reset behind a non-empty epoch.  The session has no window image yet
+                // (it is allocated when a stream first needs one, not at NewReader2): step back in front of
+                // the chunk and pause; the host allocates the image and the next refill copies the epoch into it.
+                in_window(d, chunk_start, lane);
+                aux |= AUX_SHADOW;
+                return ST_PAUSED;
+            }
             if (d.shadow && d.pos > d.wbase) shadow_update(d, out, lane);
             if (!epoch_push(d)) return ST_ERR_UNSUPPORTED; // more visible epochs than the table holds
             d.wbase = d.pos;
@@ -1160,7 +1178,7 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
             w.have_reader = RFL(st[SV_HAVE_READER]) != 0;
             w.first_chunk = RFL(st[SV_FIRST_CHUNK]) != 0;
             phase = RFL(st[SV_PHASE]);
-            aux = RFL(st[SV_AUX]) & ~(AUX_GROW | AUX_GROW_MASK); // (a request for a larger model is answered by now)
+            aux = RFL(st[SV_AUX]) & ~(AUX_GROW | AUX_GROW_MASK | AUX_SHADOW); // (requests to the host are answered by now)
             // input: continue at the saved position inside the (possibly moved) input window
             // ((*Reader1).Reopen: the input is a new stream, read from its first byte)
             const uint32_t consumed = (flags & UNIT_F_REOPEN) ? d.in_base : RFL(st[SV_CONSUMED]);

@@ -33,7 +33,17 @@ def _render(add=(), remove=()):
     g.VARIANT.difference_update(remove)
     _, final, _ = g.render()
     import layout
-    return final, layout.sizes(final), layout
+    return Program((final, layout.sizes(final), layout), set(g.VARIANT))
+
+
+class Program(tuple):
+    """(instructions, their sizes, the layout module) + the generator switches the loop was made with: some of them
+    change what the C++ around the loop passes in (xlz_kernel.hip: lzma_fast_loop), and so what this harness passes"""
+
+    def __new__(cls, items, variant):
+        self = super().__new__(cls, items)
+        self.variant = variant
+        return self
 
 
 @pytest.fixture(scope="module")
@@ -74,8 +84,12 @@ def run_fast_loop(program, payload, lc, lp, pb, dict_size, size, expect, dpp=Tru
     m.mem["outp"], m.mem["mptr"] = out, mp
     lane = np.arange(64, dtype=np.uint32)
     hc, hms, hm2, litnext = _head_vectors(lane, dpp)
+    variant = getattr(program, "variant", ())
+    if "hiss" in variant:       # head address = hc + state * (hms + 16 hm2) + posState * hm2
+        hms = hms + 16 * hm2
     m.v.update(vlane=lane, vhc=hc, vhms=hms, vhm2=hm2, vlitnext=litnext,
-               vlpm=np.full(64, (1 << lp) - 1, dtype=np.uint32), vpm=np.full(64, (1 << pb) - 1, dtype=np.uint32))
+               vlpm=np.full(64, (lc + lp) if "lctx" in variant else (1 << lp) - 1, dtype=np.uint32),   # lctx: the bit field's width
+               vpm=np.full(64, (1 << pb) - 1, dtype=np.uint32))
     s = m.s
     s.update(range=0xFFFFFFFF, code=int.from_bytes(payload[1:5], "big"), state=0, rep0=0, rep1=0, rep2=0, rep3=0,
              pos=base, wpos=0, prev=0, mb=0, exitc=0, lenout=0, dict=dict_size, dictm1=dict_size - 1,

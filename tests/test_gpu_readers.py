@@ -408,9 +408,11 @@ def test_readers_read_behind_dictionary_resets_from_the_window_image(ctx):
         for piece in (None, 1000, 70_000):
             r, err = lzma_amd.NewReader2(ctx, blob if piece is None else io.BytesIO(blob), ds, piece or (1 << 20))
             assert err is None
+            assert r.memory()[1] == 0           # no image before the stream asks for one (it was allocated here)
             out, e = r.read_all(chunk=100_000)
             assert e is None and out == want, (ds, piece)
             assert r.stats()[1] == 0
+            assert r.memory()[1] == ds          # made at the first dictionary reset behind a non-empty epoch
     # the small crafted streams of tests/test_crafted_streams.py (unwritten / short / wrapped previous epoch), fed
     from test_crafted_streams import crafted_lzma2
     for name, b, ds, cap, want in crafted_lzma2():
@@ -418,6 +420,34 @@ def test_readers_read_behind_dictionary_resets_from_the_window_image(ctx):
             r, err = lzma_amd.NewReader2(ctx, b if piece is None else io.BytesIO(b), ds, piece or (1 << 20))
             out, e = r.read_all(chunk=999)
             assert e is None and out == want and r.stats()[1] == 0, (name, piece)
+
+
+def test_a_stream_with_one_dictionary_epoch_never_allocates_a_window_image(ctx):
+    """every NewReader2 paid dictSize bytes of HBM and a memset for an image only malformed streams
+    read.  Now the wave asks for it at the first dictionary reset behind a non-empty epoch: an ordinary stream (one
+    epoch, here with a 64 MiB dictionary) never does, a stream of several epochs gets it when the second one starts --
+    and decodes the same bytes either way (liblzma streams; the oracle agrees with liblzma on them)."""
+    import corpus
+    p = corpus.plain("T", 31, 3 << 20)
+    one = corpus.compress_raw_lzma2(p, dict_size=64 << 20)
+    r, err = lzma_amd.NewReader2(ctx, one, 64 << 20)
+    assert err is None
+    out, e = r.read_all(chunk=1 << 20)
+    assert e is None and out == p
+    win, image = r.memory()
+    assert image == 0 and win < (16 << 20)      # O(stream) for a short stream, not O(dictSize)
+    # three epochs (segments that each begin with a dictionary reset), read through a session (fed: the parallel-refill
+    # path needs the whole stream at hand): the image appears with the second epoch and the bytes are the plaintext's
+    import io
+    segs = [corpus.plain("T", 40 + k, 700_000) for k in range(3)]
+    blob = b"".join(corpus.compress_raw_lzma2(x, dict_size=1 << 20)[:-1] for x in segs) + b"\x00"
+    r, err = lzma_amd.NewReader2(ctx, io.BytesIO(blob), 1 << 20, 50_000)
+    assert err is None
+    first, e = r.Read(100_000)
+    assert e is None and r.memory()[1] == 0
+    rest, e = r.read_all(chunk=1 << 20)
+    assert e is None and first + rest == b"".join(segs)
+    assert r.memory()[1] == 1 << 20 and r.stats()[1] == 0
 
 
 def test_a_reader_grows_its_model_when_a_later_chunk_brings_larger_properties(ctx):

@@ -133,3 +133,27 @@ def test_damaged_headers_do_not_derail_the_scan():
                  stored(9, True) + b"\x00" + stored(9, True) + b"\x00", b"", b"\x00", b"\x7f"):
         units = lzma_amd.lzma2_units(blob)
         assert units[0]["in_off"] == 0 and sum(u["in_len"] for u in units) == len(blob)
+
+
+def test_a_stream_beyond_4_gib_is_planned_with_64_bit_offsets():
+    """the scan kept unit offsets in 32 bits, so the plan of a stream of 4 GiB and more wrapped silently.
+    4.3 GiB of stored chunks (a sparse buffer: only the pages with chunk headers are touched): 65 600 chunks, one
+    unit per 256 KiB, offsets beyond 2^32 intact"""
+    import numpy as np
+    n_chunks, body = 65_600, 65_536
+    buf = np.zeros(n_chunks * (body + 3) + 1, dtype=np.uint8)
+    at = np.arange(n_chunks, dtype=np.int64) * (body + 3)
+    buf[at] = 2
+    buf[0] = 1
+    buf[at + 1] = 0xFF
+    buf[at + 2] = 0xFF
+    assert buf.size > 1 << 32
+    units = lzma_amd.lzma2_units(buf)
+    assert len(units) == n_chunks // 4
+    assert units[0]["in_off"] == 0 and units[0]["out_off"] == 0
+    for k in (1, 1000, len(units) - 1):
+        assert units[k]["in_off"] == 4 * k * (body + 3) and units[k]["out_off"] == 4 * k * body
+        assert units[k]["out_len"] == 4 * body or k == len(units) - 1
+    last = units[-1]
+    assert last["in_off"] > 1 << 32 and last["in_off"] + last["in_len"] == buf.size
+    assert last["out_off"] + last["out_len"] == n_chunks * body

@@ -421,6 +421,16 @@ class Machine:
     def i_v_mad_u32_u24(self, o, m):
         self.wv(o[0], (self.rv(o[1]) & np.uint64(0xFFFFFF)) * (self.rv(o[2]) & np.uint64(0xFFFFFF)) + self.rv(o[3]))
 
+    def i_v_mad_i32_i24(self, o, m):
+        def s24(x):
+            x = (x & np.uint64(0xFFFFFF)).astype(np.int64)
+            return np.where(x >= (1 << 23), x - (1 << 24), x)
+        r = s24(self.rv(o[1])) * s24(self.rv(o[2])) + self.rv(o[3]).astype(np.int64)
+        self.wv(o[0], (r & M32).astype(np.uint64))
+
+    def i_v_xor_b32(self, o, m):
+        self._v2(o, lambda a, b: a ^ b)
+
     def i_v_lshl_add_u32(self, o, m):
         self.wv(o[0], (self.rv(o[1]) << (self.rv(o[2]) & np.uint64(31))) + self.rv(o[3]))
 

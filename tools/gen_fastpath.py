@@ -477,7 +477,7 @@ def walk(nbits, blocks, early_exit=None, filler="s_nop 0"):
             nchk()
 
 
-def tree_update(nb, blocks, base="v58"):
+def tree_update(nb, blocks, base="v58", addr=None, off=0, dump="v38"):
     """Apply the model updates of a finished walk.  s88 = final slot (1, then the complemented
     bits), `blocks` = the tree's block registers (lane j of block b = slot 64b + j), `base` = VGPR
     with the byte address of the tree.  nb: int, or the name of an SGPR (single-block trees).
@@ -487,6 +487,26 @@ def tree_update(nb, blocks, base="v58"):
     registers that are already there -- nothing is recorded during the walk.  Only visited
     slots are stored (a block register may overlap other tables and be stale there); the other
     lanes store to the unused slot whose address is in v38.  Single-block trees."""
+    if "tu8" in VARIANT:
+        # tu8 (round 4): eight instructions instead of eleven, and no base register to prepare.  v61 = 2 * slot + !bit of
+        # the lane's level; XOR with 2 * lane (v56) is 0 / 1 exactly in the visited lanes and then IS !bit; one multiply-add
+        # forms p - 2017 * !bit (s85 = -2017); the store goes to `addr` (+ offset: the VGPR the block was requested with), the
+        # other lanes to `dump` (a VGPR or an inline constant: an unused slot, relative to the same offset)
+        assert "tuc" in VARIANT and addr
+        if nb in (3, 4, 6):
+            emit("v_lshrrev_b32 v61, %s, s88" % {3: "v14", 4: "v15", 6: "v16"}[nb])
+        else:
+            emit("v_sub_u32 v55, %s, v31\nv_lshrrev_b32 v61, v55, s88" % nb)
+        emit("""
+        v_xor_b32 v60, v61, v56
+        v_cmp_gt_u32 vcc, 2, v60
+        v_mad_i32_i24 v61, v60, s85, %s
+        v_ashrrev_i32 v61, 5, v61
+        v_sub_u32 v61, %s, v61
+        v_cndmask_b32 v60, %s, %s, vcc
+        ds_write_b16 v60, v61%s
+        """ % (blocks[0], blocks[0], dump, addr, (" offset:%d" % off) if off else ""))
+        return
     own = "v30"
     if "tuc" in VARIANT and nb in (3, 4, 6):  # nb - level(lane) is a loop constant: v14 / v15 / v16
         emit("v_lshrrev_b32 v61, %s, s88" % {3: "v14", 4: "v15", 6: "v16"}[nb])
@@ -684,6 +704,11 @@ def gather8(blocks, dst="v54"):
     """ % (blocks[0], blocks[1], blocks[2], blocks[3], dst, dst, dst))
 
 
+def lit_off(base):
+    """lctx: the literal table is addressed relative to its start (v39 = litState << 9); the LDS instructions carry P_LIT"""
+    return P_LIT * 2 if ("lctx" in VARIANT and base == "v39") else 0
+
+
 def rec_gather_issue(base, masked):
     """lgather: nothing was recorded during the walk: the eight probabilities it met are read back from LDS
     with ONE 8-lane gather at the addresses the update stores to anyway (instead of eight v_writelane),
@@ -694,12 +719,14 @@ def rec_gather_issue(base, masked):
     v_lshrrev_b32 v60, v19, s88
     v_lshl_add_u32 v60, v60, 1, %s
     """ % base)
+    off = lit_off(base)
+    dump = "0" if off else "v38"   # (relative addressing: slot 0 of the first literal state's tree, which no walk visits)
     if masked:
-        emit("v_cndmask_b32 v60, v60, v38, vcc")
+        emit("v_cndmask_b32 v60, v60, %s, vcc" % dump)
     emit("""
-    v_cndmask_b32 v60, v38, v60, s[76:77]
-    ds_read_u16 %s, v60
-    """ % ("v33" if masked else "v54"))
+    v_cndmask_b32 v60, %s, v60, s[76:77]
+    ds_read_u16 %s, v60%s
+    """ % (dump, "v33" if masked else "v54", (" offset:%d" % off) if off else ""))
 
 
 def tree_update_rec(nb, base, store=True, issued=False, pending=0, filler=None):
@@ -711,22 +738,20 @@ def tree_update_rec(nb, base, store=True, issued=False, pending=0, filler=None):
         if not issued:
             rec_gather_issue(base, masked=not store)
             pending = 0
-        emit("""
-        v_bfe_u32 v61, s88, v18, 1
-        v_mul_u32_u24 v61, 0x7e1, v61
-        """)
+        tu8 = "tu8" in VARIANT
+        emit("v_bfe_u32 v61, s88, v18, 1" + ("" if tu8 else "\nv_mul_u32_u24 v61, 0x7e1, v61"))
         if filler:
             filler()  # independent work of the caller in front of the wait
         emit("s_waitcnt lgkmcnt(%d)" % pending)
         if not store:
             emit("v_cndmask_b32 v54, v33, v54, vcc")
+        emit("v_mad_i32_i24 v61, v61, s85, v54" if tu8 else "v_sub_u32 v61, v54, v61")   # p - 2017 * !bit (s85 = -2017)
         emit("""
-        v_sub_u32 v61, v54, v61
         v_ashrrev_i32 v61, 5, v61
         v_sub_u32 v61, v54, v61
         """)
         if store:
-            emit("ds_write_b16 v60, v61")
+            emit("ds_write_b16 v60, v61" + ((" offset:%d" % lit_off(base)) if lit_off(base) else ""))
         return
     emit("""
     v_lshrrev_b32 v60, v19, s88
@@ -744,12 +769,13 @@ def tree_update_rec(nb, base, store=True, issued=False, pending=0, filler=None):
 def len_request(base):
     """request the low and mid length trees of this posState (blocks v41, v42; v22 = posState, on
     the VALU).  The high tree (four blocks) is rare and is requested where it is needed."""
+    av = "v58" if "tu8" in VARIANT else "v59"   # tu8: the update stores through the request's own address vector
     emit("""
     v_and_b32 v22, %%[wpos], %%[vpm]
-    v_lshl_add_u32 v59, v22, 4, v56
-    ds_read_u16 v41, v59 offset:%d
-    ds_read_u16 v42, v59 offset:%d
-    """ % ((base + LEN_LOW) * 2, (base + LEN_MID) * 2))
+    v_lshl_add_u32 AV, v22, 4, v56
+    ds_read_u16 v41, AV offset:%d
+    ds_read_u16 v42, AV offset:%d
+    """.replace("AV", av) % ((base + LEN_LOW) * 2, (base + LEN_MID) * 2))
 
 
 def len_pick(lane_c):
@@ -765,7 +791,7 @@ def posslot_request(static):
         emit("s_movk_i32 s92, %d" % ((P_POS_SLOT + 3 * 64) * 2))
     else:
         emit("v_readlane_b32 s92, v21, s89")  # table: lane = length 0..7 -> base of posSlot[min(len, 3)]
-    emit("v_add_u32 v59, s92, v56\nds_read_u16 v36, v59")
+    emit("v_add_u32 v57, s92, v56\nds_read_u16 v36, v57" if "tu8" in VARIANT else "v_add_u32 v59, s92, v56\nds_read_u16 v36, v59")
 
 
 def len_decode(tag, base, lane_c, lane_c2, posslot):
@@ -773,11 +799,12 @@ def len_decode(tag, base, lane_c, lane_c2, posslot):
     posslot: request the distance-slot block as soon as the length is known (simple match)."""
     hbit(lane_c, L(tag + "c2"), stage=2)  # bounds("v40") and the lane read: len_prefetch
     emit("s_waitcnt lgkmcnt(0)")
-    walk(3, ["v41"], filler="v_lshlrev_b32 v58, 4, v22\nv_add_u32 v58, %d, v58" % ((base + LEN_LOW) * 2))
+    tu8 = "tu8" in VARIANT
+    walk(3, ["v41"], filler="" if tu8 else "v_lshlrev_b32 v58, 4, v22\nv_add_u32 v58, %d, v58" % ((base + LEN_LOW) * 2))
     emit("s_andn2_b32 s89, 7, s88")
     if posslot:
         posslot_request(False)
-    tree_update(3, ["v41"])
+    tree_update(3, ["v41"], addr="v58", off=(base + LEN_LOW) * 2, dump="0")
     label(tag + "end")  # the common (low) path runs straight on; mid and high trees are out of line
     deferred.append(lambda: len_decode_rest(tag, base, lane_c, lane_c2, posslot))
 
@@ -787,11 +814,11 @@ def len_decode_rest(tag, base, lane_c, lane_c2, posslot):
     hbit_one(lane_c, next_head=lane_c2)
     hbit(lane_c2, L(tag + "hi"), stage=2)
     emit("s_waitcnt lgkmcnt(0)")
-    walk(3, ["v42"], filler="v_lshlrev_b32 v58, 4, v22\nv_add_u32 v58, %d, v58" % ((base + LEN_MID) * 2))
+    walk(3, ["v42"], filler="" if "tu8" in VARIANT else "v_lshlrev_b32 v58, 4, v22\nv_add_u32 v58, %d, v58" % ((base + LEN_MID) * 2))
     emit("s_xor_b32 s89, s88, 7")
     if posslot:
         posslot_request(True)
-    tree_update(3, ["v42"])
+    tree_update(3, ["v42"], addr="v58", off=(base + LEN_MID) * 2, dump="0")
     emit("s_branch %s" % L(tag + "end"))
     label(tag + "hi")
     hbit_one(lane_c2)
@@ -837,13 +864,14 @@ def tree_update_rec_hbm(base):
     v_cndmask_b32_e64 v60, 0, v60, s[76:77]
     global_load_ushort v54, v60, %%[mptr]
     v_bfe_u32 v61, s88, v18, 1
-    v_mul_u32_u24 v61, 0x7e1, v61
+    MUL
     s_waitcnt vmcnt(0)
-    v_sub_u32 v61, v54, v61
+    SUB
     v_ashrrev_i32 v61, 5, v61
     v_sub_u32 v61, v54, v61
     global_store_short v60, v61, %%[mptr]
-    """ % base)
+    """.replace("MUL", "" if "tu8" in VARIANT else "v_mul_u32_u24 v61, 0x7e1, v61")
+       .replace("SUB", "v_mad_i32_i24 v61, v61, s85, v54" if "tu8" in VARIANT else "v_sub_u32 v61, v54, v61") % base)
 
 
 wstubs = []
@@ -939,7 +967,19 @@ def literal_context(prev_v=None, part=None):
         if prev_v is None:
             emit("v_mov_b32 v55, %[prev]")
             prev_v = "v55"
-        emit("""
+        if "lctx" in VARIANT:
+            # lctx (round 4): litState = ((window.pos & lpMask) << lc) + (prevByte >> (8 - lc)) (decompress.go:56) is ONE bit
+            # field of (window.pos << 8 | prevByte): a byte permute (the normalisation's selector v13 puts the low byte of
+            # its second source under the low three bytes of the first) and a bit-field extract of lc + lp bits (%[vlpm] holds
+            # lc + lp in this variant).  Only the low byte of prev_v is looked at, so the literal's byte needs no mask.
+            emit("""
+            v_perm_b32 v57, %%[wpos], %s, v13
+            v_bfe_u32 v55, v57, %%[lc8], %%[vlpm]
+            v_lshlrev_b32 v39, 9, v55
+            v_add_u32 v59, v39, v56
+            """ % prev_v)
+        else:
+          emit("""
         v_and_b32 v57, %%[wpos], %%[vlpm]
         v_lshlrev_b32 v57, %%[lc], v57
         v_lshrrev_b32 v55, %%[lc8], %s
@@ -948,12 +988,13 @@ def literal_context(prev_v=None, part=None):
         v_add_u32 v59, v39, v56
         """ % (prev_v, P_LIT * 2))
     if part != "addr":
+        o = P_LIT * 2 if "lctx" in VARIANT else 0
         emit("""
-        ds_read_u16 v50, v59
-        ds_read_u16 v51, v59 offset:128
-        ds_read_u16 v52, v59 offset:256
-        ds_read_u16 v53, v59 offset:384
-        """)
+        ds_read_u16 v50, v59%s
+        ds_read_u16 v51, v59 offset:%d
+        ds_read_u16 v52, v59 offset:%d
+        ds_read_u16 v53, v59 offset:%d
+        """ % ((" offset:%d" % o) if o else "", o + 128, o + 256, o + 384))
 
 
 def head_issue(first=False):
@@ -961,6 +1002,16 @@ def head_issue(first=False):
     to start (addresses from its posState / state2, on the VALU)"""
     if not first:
         emit("ds_write_b16 v47, v40")
+    if "hiss" in VARIANT:
+        # hiss (round 4): address = hc + state * hms + (state << 4 | posState) * hm2 = hc + state * (hms + 16 hm2) + posState * hm2;
+        # %[vhms] holds hms + 16 hm2 in this variant: one instruction less per packet
+        emit("""
+        v_and_b32 v55, %[wpos], %[vpm]
+        v_mad_u32_u24 v47, %[state], %[vhms], %[vhc]
+        v_mad_u32_u24 v47, v55, %[vhm2], v47
+        ds_read_u16 v40, v47
+        """)
+        return
     emit("""
     v_and_b32 v55, %[wpos], %[vpm]
     v_lshl_add_u32 v55, %[state], 4, v55
@@ -981,7 +1032,7 @@ def literal_tail(run_entry=None):
     if "vprev" in VARIANT:
         # the byte (the complement of the slot's low eight bits) is formed on the VALU; the scalar copy of prevByte
         # is only brought up to date where the loop is left (sec_exits): one scalar instruction less per literal
-        emit("v_not_b32 v32, s88\nv_and_b32 v32, 0xff, v32")
+        emit("v_not_b32 v32, s88" + ("" if "lctx" in VARIANT else "\nv_and_b32 v32, 0xff, v32"))
     else:
         emit("s_andn2_b32 %[prev], 0xff, s88\nv_mov_b32 v32, %[prev]")
     if nopos():
@@ -1151,19 +1202,19 @@ def sec_packet_general():
     # already in v50..v53.  s98 = levels decided in the matched table.
     label("mlit")
     emit("""
-    v_min_u32 v55, 7, %%[vlane]
-    s_xor_b32 s89, %%[mb], 0x1ff
+    v_min_u32 v55, 7, %[vlane]
+    s_xor_b32 s89, %[mb], 0x1ff
     v_sub_u32 v60, 8, v55
     v_lshrrev_b32 v60, v60, s89
     v_sub_u32 v61, 7, v55
-    v_lshrrev_b32 v61, v61, %%[mb]
+    v_lshrrev_b32 v61, v61, %[mb]
     v_and_b32 v61, 1, v61
     v_lshl_or_b32 v60, v61, 8, v60
-    v_add_u32 v61, %d, v39
-    v_add_lshl_u32 v57, v60, v61, 1
-    global_load_ushort v54, v57, %%[mptr] offset:512
+    MLBASE
+    global_load_ushort v54, v57, %[mptr] offset:512
     s_waitcnt vmcnt(0)
-    """ % ((-P_LIT * 2) & 0xffffffff))
+    """.replace("MLBASE", "v_add_lshl_u32 v57, v60, v39, 1" if "lctx" in VARIANT else
+                "v_add_u32 v61, %d, v39\nv_add_lshl_u32 v57, v60, v61, 1" % ((-P_LIT * 2) & 0xffffffff)))
     # matched levels: the eight candidate probabilities are lanes 0..7 of v54, so the bound of
     # level k is lane k of the VALU product (no record needed: v54 itself is the record)
     bounds("v54")
@@ -1207,9 +1258,9 @@ def sec_packet_general():
     if lgather():  # (v60 is masked already)
         emit("""
         v_cndmask_b32 v57, 0, v57, vcc
-        global_store_short v57, v61, %[mptr] offset:512
-        ds_write_b16 v60, v61
-        """)
+        global_store_short v57, v61, %%[mptr] offset:512
+        ds_write_b16 v60, v61%s
+        """ % ((" offset:%d" % lit_off("v39")) if lit_off("v39") else ""))
     else:
         emit("""
         v_cndmask_b32 v57, 0, v57, vcc
@@ -1242,14 +1293,14 @@ def sec_match():
     emit("ds_read_u16 v35, v56 offset:%d" % (P_ALIGN * 2))
     len_decode("lm", P_LEN, H_LEN_C, H_LEN_C2, posslot=True)  # leaves the posSlot block requested, s92 = its base
     emit("s_waitcnt lgkmcnt(0)")
-    walk(6, ["v36"], filler="v_readlane_b32 %[state], v20, %[state]\nv_mov_b32 v58, s92")  # stateUpdateMatch as a table
+    walk(6, ["v36"], filler="v_readlane_b32 %[state], v20, %[state]" + ("" if "tu8" in VARIANT else "\nv_mov_b32 v58, s92"))  # stateUpdateMatch as a table
     emit("""
     s_andn2_b32 s98, 63, s88
     s_cmp_lt_u32 s98, 4
     s_cbranch_scc0 %s
     s_mov_b32 %%[rep0], s98
     """ % L("dist"))
-    tree_update(6, ["v36"])
+    tree_update(6, ["v36"], addr="v57")
     emit("s_branch %s" % L("distdone"))
     label("dist")
     # numDirectBits = (slot >> 1) - 1 and the distance's base (2 | slot & 1) << numDirectBits
@@ -1265,12 +1316,12 @@ def sec_match():
     v_add_u32 v59, s92, v56
     ds_read_u16 v37, v59
     """ % (L("direct"), P_POS_DEC))
-    tree_update(6, ["v36"])  # posSlot tree, while the posDecoders block is on its way
+    tree_update(6, ["v36"], addr="v57")  # posSlot tree, while the posDecoders block is on its way
     # reverse bit tree over posDecoders (:495-546): s83 levels (1..5)
     emit("s_waitcnt lgkmcnt(0)")
-    walk(5, ["v37"], early_exit=("s98", L("rtdone")), filler="v_mov_b32 v58, s92\ns_mov_b32 s98, s83")
+    walk(5, ["v37"], early_exit=("s98", L("rtdone")), filler=("" if "tu8" in VARIANT else "v_mov_b32 v58, s92\n") + "s_mov_b32 s98, s83")
     label("rtdone")
-    tree_update("s98", ["v37"])
+    tree_update("s98", ["v37"], addr="v59")
     emit("""
     s_not_b32 s80, s88
     s_brev_b32 s80, s80
@@ -1280,7 +1331,7 @@ def sec_match():
     s_branch %s
     """ % L("distdone"))
     label("direct")  # DecodeDirectBits (:549-577)
-    tree_update(6, ["v36"])  # posSlot tree
+    tree_update(6, ["v36"], addr="v57")  # posSlot tree
     # numDirectBits - 4 = s83 - 4 (2..26) halvings, unrolled; entered through a branch table so
     # that no loop counter is kept.  Exactly the reference's arithmetic: t = sign(code - range).
     # Only the range stays on the scalar side (its normalisation test needs SCC): the code (v29)
@@ -1291,14 +1342,26 @@ def sec_match():
     s_sub_u32 s82, 35, s83
     s_lshl2_add_u32 s80, s82, s80
     s_addc_u32 s81, s81, 0
-    v_mov_b32 v33, 0
+    v_mov_b32 v33, DB0
     s_setpc_b64 s[80:81]
-    """)  # s_getpc returns the address of the s_sub; the table starts 5 instructions (all 4 bytes) later:
+    """.replace("DB0", "-1" if "db6" in VARIANT else "0"))  # s_getpc returns the address of the s_sub; the table starts 5 instructions (all 4 bytes) later:
     # entry e = 26 - (s83 - 4) is at +4 * (e + 5) = 4 * (35 - s83)
     for k in range(26, 0, -1):
         emit("s_branch %s" % L("db%d" % k))
     for k in range(26, 0, -1):
         label("db%d" % k)
+        if "db6" in VARIANT:
+            # db6 (round 4): the subtract's borrow IS the complemented bit and an unsigned min selects the new code (as in
+            # decide()): six instructions per bit instead of eight.  v33 collects the borrows below a run of ones (it
+            # starts as -1), so that the bits are its complement: rep0's base takes -(v33 << 4) = 16 * bits + 16, and the
+            # align table v23 holds its values minus 16.
+            emit("""
+            s_lshr_b32 %[range], %[range], 1
+            v_subrev_co_u32 v55, vcc, %[range], v29
+            v_min_u32 v29, v29, v55
+            """)
+            nchk(mid="v_addc_co_u32 v33, vcc, v33, v33, vcc")
+            continue
         emit("""
         s_lshr_b32 %[range], %[range], 1
         v_subrev_u32 v55, %[range], v29
@@ -1327,12 +1390,43 @@ def sec_match():
         global_load_dword v27, v26, %[outp]
         """)  # (v27 is written by nothing else: a prefetch still in flight cannot disturb the next one's address in v26)
     # reverse tree over alignDecoderProbs (:579-625): M = 1 b0 b1 b2 b3
-    walk(4, ["v35"], filler="s_add_u32 s93, s93, s84\nv_mov_b32 v58, %d" % (P_ALIGN * 2))
-    tree_update(4, ["v35"])
+    walk(4, ["v35"], filler="%s s93, s93, s84" % ("s_sub_u32" if "db6" in VARIANT else "s_add_u32")
+         + ("" if "tu8" in VARIANT else "\nv_mov_b32 v58, %d" % (P_ALIGN * 2)))
+    tree_update(4, ["v35"], addr="v56", off=P_ALIGN * 2, dump="%d" % ((P_LEN + 2) * 2 - P_ALIGN * 2))
     emit("v_readlane_b32 s80, v23, s88\ns_add_u32 %[rep0], s93, s80")  # v23: slot -> the four bits, reversed
     label("distdone")
     if "vreps" in VARIANT:
         emit("v_writelane_b32 v34, %[rep0], 0")
+    if "cchk" in VARIANT:
+        # cchk (round 4): ONE window test for a new distance.  rep0 < fill (fill = bytes in the window: window.pos, or
+        # dictSize once it is full) says at once that the distance is valid (:651-653: rep0 < dictSize, rep0 <= pos) AND that
+        # the copy's source lies inside the window's bytes -- the two tests sec_match and sec_copy made one after the
+        # other.  The rare rest (rep0 == fill: the reference's off-by-one distance, window.go:89-91; an invalid
+        # distance; the end marker) is told apart out of line.  The copy then only asks whether it is one of its own
+        # (shorter than 64 bytes and than its distance).  Four scalar instructions less per simple match.
+        assert nopos()
+        emit("""
+        s_max_u32 s81, %%[wpos], s94
+        s_cmp_lt_u32 %%[rep0], s81
+        s_cbranch_scc0 %s
+        s_add_u32 s89, s89, 2
+        s_add_u32 s93, %%[rep0], 1
+        s_min_u32 s80, s93, 64
+        s_cmp_lt_u32 s89, s80
+        s_cbranch_scc0 %s
+        """ % (L("dslow"), L("x3")))  # falls into the copy itself (sec_copy: copygo); the rep paths' full test lies out of line
+
+        def dslow():
+            label("dslow")  # rep0 >= fill: valid iff rep0 <= min(fill, dictSize - 1); then the source reaches in front of the window
+            emit("""
+            s_min_u32 s80, s81, %%[dictm1]
+            s_cmp_le_u32 %%[rep0], s80
+            s_cbranch_scc0 %s
+            s_add_u32 s89, s89, 2
+            s_branch %s
+            """ % (L("dbad"), L("x3")))
+        deferred.append(dslow)
+        return
     # :633-653 in one test.  rep0 is valid iff rep0 < dictSize and (window full or rep0 <= window.pos);
     # while the window is not full window.pos = pos - wbase < dictSize, so both say
     # rep0 <= min(pos - wbase, dictSize - 1).  The end marker (rep0 = 0xFFFFFFFF) fails it too
@@ -1411,6 +1505,14 @@ def sec_rep():
 def sec_copy():
     """window.CopyMatch of short non-overlapping matches; falls into the general packet head"""
     # ------------------------------------------------------------- window.CopyMatch (window.go:55-87)
+    if "cchk" in VARIANT:  # (the simple match has made its own test and falls into copygo)
+        deferred.append(lambda: (copy_test(), emit("s_branch %s" % L("copygo"))))
+    else:
+        copy_test()
+    copy_body()
+
+
+def copy_test():
     label("copy")
     # done here if len < 64, len < distance (no overlap) and the source lies inside the window's
     # bytes; one test: the distance, or "too far" when the first two fail, against pos - wbase
@@ -1423,6 +1525,11 @@ def sec_copy():
     s_cmp_le_u32 s80, s81
     s_cbranch_scc0 %s
     """.replace("FILL", "s_max_u32 s81, %%[wpos], s94" if nopos() else "s_sub_u32 s81, %%[pos], %%[wbase]") % L("x3"))
+
+
+def copy_body():
+    if "cchk" in VARIANT:
+        label("copygo")
     need_copy_done(inline=True)  # the new source may overlap the bytes the pending copy still has to store
     emit("v_add_u32 v48, %s, %%[vlane]\nv_subrev_u32 v61, s93, v48" % ("v17" if nopos() else "%[pos]"))
     if "nocmask" in VARIANT:
@@ -1464,7 +1571,7 @@ def sec_exits():
     emit("v_readfirstlane_b32 %[code], v29")
     need_copy_done()
     if "vprev" in VARIANT:
-        emit("v_readfirstlane_b32 %[prev], v32")
+        emit("v_readfirstlane_b32 %[prev], v32" + ("\ns_and_b32 %[prev], %[prev], 0xff" if "lctx" in VARIANT else ""))
     if nopos():
         emit("v_readfirstlane_b32 %[pos], v17")
     if "warel" in VARIANT:
@@ -1510,8 +1617,13 @@ def gen():
     v_bfrev_b32 v23, v23
     v_lshrrev_b32 v23, 28, v23
     """)
+    if "db6" in VARIANT:
+        assert "pref" not in VARIANT
+        emit("v_add_u32 v23, -16, v23")
     if "tuc" in VARIANT:
         emit("v_sub_u32 v14, 3, v31\nv_sub_u32 v15, 4, v31\nv_sub_u32 v16, 6, v31")
+    if "tu8" in VARIANT:
+        emit("s_movk_i32 s85, -2017")
     if "vnorm" in VARIANT:
         emit("v_mov_b32 v17, 0x1000000")
     if "vperm" in VARIANT:
