@@ -7,6 +7,9 @@
 // (XLZ_NEED_INPUT -> xlz_reader_feed), and the decoded side arrives one refill chunk at a time
 // (include/xlz.h) -- a reader's memory does not depend on the stream's size.
 //
+// Below the break-even (16 units per host thread: xlz_batch_advice) the constructors return the reference's OWN
+// readers -- the library has no CPU decoder, the reference package is the CPU side (SetExpectedConcurrency).
+//
 // NOT COMPILED IN THIS REPOSITORY: the build image has no Go toolchain (go, gccgo: not found).
 // The same C entry points are exercised by a plain C caller (tests/c/reader_demo.c) and through
 // ctypes (lzma_amd/__init__.py, tests/).  cgo rules this file follows: no Go pointer to memory
@@ -24,13 +27,73 @@ package lzmagpu
 import "C"
 
 import (
+	"bytes"
 	"errors"
 	"fmt"
 	"io"
 	"runtime"
 	"sync"
+	"sync/atomic"
 	"unsafe"
+
+	ref "github.com/kulaginds/lzma" // the reference package itself: the CPU side of the break-even (below)
 )
+
+// ---- the CPU side of the break-even ------------------------------------------------------------------
+// One GPU wave decodes one unit -- an LZMA1 stream, one dictionary-reset unit of an LZMA2 stream -- about 18 times
+// slower than one host core decodes it (include/xlz.h: xlz_batch_advice; bench.py: stream_count_sweep), so the GPU
+// only wins when a call or a set of concurrent readers brings at least 16 units per host thread the application
+// could use instead.  libxlz.so has no CPU decoder (and must not have one: the product path fails loudly without
+// a device); the shim's fallback is the reference's OWN readers (reader1.go:18-24, reader2.go:26-41): below the
+// break-even the constructors return a Reader1 / Reader2 that wraps lzma.NewReader1 / lzma.NewReader2.
+//
+// What the shim cannot see is how many readers the application runs at once: SetExpectedConcurrency says it
+// (default 1: a lone NewReader1 + io.Copy stays on the CPU, exactly as fast as before the shim was linked in;
+// a server that keeps hundreds of readers in flight sets it once and gets coalesced GPU launches).
+
+var expectedReaders atomic.Int64
+
+// HostThreads is the number of host threads the application would decode with (0: GOMAXPROCS).
+var HostThreads = 0
+
+// ForceGPU routes every reader to the device whatever the break-even says (tests, benchmarks).
+var ForceGPU = false
+
+func init() { expectedReaders.Store(1) }
+
+// SetExpectedConcurrency tells the shim how many readers the application keeps in flight at once.
+func SetExpectedConcurrency(n int) {
+	if n < 1 {
+		n = 1
+	}
+	expectedReaders.Store(int64(n))
+}
+
+// BreakEvenUnits is xlz_batch_advice's rule: 16 units per host thread.
+func BreakEvenUnits() int {
+	t := HostThreads
+	if t <= 0 {
+		t = runtime.GOMAXPROCS(0)
+	}
+	return 16 * t
+}
+
+// worthTheDevice: `units` of this reader plus one unit for each of the other readers expected in flight.
+func worthTheDevice(units int) bool {
+	return ForceGPU || units+int(expectedReaders.Load())-1 >= BreakEvenUnits()
+}
+
+// lzma2Units counts the units the device would launch for the part of a raw LZMA2 stream at hand (xlz_lzma2_units,
+// host only): a stream written by a multi-threaded encoder is hundreds of units although it is one reader.
+func lzma2Units(data []byte) int {
+	p, n := cbuf(data)
+	var units C.size_t
+	if st := C.xlz_lzma2_units(p, n, nil, 0, &units); st != C.XLZ_OK {
+		return 1
+	}
+	runtime.KeepAlive(data)
+	return int(units)
+}
 
 // The reference's sentinels (errors.go:5-12, reader1.go:26, reader2.go:43, readcloser.go:14).
 var (
@@ -171,14 +234,29 @@ func (r *handle) read(p []byte) (int, error) {
 	}
 }
 
-// Reader1 replaces lzma.Reader1 (reader1.go:10-16).
-type Reader1 struct{ *handle }
+// Reader1 replaces lzma.Reader1 (reader1.go:10-16).  cpu != nil: below the break-even -- the reference's own reader.
+type Reader1 struct {
+	*handle
+	cpu *ref.Reader1
+}
+
+// OnDevice reports whether this reader decodes on the GPU (false: the reference's CPU reader, below the break-even).
+func (r *Reader1) OnDevice() bool { return r.cpu == nil }
 
 // Read is (*Reader1).Read (reader1.go:223-254).
-func (r *Reader1) Read(p []byte) (int, error) { return r.read(p) }
+func (r *Reader1) Read(p []byte) (int, error) {
+	if r.cpu != nil {
+		return r.cpu.Read(p)
+	}
+	return r.read(p)
+}
 
 // Reset is (*Reader1).Reset (reader1.go:161-164).
 func (r *Reader1) Reset() {
+	if r.cpu != nil {
+		r.cpu.Reset()
+		return
+	}
 	C.xlz_reader_reset(r.h)
 	runtime.KeepAlive(r)
 }
@@ -187,6 +265,9 @@ func (r *Reader1) Reset() {
 // constructors it takes the FIRST piece of the source now and feeds the rest as the decoder asks for it
 // (xlz_reader_expect_more is accepted right after xlz_reader_reopen): the source is never slurped.
 func (r *Reader1) Reopen(inStream io.ByteReader, unpackSize uint64) error {
+	if r.cpu != nil {
+		return r.cpu.Reopen(inStream, unpackSize)
+	}
 	data, rest, err := firstPiece(asReader(inStream))
 	if err != nil {
 		return err
@@ -209,11 +290,22 @@ func (r *Reader1) Reopen(inStream io.ByteReader, unpackSize uint64) error {
 	return readError(st)
 }
 
-// Reader2 replaces lzma.Reader2 (reader2.go:10-24).
-type Reader2 struct{ *handle }
+// Reader2 replaces lzma.Reader2 (reader2.go:10-24).  cpu != nil: below the break-even -- the reference's own reader.
+type Reader2 struct {
+	*handle
+	cpu *ref.Reader2
+}
+
+// OnDevice reports whether this reader decodes on the GPU.
+func (r *Reader2) OnDevice() bool { return r.cpu == nil }
 
 // Read is (*Reader2).Read (reader2.go:216-250).
-func (r *Reader2) Read(p []byte) (int, error) { return r.read(p) }
+func (r *Reader2) Read(p []byte) (int, error) {
+	if r.cpu != nil {
+		return r.cpu.Read(p)
+	}
+	return r.read(p)
+}
 
 // readCloser is readcloser.go:9-41.
 type readCloser struct {
@@ -249,6 +341,13 @@ func cbuf(b []byte) (*C.uint8_t, C.size_t) {
 
 // NewReader1 replaces lzma.NewReader1 (reader1.go:18-24).
 func NewReader1(inStream io.ByteReader) (*Reader1, error) {
+	if !worthTheDevice(1) { // one LZMA1 stream is one unit: the reference's own reader (reader1.go:18-24), untouched source
+		cpu, err := ref.NewReader1(inStream)
+		if err != nil {
+			return nil, err
+		}
+		return &Reader1{cpu: cpu}, nil
+	}
 	c, err := context()
 	if err != nil {
 		return nil, err
@@ -264,7 +363,7 @@ func NewReader1(inStream io.ByteReader) (*Reader1, error) {
 	if h == nil {
 		return nil, reader1CtorError(st, len(data))
 	}
-	return &Reader1{newHandle(h, rest)}, nil
+	return &Reader1{handle: newHandle(h, rest)}, nil
 }
 
 // asReader: bufio.Reader, bytes.Reader ... are io.Readers already; a bare io.ByteReader is adapted.
@@ -290,11 +389,24 @@ func (a byteReaderAdapter) Read(p []byte) (int, error) {
 
 // NewReader2 replaces lzma.NewReader2 (reader2.go:26-41).
 func NewReader2(inStream io.Reader, dictSize int) (*Reader2, error) {
-	c, err := context()
+	data, rest, err := firstPiece(inStream)
 	if err != nil {
 		return nil, err
 	}
-	data, rest, err := firstPiece(inStream)
+	// The units of the part at hand (the whole stream when it is shorter than a piece; a lower bound otherwise): one
+	// LZMA2 stream of many dictionary-reset units fills the chip by itself, one without inner resets is one wave.
+	if !worthTheDevice(lzma2Units(data)) {
+		var src io.Reader = bytes.NewReader(data)
+		if rest != nil {
+			src = io.MultiReader(src, rest)
+		}
+		cpu, err := ref.NewReader2(src, dictSize) // reader2.go:26-41
+		if err != nil {
+			return nil, err
+		}
+		return &Reader2{cpu: cpu}, nil
+	}
+	c, err := context() // (only a reader that goes to the device needs one)
 	if err != nil {
 		return nil, err
 	}
@@ -313,7 +425,7 @@ func NewReader2(inStream io.Reader, dictSize int) (*Reader2, error) {
 		}
 		return nil, readError(st)
 	}
-	return &Reader2{newHandle(h, rest)}, nil
+	return &Reader2{handle: newHandle(h, rest)}, nil
 }
 
 // NewLZMADecompressorForSevenZip replaces the bodgit/sevenzip constructor of reader1.go:32-61.
@@ -335,11 +447,21 @@ func sevenzip(lzma2 bool, props []byte, unpackSize uint64, readers []io.ReadClos
 	if lzma2 && len(props) != 1 {
 		return nil, errInsufficientProperties // reader2.go:54-56
 	}
-	c, err := context()
+	if !lzma2 && !worthTheDevice(1) { // an LZMA folder is one unit: the reference's constructor (reader1.go:32-61)
+		return ref.NewLZMADecompressorForSevenZip(props, unpackSize, readers)
+	}
+	data, rest, err := firstPiece(readers[0])
 	if err != nil {
 		return nil, err
 	}
-	data, rest, err := firstPiece(readers[0])
+	if lzma2 && !worthTheDevice(lzma2Units(data)) { // reader2.go:49-75 on what has been pulled + the rest of the source
+		var src io.Reader = bytes.NewReader(data)
+		if rest != nil {
+			src = io.MultiReader(src, rest)
+		}
+		return ref.NewLZMA2DecompressorForSevenZip(props, unpackSize, []io.ReadCloser{&prefixed{Reader: src, c: readers[0]}})
+	}
+	c, err := context()
 	if err != nil {
 		return nil, err
 	}
@@ -385,6 +507,14 @@ func sevenzip(lzma2 bool, props []byte, unpackSize uint64, readers []io.ReadClos
 	}
 	return &readCloser{handle: newHandle(h, rest), c: readers[0]}, nil
 }
+
+// prefixed: the bytes already pulled from a source in front of the source itself, closing the source.
+type prefixed struct {
+	io.Reader
+	c io.Closer
+}
+
+func (p *prefixed) Close() error { return p.c.Close() }
 
 // DecodeBatch is the new entry the reference has no analogue for: n independent .lzma
 // streams decoded concurrently on the GPU (one wave per stream).  outs[i] must have the

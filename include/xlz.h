@@ -133,8 +133,30 @@ int xlz_ctx_batching_stats(xlz_ctx *ctx, uint64_t *batches, uint64_t *streams);
  * 4-6 MB/s and the chip holds 4096 of them, so a call with few units is slower than the
  * host's own cores: measured on 1 MiB text streams, 64 units 0.34 GiB/s (16 host cores:
  * 1.27), 256 units 1.37 (1.28), 1024 units 5.2, 4096 units 17.2.  Below about 250 units
- * per 16 host cores decode on the CPU, or gather more streams first.   */
+ * per 16 host cores decode on the CPU, or gather more streams first;
+ * xlz_batch_advice answers that question for a given call before anything is uploaded.  */
 int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_result *results);
+
+/* BEFORE uploading anything: how much of a GPU would this call fill, and is the host the faster
+ * decoder for it?  Host only (reads stream and LZMA2 chunk headers; no device needed; `ctx` may be
+ * NULL: an MI355X's 4096 wave slots are assumed).  One wave decodes one unit -- an LZMA1 stream, or
+ * one unit of an LZMA2 stream's plan (xlz_lzma2_units) -- about 18 times slower than one host core
+ * decodes it with the reference's algorithm (4-6 MB/s against 65-80), so the GPU wins from about
+ * 16 units per host thread the caller could use instead (bench.py: stream_count_sweep; 256 units
+ * for 16 threads).  `host_threads` = 0: the hardware concurrency of this machine.  The library has
+ * no CPU decoder: a caller that is told prefer_cpu = 1 decodes with the reference's own readers
+ * (reader1.go:18-24, reader2.go:26-41; the Go shim does that by itself) or gathers more streams. */
+typedef struct xlz_advice {
+    uint64_t units;            /* independent work units the call would launch                    */
+    uint64_t in_bytes;         /* compressed bytes of all streams                                  */
+    uint32_t wave_slots;       /* units a GPU decodes at once (resident single-wave workgroups)    */
+    uint32_t break_even_units; /* 16 x host_threads                                                */
+    double   fill;             /* min(1, units / wave_slots): the share of the chip the call uses  */
+    int32_t  prefer_cpu;       /* 1: units < break_even_units                                      */
+    uint32_t reserved;
+} xlz_advice;
+int xlz_batch_advice(const xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, uint32_t host_threads,
+                     xlz_advice *out);
 
 /* What the most recent successful xlz_decode_batch on `ctx` spent where, and how well it filled the GPU.
  * ONE wave decodes one stream (LZMA1 has no parallelism inside a stream: decompress.go:13 is a serial

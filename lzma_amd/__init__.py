@@ -148,6 +148,19 @@ def decode_batch(ctx, streams):
     return [(outs[i].raw[: res[i].out_len], res[i].status, res[i].in_consumed) for i in range(n)]
 
 
+def batch_advice(streams, host_threads=0, ctx=None):
+    """xlz_batch_advice: what a decode of `streams` would launch and whether the host's cores are the faster decoder
+    for it -- host only, nothing is uploaded.  -> dict (units, in_bytes, wave_slots, break_even_units, fill, prefer_cpu)"""
+    streams = list(streams)
+    descs, keep, _ = _make_descs(streams, with_out=False)
+    adv = N.Advice()
+    st = N.lib().xlz_batch_advice(ctx._h if ctx else None, descs, len(streams), host_threads, ctypes.byref(adv))
+    if st != OK:
+        raise LzmaError(st, "xlz_batch_advice")
+    del keep
+    return {f: getattr(adv, f) for f, _ in N.Advice._fields_ if f != "reserved"}
+
+
 def decode_batch_on(ctxs, streams):
     """decode_batch over several contexts (one per GPU) through xlz_decode_batch_multi: sharded by
     stream inside the library, one host thread per context, results in input order."""

@@ -44,7 +44,7 @@ EXPORTS = [
     "xlz_batch_stats", "xlz_batch_destroy", "xlz_new_reader1", "xlz_new_reader2",
     "xlz_new_lzma_decompressor_for_sevenzip", "xlz_new_lzma2_decompressor_for_sevenzip",
     "xlz_reader_read", "xlz_reader_close", "xlz_reader_free", "xlz_xz_index", "xlz_xz_decode",
-    "xlz_decode_batch_multi", "xlz_batch_unit_trace", "xlz_reader_stats", "xlz_reader_memory", "xlz_batch_launch_info", "xlz_reader_reset", "xlz_reader_reopen", "xlz_reader_expect_more", "xlz_reader_feed", "xlz_reader_feed_eof", "xlz_7z_index", "xlz_7z_decode",
+    "xlz_decode_batch_multi", "xlz_batch_unit_trace", "xlz_reader_stats", "xlz_reader_memory", "xlz_batch_advice", "xlz_batch_launch_info", "xlz_reader_reset", "xlz_reader_reopen", "xlz_reader_expect_more", "xlz_reader_feed", "xlz_reader_feed_eof", "xlz_7z_index", "xlz_7z_decode",
     "xlz_lzma2_units",
 ]
 
@@ -98,6 +98,18 @@ class Lzma2Unit(ctypes.Structure):
         ("out_off", ctypes.c_uint64),
         ("out_len", ctypes.c_uint64),
         ("have_reader", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
+    ]
+
+
+class Advice(ctypes.Structure):
+    _fields_ = [
+        ("units", ctypes.c_uint64),
+        ("in_bytes", ctypes.c_uint64),
+        ("wave_slots", ctypes.c_uint32),
+        ("break_even_units", ctypes.c_uint32),
+        ("fill", ctypes.c_double),
+        ("prefer_cpu", ctypes.c_int32),
         ("reserved", ctypes.c_uint32),
     ]
 
@@ -193,6 +205,7 @@ def lib():
     L.xlz_reader_feed_eof.argtypes = [vp]
     L.xlz_reader_stats.argtypes = [vp] + [ctypes.POINTER(ctypes.c_uint64)] * 3
     L.xlz_reader_memory.argtypes = [vp] + [ctypes.POINTER(ctypes.c_uint64)] * 2
+    L.xlz_batch_advice.argtypes = [vp, ctypes.POINTER(StreamDesc), sz, ctypes.c_uint32, ctypes.POINTER(Advice)]
     L.xlz_batch_launch_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     L.xlz_batch_unit_trace.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]
     L.xlz_decode_batch_multi.argtypes = [ctypes.POINTER(vp), sz, ctypes.POINTER(StreamDesc), sz, ctypes.POINTER(Result)]

@@ -508,6 +508,35 @@ extern "C" int xlz_lzma2_units(const uint8_t *in, size_t len, xlz_lzma2_unit *un
     return max_units && lu.size() > max_units ? XLZ_ERR_OUT_CAP : XLZ_OK;
 }
 
+extern "C" int xlz_batch_advice(const xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, uint32_t host_threads,
+                                xlz_advice *out)
+{
+    if (!out || (!streams && n)) return XLZ_ERR_BAD_ARG;
+    memset(out, 0, sizeof *out);
+    for (size_t i = 0; i < n; i++) {
+        const xlz_stream_desc &s = streams[i];
+        if (!s.in && s.in_len) return XLZ_ERR_BAD_ARG;
+        out->in_bytes += s.in_len;
+        if (s.format == XLZ_FMT_LZMA2_RAW) { // the plan a decode would launch: units between dictionary resets
+            std::vector<Lz2Unit> lu;
+            uint32_t mx = 0;
+            scan_lzma2(s.in, s.in_len, lu, mx);
+            out->units += lu.size();
+        } else if (s.format == XLZ_FMT_LZMA_ALONE) {
+            out->units += s.in_len > 13 ? 1 : 0; // (a header alone is settled on the host)
+        } else {
+            out->units += s.in_len ? 1 : 0;
+        }
+    }
+    const uint32_t cus = ctx ? (uint32_t)ctx->num_cus : 256u;
+    out->wave_slots = cus * 16u;
+    if (!host_threads) host_threads = std::max(1u, std::thread::hardware_concurrency());
+    out->break_even_units = 16u * host_threads;
+    out->fill = out->wave_slots ? std::min(1.0, (double)out->units / out->wave_slots) : 0.0;
+    out->prefer_cpu = out->units < out->break_even_units ? 1 : 0;
+    return XLZ_OK;
+}
+
 namespace {
 
 int batch_free(xlz_batch *b)

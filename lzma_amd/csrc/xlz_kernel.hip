@@ -655,7 +655,7 @@ __device__ __forceinline__ HeadVec head_vectors(uint32_t lane)
     h.lit_next = upd_literal(lane < 12 ? lane : 0); // stateUpdateLiteral as a table: lane = old state
     h.hms = (hj >= 1 && hj <= 4) ? 2u : 0u; // indexed by state
     h.hm2 = (hj == 0 || hj == 5) ? 2u : 0u; // indexed by state2 = (state << 4) + posState
-#ifdef XLZ_HISS // A/B (--variant hiss): address = hc + state * (hms + 16 hm2) + posState * hm2
+#ifndef XLZ_NO_HISS // hiss: address = hc + state * (hms + 16 hm2) + posState * hm2 (three instructions); A/B builds --without hiss: -DXLZ_NO_HISS
     h.hms += 16u * h.hm2;
 #endif
     return h;
@@ -666,11 +666,11 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_
                                                    uint32_t &lenout)
 {
     uint32_t exitc;
-    uint32_t vlpm; // lp_mask in a VGPR: the literal context is computed on the VALU
+    uint32_t vlpm; // lc + lp in a VGPR (width of the literal state's bit field): the literal context is computed on the VALU
     uint32_t vpm;  // pos_mask likewise (head gather addresses)
-#ifdef XLZ_LCTX // A/B (tools/gen_fastpath.py --variant lctx): the literal state is one bit field of lc + lp bits
+#ifndef XLZ_NO_LCTX // lctx: the literal state is ONE bit field of lc + lp bits of (window.pos << 8 | prevByte); [vlpm] = its width
     asm volatile("v_mov_b32 %0, %1" : "=v"(vlpm) : "s"(d.lc + (uint32_t)__builtin_popcount(d.lp_mask)));
-#else
+#else // A/B build of tools/gen_fastpath.py --without lctx: [vlpm] = lp_mask
     asm volatile("v_mov_b32 %0, %1" : "=v"(vlpm) : "s"(d.lp_mask));
 #endif
     asm volatile("v_mov_b32 %0, %1" : "=v"(vpm) : "s"(d.pos_mask));

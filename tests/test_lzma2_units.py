@@ -157,3 +157,31 @@ def test_a_stream_beyond_4_gib_is_planned_with_64_bit_offsets():
     last = units[-1]
     assert last["in_off"] > 1 << 32 and last["in_off"] + last["in_len"] == buf.size
     assert last["out_off"] + last["out_len"] == n_chunks * body
+
+
+def test_batch_advice_counts_the_units_a_call_would_launch():
+    """xlz_batch_advice: a C caller asks BEFORE uploading how much of the chip a call fills and whether
+    the host's cores are the faster decoder -- units = streams for LZMA1, the plan of xlz_lzma2_units for LZMA2;
+    break-even = 16 units per host thread (bench.py's stream_count_sweep: 256 for 16 threads); no GPU needed"""
+    import corpus
+    one = corpus.compress_alone(corpus.plain("T", 1, 5000), dict_size=1 << 16)
+    a = lzma_amd.batch_advice([lzma_amd.Stream(one, out_cap=5000)] * 40, host_threads=16)
+    assert a["units"] == 40 and a["break_even_units"] == 256 and a["prefer_cpu"] == 1
+    assert a["wave_slots"] == 4096 and abs(a["fill"] - 40 / 4096) < 1e-9 and a["in_bytes"] == 40 * len(one)
+    a = lzma_amd.batch_advice([lzma_amd.Stream(one, out_cap=5000)] * 300, host_threads=16)
+    assert a["units"] == 300 and a["prefer_cpu"] == 0
+    assert lzma_amd.batch_advice([lzma_amd.Stream(one, out_cap=5000)] * 300, host_threads=64)["prefer_cpu"] == 1
+    # ONE LZMA2 stream of many dictionary-reset segments is many units: the GPU's job although it is one stream
+    blob, units = plan([stored(65536, j % 2 == 0) for j in range(1200)])
+    s2 = lzma_amd.Stream(blob, lzma_amd.FMT_LZMA2_RAW, out_cap=1200 * 65536, dict_size=1 << 16)
+    a = lzma_amd.batch_advice([s2], host_threads=16)
+    assert a["units"] == len(units) == 600 and a["prefer_cpu"] == 0
+    both = lzma_amd.batch_advice([s2, lzma_amd.Stream(one, out_cap=5000)], host_threads=16)
+    assert both["units"] == 601 and both["in_bytes"] == len(blob) + len(one)
+    # one LZMA2 stream without inner resets is one unit -- one wave: decode it on the host
+    single = corpus.compress_raw_lzma2(corpus.plain("T", 3, 300_000), dict_size=1 << 20)
+    assert lzma_amd.lzma2_units(single)[0]["in_len"] == len(single)
+    a = lzma_amd.batch_advice([lzma_amd.Stream(single, lzma_amd.FMT_LZMA2_RAW, out_cap=300_000, dict_size=1 << 20)], host_threads=1)
+    assert a["units"] == 1 and a["prefer_cpu"] == 1 and a["break_even_units"] == 16
+    empty = lzma_amd.batch_advice([], host_threads=4)
+    assert empty["units"] == 0 and empty["fill"] == 0.0 and empty["prefer_cpu"] == 1

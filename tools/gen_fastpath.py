@@ -87,8 +87,19 @@ NEXT_VARIANT = {"slot0", "vprev", "rmov", "nopos", "l7blk", "warel", "vreps"}
 # -6 % on incompressible data -- that data IS bound by the scalar port), hsb (scalar bounds for the head decisions: -0.6 %)
 # lwait: the next literal's block reads stay in flight across the isMatch decision (+0.3 .. +0.6 %, profiles/r03/ab_lwait.txt)
 ROUND3_VARIANT = {"wsb", "lwait"}
+# round 4 (profiles/r04/ab_round4_variants.txt): instruction-count changes, each checked on the emulator first (tools/fuzz_emulated.py)
+# and then measured (tools/ab_bench.py; T = 4096 x 1 MiB text, R = incompressible, S = the cfg3 shape, M = mixed):
+#   db6    direct bits in six instructions per bit instead of eight (the subtract's borrow is the complemented bit)   T +1.6 %  S +0.7 %
+#   tu8    tree_update in eight instructions instead of eleven, no base register to prepare; the 8-level trees' update
+#          with one multiply-add                                                                                      T +2.4 %  R +0.9 %  S +0.8 %
+#   cchk   ONE window test for a new distance (validity and "source inside the window" are the same comparison)        T +1.3 %
+#   lctx   the literal state as ONE bit field of (window.pos << 8 | prevByte); the literal table addressed relative to
+#          its start (LDS offsets): three vector instructions less per literal
+#   hiss   the head gather's address in three instructions instead of four                                  lctx + hiss: T +1.0 %  R +2.8 %  S +2.1 %
+# all five: T +6.5 %  R +3.3 %  S +5.5 %  M +4.2 %
+ROUND4_VARIANT = {"db6", "tu8", "cchk", "lctx", "hiss"}
 DEFAULT_VARIANT = {"lgather", "hdpp", "flim", "cflag", "tuc", "vperm", "rlhoist", "bralign", "stub32", "head32", "pktl64"}
-VARIANT = set(DEFAULT_VARIANT) | NEXT_VARIANT | ROUND3_VARIANT   # round 3: the prepared variants are the committed loop
+VARIANT = set(DEFAULT_VARIANT) | NEXT_VARIANT | ROUND3_VARIANT | ROUND4_VARIANT   # (xlz_kernel.hip passes what lctx / hiss expect: XLZ_NO_LCTX / XLZ_NO_HISS for A/B builds without them)
 
 
 def hdpp_lane(j):
@@ -492,8 +503,8 @@ def tree_update(nb, blocks, base="v58", addr=None, off=0, dump="v38"):
         # the lane's level; XOR with 2 * lane (v56) is 0 / 1 exactly in the visited lanes and then IS !bit; one multiply-add
         # forms p - 2017 * !bit (s85 = -2017); the store goes to `addr` (+ offset: the VGPR the block was requested with), the
         # other lanes to `dump` (a VGPR or an inline constant: an unused slot, relative to the same offset)
-        assert "tuc" in VARIANT and addr
-        if nb in (3, 4, 6):
+        assert addr
+        if "tuc" in VARIANT and nb in (3, 4, 6):
             emit("v_lshrrev_b32 v61, %s, s88" % {3: "v14", 4: "v15", 6: "v16"}[nb])
         else:
             emit("v_sub_u32 v55, %s, v31\nv_lshrrev_b32 v61, v55, s88" % nb)
@@ -763,7 +774,8 @@ def tree_update_rec(nb, base, store=True, issued=False, pending=0, filler=None):
     v_sub_u32 v61, v54, v61
     """ % base)
     if store:
-        emit("v_cndmask_b32 v60, v38, v60, s[76:77]\nds_write_b16 v60, v61")
+        off = lit_off(base)
+        emit("v_cndmask_b32 v60, %s, v60, s[76:77]\nds_write_b16 v60, v61%s" % ("0" if off else "v38", (" offset:%d" % off) if off else ""))
 
 
 def len_request(base):
@@ -1262,13 +1274,14 @@ def sec_packet_general():
         ds_write_b16 v60, v61%s
         """ % ((" offset:%d" % lit_off("v39")) if lit_off("v39") else ""))
     else:
+        off = lit_off("v39")
         emit("""
         v_cndmask_b32 v57, 0, v57, vcc
-        global_store_short v57, v61, %[mptr] offset:512
-        v_cndmask_b32 v60, v60, v38, vcc
-        v_cndmask_b32 v60, v38, v60, s[76:77]
-        ds_write_b16 v60, v61
-        """)
+        global_store_short v57, v61, %%[mptr] offset:512
+        v_cndmask_b32 v60, v60, %s, vcc
+        v_cndmask_b32 v60, %s, v60, s[76:77]
+        ds_write_b16 v60, v61%s
+        """ % ("0" if off else "v38", "0" if off else "v38", (" offset:%d" % off) if off else ""))
     literal_context(prev_v="v32")
     emit("s_branch %s" % L("pktl"))
 
@@ -1397,14 +1410,13 @@ def sec_match():
     label("distdone")
     if "vreps" in VARIANT:
         emit("v_writelane_b32 v34, %[rep0], 0")
-    if "cchk" in VARIANT:
+    if cchk():
         # cchk (round 4): ONE window test for a new distance.  rep0 < fill (fill = bytes in the window: window.pos, or
         # dictSize once it is full) says at once that the distance is valid (:651-653: rep0 < dictSize, rep0 <= pos) AND that
         # the copy's source lies inside the window's bytes -- the two tests sec_match and sec_copy made one after the
         # other.  The rare rest (rep0 == fill: the reference's off-by-one distance, window.go:89-91; an invalid
         # distance; the end marker) is told apart out of line.  The copy then only asks whether it is one of its own
         # (shorter than 64 bytes and than its distance).  Four scalar instructions less per simple match.
-        assert nopos()
         emit("""
         s_max_u32 s81, %%[wpos], s94
         s_cmp_lt_u32 %%[rep0], s81
@@ -1505,11 +1517,15 @@ def sec_rep():
 def sec_copy():
     """window.CopyMatch of short non-overlapping matches; falls into the general packet head"""
     # ------------------------------------------------------------- window.CopyMatch (window.go:55-87)
-    if "cchk" in VARIANT:  # (the simple match has made its own test and falls into copygo)
+    if cchk():  # (the simple match has made its own test and falls into copygo)
         deferred.append(lambda: (copy_test(), emit("s_branch %s" % L("copygo"))))
     else:
         copy_test()
     copy_body()
+
+
+def cchk():
+    return "cchk" in VARIANT and nopos()
 
 
 def copy_test():
@@ -1528,7 +1544,7 @@ def copy_test():
 
 
 def copy_body():
-    if "cchk" in VARIANT:
+    if cchk():
         label("copygo")
     need_copy_done(inline=True)  # the new source may overlap the bytes the pending copy still has to store
     emit("v_add_u32 v48, %s, %%[vlane]\nv_subrev_u32 v61, s93, v48" % ("v17" if nopos() else "%[pos]"))
@@ -1626,7 +1642,7 @@ def gen():
         emit("s_movk_i32 s85, -2017")
     if "vnorm" in VARIANT:
         emit("v_mov_b32 v17, 0x1000000")
-    if "vperm" in VARIANT:
+    if "vperm" in VARIANT or "lctx" in VARIANT:
         emit("v_mov_b32 v13, 0x06050400")
     # constants of tree_update_rec
     emit("v_sub_u32 v19, 8, %[vlane]\nv_sub_u32 v18, 7, %[vlane]\nv_cmp_gt_u32 s[76:77], 8, %[vlane]")
