@@ -78,8 +78,19 @@ typedef struct xlz_stream_desc {
                              argument of NewReader2 (values < 4096 mean 8 MiB, reader2.go:88-91)  */
     uint64_t unpack_size; /* LZMA_RAW only; all-ones = unknown (state.go:135-151)                 */
     uint8_t props;        /* LZMA_RAW only: the lc/lp/pb byte                                     */
-    uint8_t reserved[7];
+    uint8_t flags;        /* XLZ_STREAM_F_*                                                       */
+    uint8_t reserved[6];
 } xlz_stream_desc;
+
+/* LZMA2_RAW: `in` is a SLICE of a longer stream that does not begin at the stream's start -- it begins
+ * where a unit of xlz_lzma2_units begins (callers that deal the units of one stream to several GPUs or
+ * processes: xlz_decode_batch_multi does it by itself).  Bytes in front of the slice's first
+ * dictionary epoch belong to units that are not in this call: a (malformed) stream that reads them,
+ * or whose units do not decode to what their headers announce, ends in XLZ_ERR_UNSUPPORTED instead
+ * of being settled inside the slice -- decode the whole stream then.  A slice that ends before its
+ * stream does (no end byte) ends in XLZ_ERR_UNEXPECTED_EOF with all of its input consumed: that is
+ * its clean outcome.                                                                              */
+#define XLZ_STREAM_F_LZMA2_SLICE 1u
 
 typedef struct xlz_result {
     uint64_t out_len;     /* bytes produced by the decoder (even when status < 0)                 */
@@ -278,11 +289,30 @@ int xlz_reader_stats(const xlz_reader *r, uint64_t *refills, uint64_t *whole_dec
  * first dictionary reset behind a non-empty epoch, i.e. for nearly every stream                 */
 int xlz_reader_memory(const xlz_reader *r, uint64_t *window_bytes, uint64_t *image_bytes);
 
-/* Multi-GPU form of xlz_decode_batch: one context per GPU; the batch is
- * split by stream (balanced by out_cap), every context decodes its shard on its own host
- * thread, results come back in input order.  No device-to-device traffic.                   */
+/* Multi-GPU form of xlz_decode_batch: one context per GPU; every context
+ * decodes its shard on its own host thread, results come back in input order.  No device-to-device
+ * traffic.  The work is dealt by COMPRESSED bytes (what the kernel's own work queue is keyed by):
+ * whole streams, and -- for a raw LZMA2 stream that is a large part of the call -- runs of its units
+ * (xlz_lzma2_units: a dictionary reset with new properties starts an independent unit,
+ * reader2.go:100-173), each GPU getting a slice of the compressed input and a disjoint slice of the
+ * caller's output buffer.  A stream whose slices do not decode to exactly what their headers
+ * announce (malformed streams only) is decoded again as a whole on one context, so bytes, status
+ * and in_consumed are the single-GPU call's.                                                     */
 int xlz_decode_batch_multi(xlz_ctx *const *ctxs, size_t n_ctx, const xlz_stream_desc *streams,
                            size_t n, xlz_result *results);
+/* The plan of such a call alone (host only, no GPU): the items -- whole streams and runs of units of
+ * LZMA2 streams -- and the context each goes to.  At most max_items entries are filled, *n_items =
+ * their number (XLZ_ERR_OUT_CAP when larger than max_items > 0; max_items = 0 counts).  The items of
+ * a stream are adjacent and in stream order.                                                      */
+typedef struct xlz_multi_item {
+    uint64_t stream;           /* index into streams                                               */
+    uint64_t in_off, in_len;   /* the slice of the stream's input                                  */
+    uint64_t out_off, out_len; /* the slice of its output (whole streams: 0, out_cap)              */
+    uint32_t context;          /* index into ctxs                                                  */
+    uint32_t flags;            /* 1 whole stream, 2 begins at the stream's start, 4 ends at its end */
+} xlz_multi_item;
+int xlz_decode_batch_multi_plan(size_t n_ctx, const xlz_stream_desc *streams, size_t n, xlz_multi_item *items,
+                                size_t max_items, size_t *n_items);
 
 /* ---- the unit plan of a raw LZMA2 stream (host only, no GPU needed) ------------------------
  * What a decode of `in` as XLZ_FMT_LZMA2_RAW launches: the stream is cut where a chunk starts
@@ -327,6 +357,10 @@ int xlz_xz_index(const uint8_t *file, size_t len, xlz_xz_block *blocks, size_t m
  * XLZ_ERR_RESULT.                                                                             */
 int xlz_xz_decode(xlz_ctx *ctx, const uint8_t *file, size_t len, uint8_t *out, size_t out_cap,
                   uint64_t *out_len, int verify, size_t *unverified);
+/* the same over several contexts (one per GPU): the blocks -- and the units inside large blocks -- are
+ * dealt to the contexts by xlz_decode_batch_multi                                                */
+int xlz_xz_decode_multi(xlz_ctx *const *ctxs, size_t n_ctx, const uint8_t *file, size_t len, uint8_t *out,
+                        size_t out_cap, uint64_t *out_len, int verify, size_t *unverified);
 
 /* ---- .7z container front-end ----------------------------
  * (The parser was written from 7-Zip's published format description and has only been exercised
@@ -370,6 +404,9 @@ int xlz_7z_index(xlz_ctx *ctx, const uint8_t *file, size_t len, xlz_7z_folder *f
  * when a folder's coder chain is not a single LZMA / LZMA2 / Copy coder.                         */
 int xlz_7z_decode(xlz_ctx *ctx, const uint8_t *file, size_t len, uint8_t *out, size_t out_cap,
                   uint64_t *out_len, int verify, size_t *unverified);
+/* the same over several contexts (one per GPU; encoded headers are decoded on the first)         */
+int xlz_7z_decode_multi(xlz_ctx *const *ctxs, size_t n_ctx, const uint8_t *file, size_t len, uint8_t *out,
+                        size_t out_cap, uint64_t *out_len, int verify, size_t *unverified);
 
 #ifdef __cplusplus
 }

@@ -161,6 +161,24 @@ def batch_advice(streams, host_threads=0, ctx=None):
     return {f: getattr(adv, f) for f, _ in N.Advice._fields_ if f != "reserved"}
 
 
+def multi_plan(n_ctx, streams):
+    """xlz_decode_batch_multi_plan (host only): what decode_batch_on would hand to which of n_ctx contexts -> list of dicts
+    (stream, in_off, in_len, out_off, out_len, context, whole, first, last), the items of a stream adjacent and in order"""
+    streams = list(streams)
+    descs, keep, _ = _make_descs(streams, with_out=False)
+    n = ctypes.c_size_t()
+    st = N.lib().xlz_decode_batch_multi_plan(n_ctx, descs, len(streams), None, 0, ctypes.byref(n))
+    if st != OK:
+        raise LzmaError(st, "xlz_decode_batch_multi_plan")
+    items = (N.MultiItem * max(n.value, 1))()
+    st = N.lib().xlz_decode_batch_multi_plan(n_ctx, descs, len(streams), items, n.value, ctypes.byref(n))
+    if st != OK:
+        raise LzmaError(st, "xlz_decode_batch_multi_plan")
+    del keep
+    return [dict(stream=it.stream, in_off=it.in_off, in_len=it.in_len, out_off=it.out_off, out_len=it.out_len, context=it.context,
+                 whole=bool(it.flags & 1), first=bool(it.flags & 2), last=bool(it.flags & 4)) for it in items[: n.value]]
+
+
 def decode_batch_on(ctxs, streams):
     """decode_batch over several contexts (one per GPU) through xlz_decode_batch_multi: sharded by
     stream inside the library, one host thread per context, results in input order."""
@@ -512,6 +530,21 @@ def xz_decode(ctx, data, verify=True, max_size=None):
     return out.raw[:n]
 
 
+def xz_decode_on(ctxs, data, verify=True):
+    """xlz_xz_decode_multi: the file's blocks -- and the units inside large blocks -- dealt to several contexts -> bytes"""
+    _, total = xz_index(data)
+    out = ctypes.create_string_buffer(max(total, 1))
+    hs = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    out_len, unverified = ctypes.c_uint64(), ctypes.c_size_t()
+    data = bytes(data)
+    st = N.lib().xlz_xz_decode_multi(hs, len(ctxs), ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p), len(data),
+                                     ctypes.cast(out, ctypes.c_void_p), total, ctypes.byref(out_len), 1 if verify else 0,
+                                     ctypes.byref(unverified))
+    if st != OK:
+        raise LzmaError(st, "xlz_xz_decode_multi")
+    return out.raw[: out_len.value]
+
+
 def xz_decode_into(ctx, data, out, verify=True):
     """xlz_xz_decode with the caller's buffers and nothing else: `data` is read in place (bytes, or any object with the
     buffer interface), the decoded bytes land in `out` (a writable buffer of at least the index's total: bytearray,
@@ -527,6 +560,20 @@ def xz_decode_into(ctx, data, out, verify=True):
     if st != OK:
         raise LzmaError(st, "xlz_xz_decode")
     return out_len.value
+
+
+def sevenzip_decode_on(ctxs, data, verify=True):
+    """xlz_7z_decode_multi: the archive's folders dealt to several contexts -> the files' bytes back to back"""
+    _, _, total = sevenzip_index(data, ctxs[0])
+    buf = ctypes.create_string_buffer(data, len(data))
+    out = ctypes.create_string_buffer(max(total, 1))
+    hs = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    out_len, unverified = ctypes.c_uint64(), ctypes.c_size_t()
+    st = N.lib().xlz_7z_decode_multi(hs, len(ctxs), ctypes.cast(buf, ctypes.c_void_p), len(data), ctypes.cast(out, ctypes.c_void_p),
+                                     total, ctypes.byref(out_len), 1 if verify else 0, ctypes.byref(unverified))
+    if st != OK:
+        raise LzmaError(st, "xlz_7z_decode_multi")
+    return out.raw[: out_len.value]
 
 
 # ---- .7z container front-end (include/xlz.h: xlz_7z_index / xlz_7z_decode) -------------------

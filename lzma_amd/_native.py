@@ -44,7 +44,7 @@ EXPORTS = [
     "xlz_batch_stats", "xlz_batch_destroy", "xlz_new_reader1", "xlz_new_reader2",
     "xlz_new_lzma_decompressor_for_sevenzip", "xlz_new_lzma2_decompressor_for_sevenzip",
     "xlz_reader_read", "xlz_reader_close", "xlz_reader_free", "xlz_xz_index", "xlz_xz_decode",
-    "xlz_decode_batch_multi", "xlz_batch_unit_trace", "xlz_reader_stats", "xlz_reader_memory", "xlz_batch_advice", "xlz_batch_launch_info", "xlz_reader_reset", "xlz_reader_reopen", "xlz_reader_expect_more", "xlz_reader_feed", "xlz_reader_feed_eof", "xlz_7z_index", "xlz_7z_decode",
+    "xlz_decode_batch_multi", "xlz_decode_batch_multi_plan", "xlz_xz_decode_multi", "xlz_7z_decode_multi", "xlz_batch_unit_trace", "xlz_reader_stats", "xlz_reader_memory", "xlz_batch_advice", "xlz_batch_launch_info", "xlz_reader_reset", "xlz_reader_reopen", "xlz_reader_expect_more", "xlz_reader_feed", "xlz_reader_feed_eof", "xlz_7z_index", "xlz_7z_decode",
     "xlz_lzma2_units",
 ]
 
@@ -59,7 +59,8 @@ class StreamDesc(ctypes.Structure):
         ("dict_size", ctypes.c_uint32),
         ("unpack_size", ctypes.c_uint64),
         ("props", ctypes.c_uint8),
-        ("reserved", ctypes.c_uint8 * 7),
+        ("flags", ctypes.c_uint8),
+        ("reserved", ctypes.c_uint8 * 6),
     ]
 
 
@@ -99,6 +100,18 @@ class Lzma2Unit(ctypes.Structure):
         ("out_len", ctypes.c_uint64),
         ("have_reader", ctypes.c_uint32),
         ("reserved", ctypes.c_uint32),
+    ]
+
+
+class MultiItem(ctypes.Structure):
+    _fields_ = [
+        ("stream", ctypes.c_uint64),
+        ("in_off", ctypes.c_uint64),
+        ("in_len", ctypes.c_uint64),
+        ("out_off", ctypes.c_uint64),
+        ("out_len", ctypes.c_uint64),
+        ("context", ctypes.c_uint32),
+        ("flags", ctypes.c_uint32),
     ]
 
 
@@ -209,12 +222,15 @@ def lib():
     L.xlz_batch_launch_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     L.xlz_batch_unit_trace.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]
     L.xlz_decode_batch_multi.argtypes = [ctypes.POINTER(vp), sz, ctypes.POINTER(StreamDesc), sz, ctypes.POINTER(Result)]
+    L.xlz_decode_batch_multi_plan.argtypes = [sz, ctypes.POINTER(StreamDesc), sz, ctypes.POINTER(MultiItem), sz, ctypes.POINTER(sz)]
     L.xlz_xz_index.argtypes = [vp, sz, ctypes.POINTER(XzBlock), sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint64)]
     L.xlz_lzma2_units.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(Lzma2Unit), sz, ctypes.POINTER(sz)]
     L.xlz_7z_index.argtypes = [vp, vp, sz, ctypes.POINTER(SzFolder), sz, ctypes.POINTER(sz), ctypes.POINTER(SzSubstream), sz,
                                ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint64)]
     L.xlz_7z_decode.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(ctypes.c_uint64), i32, ctypes.POINTER(sz)]
     L.xlz_xz_decode.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(ctypes.c_uint64), i32, ctypes.POINTER(sz)]
+    L.xlz_xz_decode_multi.argtypes = [ctypes.POINTER(vp), sz, vp, sz, vp, sz, ctypes.POINTER(ctypes.c_uint64), i32, ctypes.POINTER(sz)]
+    L.xlz_7z_decode_multi.argtypes = [ctypes.POINTER(vp), sz, vp, sz, vp, sz, ctypes.POINTER(ctypes.c_uint64), i32, ctypes.POINTER(sz)]
     _lib = L
     return L
 

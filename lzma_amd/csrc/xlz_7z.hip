@@ -349,7 +349,8 @@ int place_folders(const Streams &s, size_t file_len, std::vector<xlz_7z_folder> 
 
 // decode the given folders (all of a StreamsInfo) into `out`, verify their CRCs
 int decode_folders(xlz_ctx *ctx, const uint8_t *file, const std::vector<xlz_7z_folder> &fo,
-                   const std::vector<xlz_7z_substream> &subs, uint8_t *out, int verify, size_t *unverified)
+                   const std::vector<xlz_7z_substream> &subs, uint8_t *out, int verify, size_t *unverified,
+                   xlz_ctx *const *ctxs = nullptr, size_t n_ctx = 0) // ctxs: deal the folders to several GPUs (xlz_decode_batch_multi)
 {
     std::vector<xlz_stream_desc> d;
     std::vector<size_t> which;
@@ -383,7 +384,8 @@ int decode_folders(xlz_ctx *ctx, const uint8_t *file, const std::vector<xlz_7z_f
     }
     std::vector<xlz_result> r(d.size());
     if (!d.empty()) {
-        int st = xlz_decode_batch(ctx, d.data(), d.size(), r.data());
+        int st = n_ctx > 1 ? xlz_decode_batch_multi(ctxs, n_ctx, d.data(), d.size(), r.data())
+                           : xlz_decode_batch(ctx, d.data(), d.size(), r.data());
         if (st != XLZ_OK) return st;
     }
     for (size_t k = 0; k < d.size(); k++) {
@@ -521,10 +523,31 @@ extern "C" int xlz_7z_index(xlz_ctx *ctx, const uint8_t *file, size_t len, xlz_7
     return XLZ_OK;
 }
 
+static int sz_decode(xlz_ctx *const *ctxs, size_t n_ctx, const uint8_t *file, size_t len, uint8_t *out, size_t out_cap,
+                     uint64_t *out_len, int verify, size_t *unverified);
+
 extern "C" int xlz_7z_decode(xlz_ctx *ctx, const uint8_t *file, size_t len, uint8_t *out, size_t out_cap, uint64_t *out_len,
                              int verify, size_t *unverified)
 {
-    if (!ctx || !file || (!out && out_cap) || !out_len) return XLZ_ERR_BAD_ARG;
+    return sz_decode(&ctx, 1, file, len, out, out_cap, out_len, verify, unverified);
+}
+
+// several contexts (one per GPU): the folders, and the units inside large LZMA2 folders, are dealt by
+// xlz_decode_batch_multi; encoded headers are decoded on the first context
+extern "C" int xlz_7z_decode_multi(xlz_ctx *const *ctxs, size_t n_ctx, const uint8_t *file, size_t len, uint8_t *out,
+                                   size_t out_cap, uint64_t *out_len, int verify, size_t *unverified)
+{
+    if (!ctxs || !n_ctx) return XLZ_ERR_BAD_ARG;
+    return sz_decode(ctxs, n_ctx, file, len, out, out_cap, out_len, verify, unverified);
+}
+
+static int sz_decode(xlz_ctx *const *ctxs, size_t n_ctx, const uint8_t *file, size_t len, uint8_t *out, size_t out_cap,
+                     uint64_t *out_len, int verify, size_t *unverified)
+{
+    for (size_t c = 0; c < n_ctx; c++)
+        if (!ctxs[c]) return XLZ_ERR_BAD_ARG;
+    xlz_ctx *ctx = ctxs[0];
+    if (!file || (!out && out_cap) || !out_len) return XLZ_ERR_BAD_ARG;
     *out_len = 0;
     if (unverified) *unverified = 0;
     Streams s;
@@ -537,7 +560,7 @@ extern "C" int xlz_7z_decode(xlz_ctx *ctx, const uint8_t *file, size_t len, uint
     uint64_t total = 0;
     for (auto &f : fo) total += f.unpack_len;
     if (total > out_cap) return XLZ_ERR_OUT_CAP;
-    st = decode_folders(ctx, file, fo, s.subs, out, verify, unverified);
+    st = decode_folders(ctx, file, fo, s.subs, out, verify, unverified, ctxs, n_ctx);
     if (st != XLZ_OK) return st;
     *out_len = total;
     return XLZ_OK;

@@ -104,6 +104,7 @@ struct StreamPlan {
     uint32_t in_len = 0;  // LZMA2: stream length
     uint32_t dict_size = 0;
     bool lzma2 = false;
+    bool slice = false;    // XLZ_STREAM_F_LZMA2_SLICE: earlier units of the stream are not in this call
     bool oversize = false; // >= 4 GiB of input or output: not in the arenas, decoded as a session by xlz_decode_batch
 };
 
@@ -591,6 +592,7 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
             u.dict_size = s.dict_size < kLzmaDicMin ? 8u * 1024 * 1024 : s.dict_size; // reader2.go:88-91
             u.unpack_size = kUnknownSize;
             pl.header_len = 0;
+            pl.slice = (s.flags & XLZ_STREAM_F_LZMA2_SLICE) != 0;
             has_unit = true;
             break;
         default: pl.host_status = XLZ_ERR_BAD_ARG; break;
@@ -630,7 +632,7 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
                 v.expect_out = (uint32_t)lu[k].expect_out;
                 v.stream = (uint32_t)i;
                 v.flags = (last ? UNIT_F_LAST : 0u) | (lu[k].have_reader ? UNIT_F_HAVE_READER : 0u) |
-                          (k ? UNIT_F_NOT_FIRST : 0u) | (big ? UNIT_F_BIG_MODEL : 0u);
+                          ((k || pl.slice) ? UNIT_F_NOT_FIRST : 0u) | (big ? UNIT_F_BIG_MODEL : 0u);
                 v.lc = (uint8_t)mx; // sizes the model storage; the real lc/lp/pb come from the chunk headers
                 b->units.push_back(v);
                 unit_src_off.push_back(lu[k].in_start);
@@ -937,9 +939,20 @@ void fold_streams(xlz_batch *b, size_t s0, size_t s1, std::vector<size_t> &redo)
         // a unit read window bytes of an earlier dictionary epoch (AUX_STALE): the ordinary launch
         // returns zeros there, the reference returns what its uncleared buffer holds -- decode the
         // stream again as one unit of an exact launch
+        // (a SLICE of a stream cannot be settled here: the earlier epochs are not in this call, and a re-run of the
+        //  slice as one unit would read zeros where the reference reads them -- the caller decodes the whole stream)
+        auto again = [&] {
+            if (pl.slice) {
+                r.status = XLZ_ERR_UNSUPPORTED;
+                r.out_len = 0;
+                r.in_consumed = 0;
+            } else {
+                redo.push_back(i);
+            }
+        };
         for (uint32_t k = 0; k < pl.n_units && !settled; k++)
             if (ur[pl.first_unit + k].aux & AUX_STALE) {
-                redo.push_back(i);
+                again();
                 settled = true;
             }
         for (uint32_t k = 0; k < pl.n_units && !settled; k++) {
@@ -962,7 +975,7 @@ void fold_streams(xlz_batch *b, size_t s0, size_t s1, std::vector<size_t> &redo)
                 r.in_consumed = in_base + u.in_consumed;
                 settled = true;
             } else {
-                redo.push_back(i);
+                again();
                 settled = true;
             }
         }
@@ -1442,40 +1455,161 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     return st;
 }
 
-// Multi-GPU form of xlz_decode_batch: the streams are independent, so the
-// batch is split by stream -- longest-processing-time greedy on the output capacity -- and every
-// context (one per GPU) decodes its shard on its own host thread.  No device-to-device traffic.
-extern "C" int xlz_decode_batch_multi(xlz_ctx *const *ctxs, size_t n_ctx, const xlz_stream_desc *streams, size_t n,
-                                      xlz_result *results)
+// Multi-GPU form of xlz_decode_batch.  The streams are independent, and so are the units of an
+// LZMA2 stream (a chunk that resets the dictionary and brings new properties depends on nothing before it,
+// reader2.go:100-173; the output offset of every unit follows from the chunk headers): the call is dealt to the contexts
+// (one per GPU, each on its own host thread) as ITEMS -- whole streams, and runs of units of the LZMA2 streams that are a
+// large part of the call -- by compressed bytes, longest first (the key of the kernel's own work queue; round 3 dealt whole
+// streams by out_cap, so ONE big LZMA2 stream, one .xz file of few blocks or one .7z folder landed on one GPU).  A run of
+// units is a slice of the compressed input and a disjoint slice of the caller's output buffer: no device-to-device
+// traffic, no collective.  A stream whose slices do not come back exactly as their headers announce (malformed streams:
+// a unit that produces or consumes something else, a copy that reads behind its dictionary reset into another slice's
+// bytes) is decoded again as a whole on one context: bytes, status and in_consumed are the single-GPU call's.
+namespace {
+
+struct MultiItem {
+    size_t stream;
+    uint64_t in_off, in_len;   // slice of the stream's input (whole stream: 0, in_len)
+    uint64_t out_off, out_len; // slice of its output (the announced size of the run of units)
+    bool whole, first, last;
+    xlz_result res;
+};
+
+constexpr uint64_t kMultiMinSplitBytes = 64u << 10; // an LZMA2 stream shorter than this is dealt whole
+
+// cut an LZMA2 stream into at most `pieces` runs of units of about equal compressed size
+void multi_split(const xlz_stream_desc &s, size_t stream, size_t pieces, std::vector<MultiItem> &items)
 {
-    if (!ctxs || n_ctx == 0 || (!streams && n) || (!results && n)) return XLZ_ERR_BAD_ARG;
-    for (size_t c = 0; c < n_ctx; c++)
-        if (!ctxs[c]) return XLZ_ERR_BAD_ARG;
-    if (n_ctx == 1 || n <= 1) return xlz_decode_batch(ctxs[0], streams, n, results);
-    std::vector<size_t> order(n);
+    std::vector<Lz2Unit> lu;
+    uint32_t mx = 0;
+    if (pieces >= 2 && s.in_len <= kMaxUnitBytes) scan_lzma2(s.in, s.in_len, lu, mx);
+    uint64_t announced = 0;
+    for (const Lz2Unit &u : lu) announced += u.expect_out;
+    if (lu.size() < 2 || announced > s.out_cap) { // one unit, or the caller's room is short of the headers: whole
+        MultiItem it{stream, 0, s.in_len, 0, s.out_cap, true, true, true, xlz_result{}};
+        items.push_back(it);
+        return;
+    }
+    pieces = std::min(pieces, lu.size());
+    size_t k = 0;
+    for (size_t p = 0; p < pieces; p++) {
+        const size_t k0 = k;
+        const uint64_t until = (uint64_t)s.in_len * (p + 1) / pieces;
+        k++;
+        while (k < lu.size() && (p + 1 == pieces || lu[k].in_start + lu[k].in_len <= until) && lu.size() - k > pieces - p - 1) k++;
+        if (p + 1 == pieces) k = lu.size();
+        MultiItem it;
+        it.stream = stream;
+        it.in_off = lu[k0].in_start;
+        it.in_len = (k == lu.size() ? (uint64_t)s.in_len : lu[k].in_start) - it.in_off;
+        it.out_off = lu[k0].out_start;
+        it.out_len = (k == lu.size() ? announced : lu[k].out_start) - it.out_off;
+        it.whole = false;
+        it.first = k0 == 0;
+        it.last = k == lu.size();
+        it.res = xlz_result{};
+        items.push_back(it);
+    }
+}
+
+} // namespace
+
+namespace {
+
+// items of a call and the context each goes to
+void multi_plan(size_t n_ctx, const xlz_stream_desc *streams, size_t n, std::vector<MultiItem> &items,
+                std::vector<std::vector<size_t>> &shard)
+{
+    // ---- items: an LZMA2 stream that holds more than a quarter of a context's share is cut into runs of units
+    uint64_t total_in = 0;
+    for (size_t i = 0; i < n; i++) total_in += streams[i].in_len;
+    const uint64_t share = std::max<uint64_t>(1, total_in / n_ctx);
+    items.clear();
+    items.reserve(n + 4 * n_ctx);
+    for (size_t i = 0; i < n; i++) {
+        const xlz_stream_desc &s = streams[i];
+        size_t pieces = 1;
+        if (n_ctx > 1 && s.format == XLZ_FMT_LZMA2_RAW && !(s.flags & XLZ_STREAM_F_LZMA2_SLICE) && s.in_len >= kMultiMinSplitBytes &&
+            s.in_len > share / 4)
+            pieces = (size_t)std::min<uint64_t>(4 * n_ctx, (s.in_len + share / 4 - 1) / std::max<uint64_t>(1, share / 4));
+        multi_split(s, i, pieces, items);
+    }
+    // ---- deal: longest compressed size first, to the context with the least so far
+    std::vector<size_t> order(items.size());
     std::iota(order.begin(), order.end(), (size_t)0);
-    std::stable_sort(order.begin(), order.end(),
-                     [&](size_t a, size_t b) { return streams[a].out_cap > streams[b].out_cap; });
-    std::vector<std::vector<size_t>> shard(n_ctx);
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return items[a].in_len > items[b].in_len; });
+    shard.assign(n_ctx, {});
     std::vector<uint64_t> load(n_ctx, 0);
     for (size_t i : order) {
         size_t k = 0;
         for (size_t c = 1; c < n_ctx; c++)
             if (load[c] < load[k]) k = c;
         shard[k].push_back(i);
-        load[k] += (uint64_t)streams[i].out_cap + 1;
+        load[k] += items[i].in_len + 1;
     }
+    for (auto &idx : shard) std::sort(idx.begin(), idx.end());
+}
+
+} // namespace
+
+// the plan alone (host only, no GPU): which slice of which stream xlz_decode_batch_multi would hand to which context
+extern "C" int xlz_decode_batch_multi_plan(size_t n_ctx, const xlz_stream_desc *streams, size_t n, xlz_multi_item *out,
+                                           size_t max_items, size_t *n_items)
+{
+    if (!n_ctx || (!streams && n) || !n_items || (!out && max_items)) return XLZ_ERR_BAD_ARG;
+    for (size_t i = 0; i < n; i++)
+        if (!streams[i].in && streams[i].in_len) return XLZ_ERR_BAD_ARG;
+    std::vector<MultiItem> items;
+    std::vector<std::vector<size_t>> shard;
+    multi_plan(n_ctx, streams, n, items, shard);
+    *n_items = items.size();
+    for (size_t c = 0; c < n_ctx; c++)
+        for (size_t k : shard[c]) {
+            if (k >= max_items) continue;
+            const MultiItem &it = items[k];
+            out[k].stream = it.stream;
+            out[k].context = (uint32_t)c;
+            out[k].flags = (it.whole ? 1u : 0u) | (it.first ? 2u : 0u) | (it.last ? 4u : 0u);
+            out[k].in_off = it.in_off;
+            out[k].in_len = it.in_len;
+            out[k].out_off = it.out_off;
+            out[k].out_len = it.out_len;
+        }
+    return max_items && items.size() > max_items ? XLZ_ERR_OUT_CAP : XLZ_OK;
+}
+
+extern "C" int xlz_decode_batch_multi(xlz_ctx *const *ctxs, size_t n_ctx, const xlz_stream_desc *streams, size_t n,
+                                      xlz_result *results)
+{
+    if (!ctxs || n_ctx == 0 || (!streams && n) || (!results && n)) return XLZ_ERR_BAD_ARG;
+    for (size_t c = 0; c < n_ctx; c++)
+        if (!ctxs[c]) return XLZ_ERR_BAD_ARG;
+    for (size_t i = 0; i < n; i++)
+        if ((!streams[i].in && streams[i].in_len) || (!streams[i].out && streams[i].out_cap)) return XLZ_ERR_BAD_ARG;
+    if (n_ctx == 1 || n == 0) return xlz_decode_batch(ctxs[0], streams, n, results);
+    std::vector<MultiItem> items;
+    std::vector<std::vector<size_t>> shard;
+    multi_plan(n_ctx, streams, n, items, shard);
     std::vector<int> st(n_ctx, XLZ_OK);
     auto work = [&](size_t c) {
         std::vector<size_t> &idx = shard[c];
         if (idx.empty()) return;
-        std::sort(idx.begin(), idx.end());
         std::vector<xlz_stream_desc> d(idx.size());
         std::vector<xlz_result> r(idx.size());
-        for (size_t k = 0; k < idx.size(); k++) d[k] = streams[idx[k]];
+        for (size_t k = 0; k < idx.size(); k++) {
+            const MultiItem &it = items[idx[k]];
+            d[k] = streams[it.stream];
+            if (!it.whole) {
+                d[k].in += it.in_off;
+                d[k].in_len = (size_t)it.in_len;
+                d[k].out += it.out_off;
+                d[k].out_cap = it.last ? (size_t)(streams[it.stream].out_cap - it.out_off) : (size_t)it.out_len;
+                if (!it.first) d[k].flags |= XLZ_STREAM_F_LZMA2_SLICE;
+            }
+        }
         st[c] = xlz_decode_batch(ctxs[c], d.data(), d.size(), r.data());
         if (st[c] == XLZ_OK)
-            for (size_t k = 0; k < idx.size(); k++) results[idx[k]] = r[k];
+            for (size_t k = 0; k < idx.size(); k++) items[idx[k]].res = r[k];
     };
     std::vector<std::thread> th;
     for (size_t c = 1; c < n_ctx; c++) th.emplace_back(work, c);
@@ -1483,6 +1617,45 @@ extern "C" int xlz_decode_batch_multi(xlz_ctx *const *ctxs, size_t n_ctx, const 
     for (auto &x : th) x.join();
     for (size_t c = 0; c < n_ctx; c++)
         if (st[c] != XLZ_OK) return st[c];
+    // ---- fold: a stream dealt in slices is done when every slice came back exactly as its headers announce
+    std::vector<size_t> again;
+    for (size_t k = 0; k < items.size();) {
+        const size_t i = items[k].stream;
+        if (items[k].whole) {
+            results[i] = items[k].res;
+            k++;
+            continue;
+        }
+        bool clean = true;
+        xlz_result sum{};
+        size_t e = k;
+        for (; e < items.size() && items[e].stream == i; e++) {
+            const MultiItem &it = items[e];
+            if (it.last)
+                clean = clean && it.res.status == XLZ_OK;
+            else
+                clean = clean && it.res.status == XLZ_ERR_UNEXPECTED_EOF && it.res.out_len == it.out_len &&
+                        it.res.in_consumed == it.in_len;
+            sum.out_len += it.res.out_len;
+            if (it.last) {
+                sum.in_consumed = it.in_off + it.res.in_consumed;
+                sum.status = it.res.status;
+            }
+        }
+        if (clean)
+            results[i] = sum;
+        else
+            again.push_back(i);
+        k = e;
+    }
+    if (!again.empty()) { // (malformed streams only) as a whole, on the first context: what the single-GPU call returns
+        std::vector<xlz_stream_desc> d(again.size());
+        std::vector<xlz_result> r(again.size());
+        for (size_t k = 0; k < again.size(); k++) d[k] = streams[again[k]];
+        const int s2 = xlz_decode_batch(ctxs[0], d.data(), d.size(), r.data());
+        if (s2 != XLZ_OK) return s2;
+        for (size_t k = 0; k < again.size(); k++) results[again[k]] = r[k];
+    }
     return XLZ_OK;
 }
 

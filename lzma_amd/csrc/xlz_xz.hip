@@ -208,10 +208,29 @@ extern "C" int xlz_xz_index(const uint8_t *file, size_t len, xlz_xz_block *block
 // Whole file: index, one batch (block = raw LZMA2 stream, reader2.go:26-41), optional integrity
 // check of every block (CRC32 / CRC64 on host threads; other check types are left unverified
 // and reported through *unverified).
+static int xz_decode(xlz_ctx *const *ctxs, size_t n_ctx, const uint8_t *file, size_t len, uint8_t *out, size_t out_cap,
+                     uint64_t *out_len, int verify, size_t *unverified);
+
 extern "C" int xlz_xz_decode(xlz_ctx *ctx, const uint8_t *file, size_t len, uint8_t *out, size_t out_cap, uint64_t *out_len,
                              int verify, size_t *unverified)
 {
-    if (!ctx || !file || (!out && out_cap) || !out_len) return XLZ_ERR_BAD_ARG;
+    return xz_decode(&ctx, 1, file, len, out, out_cap, out_len, verify, unverified);
+}
+
+// several contexts (one per GPU): the blocks, and the units inside large blocks, are dealt by xlz_decode_batch_multi
+extern "C" int xlz_xz_decode_multi(xlz_ctx *const *ctxs, size_t n_ctx, const uint8_t *file, size_t len, uint8_t *out,
+                                   size_t out_cap, uint64_t *out_len, int verify, size_t *unverified)
+{
+    if (!ctxs || !n_ctx) return XLZ_ERR_BAD_ARG;
+    return xz_decode(ctxs, n_ctx, file, len, out, out_cap, out_len, verify, unverified);
+}
+
+static int xz_decode(xlz_ctx *const *ctxs, size_t n_ctx, const uint8_t *file, size_t len, uint8_t *out, size_t out_cap,
+                     uint64_t *out_len, int verify, size_t *unverified)
+{
+    for (size_t c = 0; c < n_ctx; c++)
+        if (!ctxs[c]) return XLZ_ERR_BAD_ARG;
+    if (!file || (!out && out_cap) || !out_len) return XLZ_ERR_BAD_ARG;
     *out_len = 0;
     if (unverified) *unverified = 0;
     size_t nb = 0;
@@ -233,7 +252,7 @@ extern "C" int xlz_xz_decode(xlz_ctx *ctx, const uint8_t *file, size_t len, uint
         d[i].format = XLZ_FMT_LZMA2_RAW;
         d[i].dict_size = blk[i].dict_size;
     }
-    st = xlz_decode_batch(ctx, d.data(), nb, r.data());
+    st = n_ctx > 1 ? xlz_decode_batch_multi(ctxs, n_ctx, d.data(), nb, r.data()) : xlz_decode_batch(ctxs[0], d.data(), nb, r.data());
     if (st != XLZ_OK) return st;
     for (size_t i = 0; i < nb; i++) {
         if (r[i].status < 0) return r[i].status;

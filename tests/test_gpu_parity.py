@@ -338,6 +338,67 @@ def test_multi_device_driver_on_gpu(ctx):
     assert lzma_amd.decode_batch_on([ctx], streams2[:3]) == lzma_amd.decode_batch(ctx, streams2[:3])
 
 
+def test_units_of_one_stream_and_blocks_of_one_file_over_three_contexts(ctx):
+    """SURVEY 8e, second clause: ONE LZMA2 stream of 4096 dictionary-reset units through
+    xlz_decode_batch_multi with three contexts (all on this GPU): every context decodes a run of units -- a slice of the
+    compressed input into a disjoint slice of the caller's buffer --, bytes / status / in_consumed equal the oracle's,
+    every context's last call decoded units.  Then the same stream damaged (a unit that no longer decodes to what its
+    headers announce: the call falls back to the whole stream on one context and still equals the oracle), a stream that
+    reads behind a dictionary reset into another slice's bytes, and a multi-block .xz file through xlz_xz_decode_multi."""
+    import lzma
+    from lzma_craft import long_stale_lzma2_stream
+    enc = {"mode": 1, "mf": 3, "nice_len": 32, "depth": 2}
+    segs = [corpus.plain("TRMZ"[k % 4] if k % 16 == 0 else "T", 7000 + k, 9000 + 700 * (k % 13)) for k in range(4096)]
+    blob = corpus.lzma2_concat(segs, dict_size=1 << 16, preset=enc)
+    plain = b"".join(segs)
+    want = oracle.lzma2_raw(blob, 1 << 16, len(plain))
+    assert want == (plain, 0, len(blob))
+    ctxs = [ctx, lzma_amd.Context(0), lzma_amd.Context(0)]
+    s = Stream(blob, lzma_amd.FMT_LZMA2_RAW, out_cap=len(plain), dict_size=1 << 16)
+    items = lzma_amd.multi_plan(3, [s])
+    assert len(items) == 12 and {it["context"] for it in items} == {0, 1, 2}
+    res = lzma_amd.decode_batch_on(ctxs, [s])
+    assert res[0] == want
+    units = [c.last_call_stats()["units"] for c in ctxs]
+    assert all(u > 0 for u in units) and sum(units) == 4096, units
+    # with other streams around it (dealt whole), results in input order
+    small = [corpus.plain("T", 7900 + i, 20_000) for i in range(30)]
+    mixed = [Stream(corpus.compress_alone(p), out_cap=len(p)) for p in small[:15]] + [s] + \
+            [Stream(corpus.compress_alone(p), out_cap=len(p)) for p in small[15:]]
+    res = lzma_amd.decode_batch_on(ctxs, mixed)
+    assert res[15] == want and [r[0] for r in res[:15] + res[16:]] == small and all(r[1] == 0 for r in res)
+    # a damaged unit in the middle: the slices no longer come back as announced -> the whole stream on one context
+    for at in (len(blob) // 2, len(blob) // 3 + 17, len(blob) - 5000):
+        bad = bytearray(blob)
+        bad[at] ^= 0x40
+        bad = bytes(bad)
+        got = lzma_amd.decode_batch_on(ctxs, [Stream(bad, lzma_amd.FMT_LZMA2_RAW, out_cap=len(plain), dict_size=1 << 16)])[0]
+        assert got == oracle.lzma2_raw(bad, 1 << 16, len(plain)), at
+    # the stream cut short (no end byte) and with too little room
+    for cut, cap in ((len(blob) - 1, len(plain)), (len(blob) * 2 // 3, len(plain)), (len(blob), len(plain) - 100_000)):
+        got = lzma_amd.decode_batch_on(ctxs, [Stream(blob[:cut], lzma_amd.FMT_LZMA2_RAW, out_cap=cap, dict_size=1 << 16)])[0]
+        assert got == oracle.lzma2_raw(blob[:cut], 1 << 16, cap), (cut, cap)
+    # copies that read BEHIND a dictionary reset (window.go:135-140 keeps the buffer): the bytes belong to another slice
+    # (behind four incompressible dictionary-reset segments, so that the stream is worth cutting and the reads happen in a
+    #  slice that does not begin at the stream's start: no slice can settle them -> the whole stream on one context)
+    pre = [corpus.plain("R", 8000 + k, 30_000) for k in range(4)]
+    for ds in (4096, 65536):
+        sb, sw = long_stale_lzma2_stream(ds, seed=ds + 1)
+        assert sb[0] == 1 or sb[0] >= 0xE0
+        both = corpus.lzma2_concat(pre, dict_size=ds, preset=enc)[:-1] + sb
+        ss = Stream(both, lzma_amd.FMT_LZMA2_RAW, out_cap=120_000 + len(sw) + 100, dict_size=ds)
+        assert len(lzma_amd.multi_plan(3, [ss])) > 1
+        assert lzma_amd.decode_batch_on(ctxs, [ss])[0] == oracle.lzma2_raw(both, ds, ss.out_cap) == (b"".join(pre) + sw, 0, len(both))
+    # an .xz file of 48 blocks: the blocks are the items
+    blocks = [corpus.plain("T", 8100 + i, 150_000 + 1000 * i) for i in range(48)]
+    filt = [dict(corpus.lzma1_filters(dict_size=1 << 20, preset=enc)[0], id=lzma.FILTER_LZMA2)]
+    xz = b"".join(lzma.compress(p, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC64, filters=filt) for p in blocks)
+    assert lzma_amd.xz_decode_on(ctxs, xz) == b"".join(blocks) == lzma_amd.xz_decode(ctx, xz)
+    assert all(c.last_call_stats()["units"] > 0 for c in ctxs)
+    for c in ctxs[1:]:
+        c.close()
+
+
 # ------------------------------------------------ models too large for LDS (lc+lp > 6) ----
 def test_large_lc_lp_models_live_in_hbm(ctx):
     """The reference accepts lc <= 8, lp <= 4 (reader1.go:210-221): up to 0x300 << 12 probs.

@@ -185,3 +185,58 @@ def test_batch_advice_counts_the_units_a_call_would_launch():
     assert a["units"] == 1 and a["prefer_cpu"] == 1 and a["break_even_units"] == 16
     empty = lzma_amd.batch_advice([], host_threads=4)
     assert empty["units"] == 0 and empty["fill"] == 0.0 and empty["prefer_cpu"] == 1
+
+
+def _check_plan(items, streams, n_ctx):
+    """every stream is covered exactly once by its items, in order; slices begin and end at unit boundaries"""
+    by = {}
+    for k, it in enumerate(items):
+        by.setdefault(it["stream"], []).append(it)
+        assert it["context"] < n_ctx
+    assert sorted(by) == list(range(len(streams)))
+    for i, its in by.items():
+        s = streams[i]
+        if its[0]["whole"]:
+            assert len(its) == 1 and its[0]["in_off"] == 0 and its[0]["in_len"] == len(s.data)
+            continue
+        starts = {u["in_off"]: u for u in lzma_amd.lzma2_units(s.data)}
+        assert its[0]["first"] and its[-1]["last"] and its[0]["in_off"] == 0 and its[0]["out_off"] == 0
+        for a, b in zip(its, its[1:]):
+            assert a["in_off"] + a["in_len"] == b["in_off"] and a["out_off"] + a["out_len"] == b["out_off"]
+            assert not a["last"] and not b["first"]
+        for it in its:
+            assert it["in_off"] in starts and starts[it["in_off"]]["out_off"] == it["out_off"]
+        assert its[-1]["in_off"] + its[-1]["in_len"] == len(s.data)
+
+
+def test_the_units_of_one_stream_are_dealt_to_several_contexts():
+    """SURVEY 8e, second clause: xlz_decode_batch_multi deals the UNITS of an LZMA2 stream that is a large
+    part of the call to the contexts -- each gets a slice of the compressed input and a disjoint slice of the output,
+    balanced by compressed bytes -- instead of landing the whole stream on one GPU.  The plan alone, without a GPU."""
+    import corpus
+    # ONE stream of 600 dictionary-reset units of unequal size, three contexts
+    blob, units = plan([stored(2000 + 97 * (j % 50), True) for j in range(600)])
+    big = lzma_amd.Stream(blob, lzma_amd.FMT_LZMA2_RAW, out_cap=sum(u["out_len"] for u in units), dict_size=1 << 16)
+    items = lzma_amd.multi_plan(3, [big])
+    _check_plan(items, [big], 3)
+    assert len(items) == 12 and not items[0]["whole"]            # (4 pieces per context at most)
+    load = [sum(it["in_len"] for it in items if it["context"] == c) for c in range(3)]
+    assert max(load) - min(load) < 0.1 * sum(load) and min(load) > 0
+    # a mixed call: the big stream, many small LZMA1 streams, one LZMA2 stream of a single unit
+    one = corpus.compress_alone(corpus.plain("T", 1, 5000), dict_size=1 << 16)
+    single = corpus.compress_raw_lzma2(corpus.plain("T", 3, 300_000), dict_size=1 << 20)
+    streams = [lzma_amd.Stream(one, out_cap=5000) for _ in range(40)] + [big] + \
+              [lzma_amd.Stream(single, lzma_amd.FMT_LZMA2_RAW, out_cap=300_000, dict_size=1 << 20)]
+    items = lzma_amd.multi_plan(4, streams)
+    _check_plan(items, streams, 4)
+    assert sum(1 for it in items if it["stream"] == 40) > 4       # the big stream in slices
+    assert [it["whole"] for it in items if it["stream"] == 41] == [True]
+    load = [sum(it["in_len"] for it in items if it["context"] == c) for c in range(4)]
+    assert max(load) < 1.25 * (sum(load) / 4)
+    # too little room for what the headers announce: dealt whole (the single-GPU path settles status and bytes)
+    tight = lzma_amd.Stream(blob, lzma_amd.FMT_LZMA2_RAW, out_cap=1000, dict_size=1 << 16)
+    assert [it["whole"] for it in lzma_amd.multi_plan(3, [tight])] == [True]
+    # a small stream is not worth cutting; one context gets everything whole
+    small, _ = plan([stored(3000, True) for _ in range(10)])
+    assert [it["whole"] for it in lzma_amd.multi_plan(3, [lzma_amd.Stream(small, lzma_amd.FMT_LZMA2_RAW, out_cap=30000)])] == [True]
+    assert all(it["whole"] and it["context"] == 0 for it in lzma_amd.multi_plan(1, streams))
