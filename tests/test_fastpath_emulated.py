@@ -172,7 +172,9 @@ NEXT = ("slot0", "vprev", "rmov", "nopos", "l7blk", "warel", "vreps")   # round 
                                         (("dbrw",), ("slot0",)), ((), ("wsb",)), (("dbr",), ("rlhoist",)), (("scode",), ()),
                                         (("scode",), ("rlhoist", "wsb")), (("hsb",), ()), (("hsb", "scode"), ()), ((), ("lwait",)), (("dbr", "dbrs"), ()), (("pref",), ("db6",)),
                                         ((), ("db6",)), ((), ("tu8",)), ((), ("cchk",)), ((), ("lctx",)), ((), ("hiss",)),
-                                        ((), ("db6", "tu8", "cchk", "lctx", "hiss")), ((), ("tuc",)), ((), ("vperm",))])
+                                        ((), ("db6", "tu8", "cchk", "lctx", "hiss", "g8", "hd2", "rmov2")), ((), ("tuc",)), ((), ("vperm",)),
+                                        ((), ("g8",)), ((), ("hd2",)), ((), ("rmov2",)), (("rot",), ()), (("vcur",), ("hd2",)),
+                                        (("hoist0",), ("hd2",)), (("rot", "vcur", "hoist0"), ("hd2", "rmov2"))])
 def test_generator_switches_still_decode(add, remove):
     """the code paths kept in the generator as measured alternatives (profiles/r02/layout_scan.md)
     are not dead code: each of them decodes a stream correctly on the emulator"""

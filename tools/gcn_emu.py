@@ -531,6 +531,10 @@ class Machine:
         en, a = self._dpp(mods, self.rv(o[1]))
         self.wv(o[0], a - self.rv(o[2]), mask=en)
 
+    def i_v_lshrrev_b32_dpp(self, o, mods):
+        en, a = self._dpp(mods, self.rv(o[1]))  # (src0, the shift count, is what the DPP control permutes)
+        self.wv(o[0], self.rv(o[2]) >> (a & np.uint64(31)), mask=en)
+
     def i_v_mov_b32_dpp(self, o, mods):
         en, a = self._dpp(mods, self.rv(o[1]))
         self.wv(o[0], a, mask=en)

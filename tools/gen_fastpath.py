@@ -97,9 +97,23 @@ ROUND3_VARIANT = {"wsb", "lwait"}
 #          its start (LDS offsets): three vector instructions less per literal
 #   hiss   the head gather's address in three instructions instead of four                                  lctx + hiss: T +1.0 %  R +2.8 %  S +2.1 %
 # all five: T +6.5 %  R +3.3 %  S +5.5 %  M +4.2 %
-ROUND4_VARIANT = {"db6", "tu8", "cchk", "lctx", "hiss"}
+#   g8     the 8-level trees' update addresses slot 0 in the lanes that are no level by a shift count of 31: no select
+#   hd2    head update as ONE multiply-add and a DPP shift: (31 p + 2048) >> 5 = p - ((p - 2017) >> 5)
+#   rmov2  isRep = 0 and the length choice = 0 leave their bound where it was read; no s_mov into the range per decision
+#          g8 + hd2 + rmov2: T +0.7 %  R +0.9 %  M +0.7 %  (S within the noise of +-0.4 %)
+# measured and NOT adopted (profiles/r04/ab_round4_variants.txt): rot (the literal loop rotated so that the isMatch branch is the
+# back edge: S +0.9 %, R -0.3 %), vcur (the input word on the VALU: one scalar instruction less per input byte, +-0.2 % --
+# incompressible data is NOT simply bound by the scalar port), hoist0 (the packet head's hazard s_nop replaced by useful work: -0.4 % T)
+ROUND4_VARIANT = {"db6", "tu8", "cchk", "lctx", "hiss", "g8", "hd2", "rmov2"}
 DEFAULT_VARIANT = {"lgather", "hdpp", "flim", "cflag", "tuc", "vperm", "rlhoist", "bralign", "stub32", "head32", "pktl64"}
 VARIANT = set(DEFAULT_VARIANT) | NEXT_VARIANT | ROUND3_VARIANT | ROUND4_VARIANT   # (xlz_kernel.hip passes what lctx / hiss expect: XLZ_NO_LCTX / XLZ_NO_HISS for A/B builds without them)
+
+
+def rot():
+    """rot (round 4): the literal loop is rotated -- the literal's body lies in FRONT of the packet head that follows it, and
+    the isMatch decision's branch is the loop's back edge (taken for a literal); a match falls through into the match path.
+    One instruction less per literal (the unconditional branch back to the head) and no taken branch into the match path."""
+    return "rot" in VARIANT and "rmov" in VARIANT and "litrun" not in VARIANT
 
 
 def hdpp_lane(j):
@@ -131,7 +145,7 @@ ALIGNED = ("pktl", "match", "mlit", "rep")  # reached by branches only (the code
 
 
 def label(name):
-    if "bralign" in VARIANT and name == "pktl":  # tools/layout.py lays the stream out from here
+    if "bralign" in VARIANT and name == ("litb" if rot() else "pktl"):  # tools/layout.py lays the stream out from here
         lines.append(".p2align %d" % (6 if "pktl64" in VARIANT else 5 if "pktl32" in VARIANT else 4))
     for v in VARIANT:
         if v.startswith("shift") and name == "pktl":  # A/B: everything behind the loop's entry code moves by N dwords
@@ -162,7 +176,7 @@ def head_src():
     return "v40" if hsb() else "v55"
 
 
-def bounds(src, dst="v55"):
+def bounds(src, dst="v55", rin="%[range]"):
     """dst = (range >> 11) * p for all 64 probabilities of VGPR `src` -- entirely on the VALU (the
     scalar port is the bottleneck).  The lane select of a later v_readlane then picks the BOUND.
     gfx940-family hazard: that v_readlane must not be the very next instruction (one wait state
@@ -170,7 +184,7 @@ def bounds(src, dst="v55"):
     inside inline asm) -- callers put independent work in between."""
     if src == "v40" and hsb():
         return  # (the head probabilities are read as they are; hbit multiplies on the scalar side)
-    emit("v_lshrrev_b32 %s, 11, %%[range]\nv_mul_u32_u24 %s, %s, %s" % (dst, dst, dst, src))
+    emit("v_lshrrev_b32 %s, 11, %s\nv_mul_u32_u24 %s, %s, %s" % (dst, rin, dst, dst, src))
 
 
 def decide(scalar_bound=False, rin="%[range]"):
@@ -293,12 +307,32 @@ stub_scode = set()   # stubs of a walk whose CODE lives in s87 (scode)
 SCODE = [False]      # a scode walk is being generated
 
 
+def vcur():
+    return "vcur" in VARIANT and "vperm" in VARIANT and "warel" in VARIANT and "tu8" in VARIANT and "scode" not in VARIANT
+
+
 def emit_stubs():
     for k in stubs:
         label(k)
         rr = stub_reg.get(k, "%[range]")
         if k in stub_scode:  # the code is in s87 during this walk (s81: the normalisation test's dead result)
             emit("s_lshl_b32 %s, %s, 8\ns_lshl_b32 s87, s87, 8\ns_and_b32 s81, %%[cur], 0xff\ns_or_b32 s87, s87, s81" % (rr, rr))
+        elif vcur():
+            # vcur (round 4): the current input word lives in v30 (wave-uniform; free since tu8): its shift is a vector
+            # instruction -- one scalar-port instruction less per input byte (the port is what binds literal-heavy data)
+            emit("""
+            s_lshl_b32 %s, %s, 8
+            v_perm_b32 v29, v29, v30, v13
+            v_lshrrev_b32 v30, 8, v30
+            s_sub_u32 s91, s91, 1
+            s_cbranch_scc0 %s
+            s_add_u32 s90, s90, 1
+            s_mov_b32 s91, 3
+            v_readlane_b32 %%[cur], %%[vin], s90
+            v_mov_b32 v30, %%[cur]
+            s_branch %s
+            """ % (rr, rr, L(k + "b"), L(k + "b")))
+            continue
         elif "vperm" in VARIANT:  # code = code << 8 | next byte in ONE byte permute (v13 = the selector), no scalar mask
             emit("s_lshl_b32 %s, %s, 8\nv_perm_b32 v29, v29, %%[cur], v13" % (rr, rr))
         else:
@@ -376,7 +410,22 @@ def emit_finish_blocks():
         emit("s_branch %s" % L(k + "b"))
 
 
-def head_update(lane, bit):
+def hoist0():
+    """hoist0 (round 4): the first instruction of the isMatch = 0 update (v63 = p - 2017) does not depend on the decision: it
+    sits in the wait state between the lane read of the bound and the compare that uses it (gfx950: two wait states
+    between a VALU write of an SGPR and its VALU read), where the hazard pass had to put an s_nop -- one instruction less
+    per packet head.  (A match recomputes v63 in its own update.)"""
+    return "hoist0" in VARIANT and "hdpp" in VARIANT and "flim" in VARIANT and not hsb()
+
+
+def hd2():
+    """hd2 (round 4): p - ((p - 2017) >> 5) = (31 p + 2048) >> 5 and p - (p >> 5) = (31 p + 31) >> 5: the head update is one
+    multiply-add (s87 = 2048) and one DPP shift (v30 = 5 in every lane; free since tu8) -- two vector instructions instead of
+    three for a decision that comes out 0 (every literal's isMatch, a simple match's isRep and length choice)"""
+    return "hd2" in VARIANT and "hdpp" in VARIANT and "tu8" in VARIANT and "scode" not in VARIANT and not vcur() and not hoist0()
+
+
+def head_update(lane, bit, hoisted=False):
     """new value of head probability `lane` (decompress.go:30 / :177), VALU only: the lanes of v40
     all compute it from their own value, lane `lane` keeps it.  v40 goes back to LDS in one
     store when the packet is over (head_issue / exit)."""
@@ -385,12 +434,17 @@ def head_update(lane, bit):
         # last subtract writes only that cell (row_mask / bank_mask) -- no lane compare, no select
         j = (lane // 16) * 4 + (lane % 16) // 4
         assert lane == hdpp_lane(j)
+        if hd2():
+            emit("v_mad_u32_u24 v63, v40, 31, %s" % ("s87" if bit == 0 else "31"))
+            emit("v_lshrrev_b32_dpp v40, v30, v63 quad_perm:[0,1,2,3] row_mask:0x%x bank_mask:0x%x" % (1 << (j // 4), 1 << (j % 4)))
+            return
         if bit == 0:
-            emit("v_add_u32 v63, 0xfffff81f, v40\nv_ashrrev_i32 v63, 5, v63")
+            emit(("" if hoisted else "v_add_u32 v63, 0xfffff81f, v40\n") + "v_ashrrev_i32 v63, 5, v63")
         else:
             emit("v_ashrrev_i32 v63, 5, v40")
         emit("v_sub_u32_dpp v40, v40, v63 quad_perm:[0,1,2,3] row_mask:0x%x bank_mask:0x%x" % (1 << (j // 4), 1 << (j % 4)))
         return
+    assert not hoisted
     emit("v_cmp_eq_u32 vcc, %d, %%[vlane]" % lane)
     if bit == 0:
         emit("v_add_u32 v63, 0xfffff81f, v40\nv_ashrrev_i32 v63, 5, v63")
@@ -399,11 +453,11 @@ def head_update(lane, bit):
     emit("v_sub_u32 v63, v40, v63\nv_cndmask_b32 v40, v40, v63, vcc")
 
 
-def head_pick(lane, src=None):
-    return lambda: emit("v_readlane_b32 s80, %s, %d" % (src or head_src(), lane))
+def head_pick(lane, src=None, dst="s80"):
+    return lambda: emit("v_readlane_b32 %s, %s, %d" % (dst, src or head_src(), lane))
 
 
-def hbit(lane, one, stage=0, next_head=None, breg="s80", keep=False):
+def hbit(lane, one, stage=0, next_head=None, breg="s80", keep=False, hoisted=False):
     """One decision on head probability `lane` (already in v40), both outcomes specialised: VCC of
     the compare is branched on directly.  Bit 0 falls through; bit 1 goes to label `one`, where
     the caller emits hbit_one(lane) first.
@@ -419,7 +473,7 @@ def hbit(lane, one, stage=0, next_head=None, breg="s80", keep=False):
     emit("v_cmp_gt_u32 vcc, %s, v29\ns_cbranch_vccz %s" % (breg, one))
     if not keep:  # keep (rmov): the new range stays in `breg`; the literal's first level reads it there
         emit("s_mov_b32 %%[range], %s" % breg)
-    head_update(lane, 0)
+    head_update(lane, 0, hoisted=hoisted)
     if next_head is not None:
         assert not keep
         nchk(prefix=lambda: bounds("v40"), pick=head_pick(next_head))
@@ -427,11 +481,11 @@ def hbit(lane, one, stage=0, next_head=None, breg="s80", keep=False):
         nchk(rreg=breg if keep else None)
 
 
-def hbit_one(lane, next_head=None, breg="s80"):
-    emit("v_subrev_u32 v29, %s, v29\ns_sub_u32 %%[range], %%[range], %s" % (breg, breg))
+def hbit_one(lane, next_head=None, breg="s80", rin="%[range]", pick_dst="s80"):
+    emit("v_subrev_u32 v29, %s, v29\ns_sub_u32 %%[range], %s, %s" % (breg, rin, breg))
     head_update(lane, 1)
     if next_head is not None:
-        nchk(prefix=lambda: bounds("v40"), pick=head_pick(next_head))
+        nchk(prefix=lambda: bounds("v40"), pick=head_pick(next_head, dst=pick_dst))
     else:
         nchk()
 
@@ -454,7 +508,7 @@ def level_pick(k):
         emit("v_readlane_b32 s84, v62, s88\ns_bitcmp1_b32 s88, 6\ns_cselect_b32 s80, s84, s80")
 
 
-def walk(nbits, blocks, early_exit=None, filler="s_nop 0"):
+def walk(nbits, blocks, early_exit=None, filler="s_nop 0", range0=None):
     """Walk nbits <= 6 levels of a bit tree whose 64-prob block is already in blocks[0]
     (bit_tree_decoder.go:18-40).  s88 ends as 1 followed by the COMPLEMENTED decided bits (the tree
     slot order of xlz_kernel.hip: tree_slot).  Nothing is recorded: tree_update finds the
@@ -469,8 +523,9 @@ def walk(nbits, blocks, early_exit=None, filler="s_nop 0"):
         # between the scalar and the vector side twice per level instead of four times -- the waves are bound by that
         # chain's latency, not by the issue ports (bench.py roofline.issue: 78 % of a lone wave's speed at 16 per CU)
         emit(filler)
-        walk_rec(nbits, blocks, early_exit=early_exit)
+        walk_rec(nbits, blocks, early_exit=early_exit, range0=range0)
         return
+    assert range0 is None
     level_prefix(0, blocks)
     emit(filler)
     emit("v_readlane_b32 s80, v55, 1\n" + slot_init())
@@ -715,6 +770,12 @@ def gather8(blocks, dst="v54"):
     """ % (blocks[0], blocks[1], blocks[2], blocks[3], dst, dst, dst))
 
 
+def g8():
+    """g8 (round 4): the per-lane shift count v19 (8 - level) is 31 in the lanes that are no level (>= 8): their slot is 0, the
+    tree's unused entry, without a select -- one vector instruction less per 8-level tree update"""
+    return "g8" in VARIANT
+
+
 def lit_off(base):
     """lctx: the literal table is addressed relative to its start (v39 = litState << 9); the LDS instructions carry P_LIT"""
     return P_LIT * 2 if ("lctx" in VARIANT and base == "v39") else 0
@@ -734,10 +795,9 @@ def rec_gather_issue(base, masked):
     dump = "0" if off else "v38"   # (relative addressing: slot 0 of the first literal state's tree, which no walk visits)
     if masked:
         emit("v_cndmask_b32 v60, v60, %s, vcc" % dump)
-    emit("""
-    v_cndmask_b32 v60, %s, v60, s[76:77]
-    ds_read_u16 %s, v60%s
-    """ % (dump, "v33" if masked else "v54", (" offset:%d" % off) if off else ""))
+    if not g8():
+        emit("v_cndmask_b32 v60, %s, v60, s[76:77]" % dump)
+    emit("ds_read_u16 %s, v60%s" % ("v33" if masked else "v54", (" offset:%d" % off) if off else ""))
 
 
 def tree_update_rec(nb, base, store=True, issued=False, pending=0, filler=None):
@@ -775,7 +835,9 @@ def tree_update_rec(nb, base, store=True, issued=False, pending=0, filler=None):
     """ % base)
     if store:
         off = lit_off(base)
-        emit("v_cndmask_b32 v60, %s, v60, s[76:77]\nds_write_b16 v60, v61%s" % ("0" if off else "v38", (" offset:%d" % off) if off else ""))
+        if not g8():
+            emit("v_cndmask_b32 v60, %s, v60, s[76:77]" % ("0" if off else "v38"))
+        emit("ds_write_b16 v60, v61%s" % ((" offset:%d" % off) if off else ""))
 
 
 def len_request(base):
@@ -806,24 +868,42 @@ def posslot_request(static):
     emit("v_add_u32 v57, s92, v56\nds_read_u16 v36, v57" if "tu8" in VARIANT else "v_add_u32 v59, s92, v56\nds_read_u16 v36, v59")
 
 
-def len_decode(tag, base, lane_c, lane_c2, posslot):
+def rmov2():
+    """rmov2 (round 4): what rmov does for isMatch -> literal, for isRep -> length choice -> length tree: a head decision
+    that comes out 0 leaves its bound, which is the new range, where it was read (s83, then s84) and the next decision takes
+    it from there -- no s_mov into %[range] per decision (two scalar instructions less per simple match)"""
+    return "rmov2" in VARIANT and "wsb" in VARIANT and lgather() and not hsb() and "litrun" not in VARIANT
+
+
+def len_decode(tag, base, lane_c, lane_c2, posslot, chain=None):
     """lenDecoder.Decode (len_decoder.go:34-60): raw length -> s89, the walked tree updated.
-    posslot: request the distance-slot block as soon as the length is known (simple match)."""
-    hbit(lane_c, L(tag + "c2"), stage=2)  # bounds("v40") and the lane read: len_prefetch
+    posslot: request the distance-slot block as soon as the length is known (simple match).
+    chain = (rin, breg): rmov2 -- the range comes in `rin`, the choice's bound was read into `breg`"""
+    h0 = hoist0()
+    if h0:  # (the wait state between the lane read of the choice's bound and the compare; see hoist0)
+        emit("v_add_u32 v63, 0xfffff81f, v40")
+    if chain:
+        hbit(lane_c, L(tag + "c2"), stage=2, breg=chain[1], keep=True, hoisted=h0)
+    else:
+        hbit(lane_c, L(tag + "c2"), stage=2, hoisted=h0)  # bounds("v40") and the lane read: len_prefetch
     emit("s_waitcnt lgkmcnt(0)")
     tu8 = "tu8" in VARIANT
-    walk(3, ["v41"], filler="" if tu8 else "v_lshlrev_b32 v58, 4, v22\nv_add_u32 v58, %d, v58" % ((base + LEN_LOW) * 2))
+    walk(3, ["v41"], filler="" if tu8 else "v_lshlrev_b32 v58, 4, v22\nv_add_u32 v58, %d, v58" % ((base + LEN_LOW) * 2),
+         range0=chain[1] if chain else None)
     emit("s_andn2_b32 s89, 7, s88")
     if posslot:
         posslot_request(False)
     tree_update(3, ["v41"], addr="v58", off=(base + LEN_LOW) * 2, dump="0")
     label(tag + "end")  # the common (low) path runs straight on; mid and high trees are out of line
-    deferred.append(lambda: len_decode_rest(tag, base, lane_c, lane_c2, posslot))
+    deferred.append(lambda: len_decode_rest(tag, base, lane_c, lane_c2, posslot, chain))
 
 
-def len_decode_rest(tag, base, lane_c, lane_c2, posslot):
+def len_decode_rest(tag, base, lane_c, lane_c2, posslot, chain=None):
     label(tag + "c2")
-    hbit_one(lane_c, next_head=lane_c2)
+    if chain:
+        hbit_one(lane_c, next_head=lane_c2, breg=chain[1], rin=chain[0])
+    else:
+        hbit_one(lane_c, next_head=lane_c2)
     hbit(lane_c2, L(tag + "hi"), stage=2)
     emit("s_waitcnt lgkmcnt(0)")
     walk(3, ["v42"], filler="" if "tu8" in VARIANT else "v_lshlrev_b32 v58, 4, v22\nv_add_u32 v58, %d, v58" % ((base + LEN_MID) * 2))
@@ -873,7 +953,7 @@ def tree_update_rec_hbm(base):
     emit("""
     v_lshrrev_b32 v60, v19, s88
     v_lshl_add_u32 v60, v60, 1, %s
-    v_cndmask_b32_e64 v60, 0, v60, s[76:77]
+    G8MASK
     global_load_ushort v54, v60, %%[mptr]
     v_bfe_u32 v61, s88, v18, 1
     MUL
@@ -882,7 +962,8 @@ def tree_update_rec_hbm(base):
     v_ashrrev_i32 v61, 5, v61
     v_sub_u32 v61, v54, v61
     global_store_short v60, v61, %%[mptr]
-    """.replace("MUL", "" if "tu8" in VARIANT else "v_mul_u32_u24 v61, 0x7e1, v61")
+    """.replace("G8MASK", "" if g8() else "v_cndmask_b32_e64 v60, 0, v60, s[76:77]")
+       .replace("MUL", "" if "tu8" in VARIANT else "v_mul_u32_u24 v61, 0x7e1, v61")
        .replace("SUB", "v_mad_i32_i24 v61, v61, s85, v54" if "tu8" in VARIANT else "v_sub_u32 v61, v54, v61") % base)
 
 
@@ -934,6 +1015,9 @@ def packet_limits(head_lane, breg="s80"):
         s_cbranch_scc1 %s
         """.replace("AREL", "s90" if "warel" in VARIANT else "%%[arel]").replace("HSRC", head_src()) % (breg, head_lane, L("x0")))
         emit(slot_init())  # (a wait state between the lane read and the compare that uses its result)
+        if hoist0():
+            assert head_lane == H_IS_MATCH
+            emit("v_add_u32 v63, 0xfffff81f, v40")
         return
     emit("""
     s_cmp_gt_u32 %%[arel], %%[arel_lim]
@@ -1062,8 +1146,8 @@ def literal_tail(run_entry=None):
     head_issue()
 
 
-def plain_literal(run_entry=None, range0=None):
-    """plain literal (:127-175) with its blocks in v50..v53 and base in v39; ends at pktl"""
+def plain_literal(run_entry=None, range0=None, loop=True):
+    """plain literal (:127-175) with its blocks in v50..v53 and base in v39; ends at pktl (loop=False: falls into what follows)"""
     if "lit8" in VARIANT or "lit8g" in VARIANT:
         walk8(LIT_BLOCKS)
         if lgather():
@@ -1084,7 +1168,8 @@ def plain_literal(run_entry=None, range0=None):
     else:
         tree_update_rec(8, "v39")
         literal_context(prev_v="v32")
-    emit("s_branch %s" % L("pktl"))
+    if loop:
+        emit("s_branch %s" % L("pktl"))
 
 
 def sec_packet_after_literal():
@@ -1092,6 +1177,11 @@ def sec_packet_after_literal():
     # ------------------------------------------------------------- packet after a literal
     # state < 7, no copy pending, literal blocks requested: the three tests of the general
     # packet head are known
+    if rot():
+        label("litb")  # isMatch = 0 has been decided against the bound in s82, which is the new range
+        head_update(H_IS_MATCH, 0, hoisted=hoist0())
+        nchk(rreg="s82")
+        plain_literal(range0="s82", loop=False)
     label("pktl")
     # lwait: both ways here end with the next literal's four block reads as their YOUNGEST LDS operations (literal_context);
     # LDS returns in order, so lgkmcnt(4) says the head gather is back while the blocks are still on their way -- their
@@ -1103,11 +1193,14 @@ def sec_packet_after_literal():
         # level takes it from s82 and writes %[range] itself -- no s_mov per literal (lit8 forms read %[range]: excluded)
         assert "lit8" not in VARIANT and "lit8g" not in VARIANT and "litrun" not in VARIANT
         packet_limits(H_IS_MATCH, breg="s82")
-        hbit(H_IS_MATCH, L("match"), stage=2, breg="s82", keep=True)
+        if rot():
+            emit("v_cmp_gt_u32 vcc, s82, v29\ns_cbranch_vccnz %s" % L("litb"))  # falls into sec_match
+            return
+        hbit(H_IS_MATCH, L("match"), stage=2, breg="s82", keep=True, hoisted=hoist0())
         plain_literal(range0="s82")
         return
     packet_limits(H_IS_MATCH)
-    hbit(H_IS_MATCH, L("match"), stage=2)
+    hbit(H_IS_MATCH, L("match"), stage=2, hoisted=hoist0())
     plain_literal(run_entry=L("lrent") if "litrun" in VARIANT else None)
 
 
@@ -1189,7 +1282,7 @@ def sec_packet_general():
     emit("s_waitcnt lgkmcnt(0)")
     bounds("v40")
     packet_limits(H_IS_MATCH, breg=ismatch_reg())
-    hbit(H_IS_MATCH, L("match"), stage=2, breg=ismatch_reg())
+    hbit(H_IS_MATCH, L("match"), stage=2, breg=ismatch_reg(), hoisted=hoist0())
     # ------------------------------------------------------------- literal (decompress.go:44-175)
     if "cflag" in VARIANT:
         # `pkt` is reached from a copy (pending; prevByte unknown, so no literal blocks yet) or from the loop's
@@ -1279,9 +1372,10 @@ def sec_packet_general():
         v_cndmask_b32 v57, 0, v57, vcc
         global_store_short v57, v61, %%[mptr] offset:512
         v_cndmask_b32 v60, v60, %s, vcc
-        v_cndmask_b32 v60, %s, v60, s[76:77]
+        G8MASK
         ds_write_b16 v60, v61%s
-        """ % ("0" if off else "v38", "0" if off else "v38", (" offset:%d" % off) if off else ""))
+        """.replace("G8MASK", "" if g8() else "v_cndmask_b32 v60, %s, v60, s[76:77]" % ("0" if off else "v38"))
+             % ("0" if off else "v38", (" offset:%d" % off) if off else ""))
     literal_context(prev_v="v32")
     emit("s_branch %s" % L("pktl"))
 
@@ -1290,21 +1384,28 @@ def sec_match():
     """simple match up to the validity test of the new distance; falls into sec_copy"""
     # ------------------------------------------------------------- match or rep
     label("match")
-    hbit_one(H_IS_MATCH, next_head=H_IS_REP, breg=ismatch_reg())
+    r2 = rmov2()
+    hbit_one(H_IS_MATCH, next_head=H_IS_REP, breg=ismatch_reg(), pick_dst="s83" if r2 else "s80")
     label("match2")  # (a literal run joins here with its own isMatch decision done)
     len_request(P_LEN)  # speculative (a rep match asks for its own trees): one LDS round trip earlier
-    hbit(H_IS_REP, L("rep"), stage=2)
+    if r2:
+        hbit(H_IS_REP, L("rep"), stage=2, breg="s83", keep=True)
+    else:
+        hbit(H_IS_REP, L("rep"), stage=2)
     # simple match (:215-668)
-    bounds("v40")  # for the length coder's first decision
+    bounds("v40", rin="s83" if r2 else "%[range]")  # for the length coder's first decision
     if "vreps" in VARIANT:
         # the four reps live in lanes 0..3 of v34 (lane 0 mirrors the scalar rep0): the shift of :216 is one DPP move,
         # the rotations of a rep match one quad permute + one lane read; rep1..3 go back to SGPRs where the loop is left
         emit("v_mov_b32_dpp v34, v34 row_shr:1 row_mask:0x1 bank_mask:0x1")
     else:
         emit("s_mov_b32 %[rep3], %[rep2]\ns_mov_b32 %[rep2], %[rep1]\ns_mov_b32 %[rep1], %[rep0]")
-    len_pick(H_LEN_C)
+    if r2:
+        emit("v_readlane_b32 s84, %s, %d" % (head_src(), H_LEN_C))
+    else:
+        len_pick(H_LEN_C)
     emit("ds_read_u16 v35, v56 offset:%d" % (P_ALIGN * 2))
-    len_decode("lm", P_LEN, H_LEN_C, H_LEN_C2, posslot=True)  # leaves the posSlot block requested, s92 = its base
+    len_decode("lm", P_LEN, H_LEN_C, H_LEN_C2, posslot=True, chain=("s83", "s84") if r2 else None)  # leaves the posSlot block requested, s92 = its base
     emit("s_waitcnt lgkmcnt(0)")
     walk(6, ["v36"], filler="v_readlane_b32 %[state], v20, %[state]" + ("" if "tu8" in VARIANT else "\nv_mov_b32 v58, s92"))  # stateUpdateMatch as a table
     emit("""
@@ -1456,7 +1557,7 @@ def sec_rep():
     """rep matches; out of line, ends with a branch to the copy"""
     # ------------------------------------------------------------- rep match (:685-1123)
     label("rep")
-    hbit_one(H_IS_REP, next_head=H_G0)
+    hbit_one(H_IS_REP, next_head=H_G0, breg="s83" if rmov2() else "s80")
     if nopos():
         emit("s_or_b32 s81, %%[wpos], s94\ns_cbranch_scc0 %s" % L("x1"))  # nothing in the window: pos == wbase
     else:
@@ -1590,6 +1691,8 @@ def sec_exits():
         emit("v_readfirstlane_b32 %[prev], v32" + ("\ns_and_b32 %[prev], %[prev], 0xff" if "lctx" in VARIANT else ""))
     if nopos():
         emit("v_readfirstlane_b32 %[pos], v17")
+    if vcur():
+        emit("v_readfirstlane_b32 %[cur], v30")
     if "warel" in VARIANT:
         emit("s_sub_u32 s80, 3, s91\ns_lshl2_add_u32 %[arel], s90, s80")
     if "vreps" in VARIANT:
@@ -1640,12 +1743,16 @@ def gen():
         emit("v_sub_u32 v14, 3, v31\nv_sub_u32 v15, 4, v31\nv_sub_u32 v16, 6, v31")
     if "tu8" in VARIANT:
         emit("s_movk_i32 s85, -2017")
+    if hd2():
+        emit("s_movk_i32 s87, 2048\nv_mov_b32 v30, 5")
     if "vnorm" in VARIANT:
         emit("v_mov_b32 v17, 0x1000000")
     if "vperm" in VARIANT or "lctx" in VARIANT:
         emit("v_mov_b32 v13, 0x06050400")
     # constants of tree_update_rec
     emit("v_sub_u32 v19, 8, %[vlane]\nv_sub_u32 v18, 7, %[vlane]\nv_cmp_gt_u32 s[76:77], 8, %[vlane]")
+    if g8():
+        emit("s_nop 1\nv_cndmask_b32 v19, 31, v19, s[76:77]")
     if "lit8" in VARIANT:
         emit("v_cmp_eq_u32 s[78:79], 6, %[vlane]")  # gather8: lane 6 takes block 1
     if "litrun" in VARIANT:
@@ -1693,6 +1800,8 @@ def gen():
     head_issue(first=True)
     if "vprev" in VARIANT:
         emit("v_mov_b32 v32, %[prev]")
+    if vcur():
+        emit("v_mov_b32 v30, %[cur]")
     literal_context()  # no copy is pending on entry: prevByte is valid
     if "cflag" in VARIANT:
         emit("s_branch %s" % L("pkt"))
