@@ -661,6 +661,7 @@ def main():
         """the corpus, waiting for its jobs if they are still running"""
         if name not in corp:
             start(name)
+        if name not in corp:   # (start() may have found it in the cache)
             t0 = time.time()
             corp[name] = pending.pop(name).result()
             wait_s[name] = round(time.time() - t0, 1)
