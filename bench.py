@@ -597,7 +597,7 @@ def main():
                                                      "as <prefix><config>.npz")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=12.0)
-    ap.add_argument("--side-cpu-target-s", type=float, default=4.0)
+    ap.add_argument("--side-cpu-target-s", type=float, default=3.0)
     ap.add_argument("--corpus-cache", default="", help="dev (profiling passes): keep generated corpora in this directory and reuse them")
     ap.add_argument("--allow-xlz-so", action="store_true", help="dev: accept a library swapped in with XLZ_SO (recorded in the line)")
     ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"),
