@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 P_LEN, P_LIT = 820, 1596   # (xlz_format.h; the rep-length high tree is the first 256 entries of the model's HBM part)
-K_IN_WINDOW, K_FAST_INPUT, K_FAST_OUTPUT = 256, 32, 336
+K_IN_WINDOW, K_FAST_INPUT, K_FAST_OUTPUT = 256, 32, 128   # (xlz_kernel.hip: kInWindow, kFastInput, kFastOutput)
 
 
 def _render(add=(), remove=()):
@@ -173,7 +173,7 @@ NEXT = ("slot0", "vprev", "rmov", "nopos", "l7blk", "warel", "vreps")   # round 
                                         (("scode",), ("rlhoist", "wsb")), (("hsb",), ()), (("hsb", "scode"), ()), ((), ("lwait",)), (("dbr", "dbrs"), ()), (("pref",), ("db6",)),
                                         ((), ("db6",)), ((), ("tu8",)), ((), ("cchk",)), ((), ("lctx",)), ((), ("hiss",)),
                                         ((), ("db6", "tu8", "cchk", "lctx", "hiss", "g8", "hd2", "rmov2")), ((), ("tuc",)), ((), ("vperm",)),
-                                        ((), ("g8",)), ((), ("hd2",)), ((), ("rmov2",)), (("rot",), ()), (("vcur",), ("hd2",)),
+                                        ((), ("g8",)), ((), ("hd2",)), ((), ("rmov2",)), (("rot",), ()), ((), ("ml4",)), ((), ("pkm",)), ((), ("ml4", "pkm", "g8")), (("vcur",), ("hd2",)),
                                         (("hoist0",), ("hd2",)), (("rot", "vcur", "hoist0"), ("hd2", "rmov2"))])
 def test_generator_switches_still_decode(add, remove):
     """the code paths kept in the generator as measured alternatives (profiles/r02/layout_scan.md)

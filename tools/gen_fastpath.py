@@ -104,9 +104,16 @@ ROUND3_VARIANT = {"wsb", "lwait"}
 # measured and NOT adopted (profiles/r04/ab_round4_variants.txt): rot (the literal loop rotated so that the isMatch branch is the
 # back edge: S +0.9 %, R -0.3 %), vcur (the input word on the VALU: one scalar instruction less per input byte, +-0.2 % --
 # incompressible data is NOT simply bound by the scalar port), hoist0 (the packet head's hazard s_nop replaced by useful work: -0.4 % T)
-ROUND4_VARIANT = {"db6", "tu8", "cchk", "lctx", "hiss", "g8", "hd2", "rmov2"}
+#   ml4    the matched literal's gather addresses from the loop's per-lane constants: four instructions instead of nine
+#   pkm    a pending copy means the packet before was a match: the literal behind it IS a matched literal, no test of the state
+#          ml4 + pkm: +0.3 % on every family; with the fast loop running to 128 bytes in front of a unit's end (kFastOutput): S +0.5 .. 0.8 %
+ROUND4_VARIANT = {"db6", "tu8", "cchk", "lctx", "hiss", "g8", "hd2", "rmov2", "ml4", "pkm"}
 DEFAULT_VARIANT = {"lgather", "hdpp", "flim", "cflag", "tuc", "vperm", "rlhoist", "bralign", "stub32", "head32", "pktl64"}
 VARIANT = set(DEFAULT_VARIANT) | NEXT_VARIANT | ROUND3_VARIANT | ROUND4_VARIANT   # (xlz_kernel.hip passes what lctx / hiss expect: XLZ_NO_LCTX / XLZ_NO_HISS for A/B builds without them)
+
+
+def ml4():
+    return "ml4" in VARIANT and g8()
 
 
 def rot():
@@ -1284,6 +1291,22 @@ def sec_packet_general():
     packet_limits(H_IS_MATCH, breg=ismatch_reg())
     hbit(H_IS_MATCH, L("match"), stage=2, breg=ismatch_reg(), hoisted=hoist0())
     # ------------------------------------------------------------- literal (decompress.go:44-175)
+    if pkm():
+        # pkm (round 4): a pending copy means that the packet before was a match, so the state is >= 7 and this literal is a
+        # MATCHED literal: the path falls straight into it; the test of the state (and the plain literal behind it) is only
+        # reached from the loop's entry, out of line -- two instructions and a taken branch less per literal after a match
+        emit("s_cmp_eq_u32 s95, 0\ns_cbranch_scc1 %s" % L("litready"))
+        finish_body()
+        literal_context()
+        emit("s_waitcnt lgkmcnt(0)")
+
+        def entry_literal():
+            label("litready")
+            emit("s_cmp_ge_u32 %%[state], 7\ns_cbranch_scc1 %s" % L("mlit"))
+            plain_literal()
+        deferred.append(entry_literal)
+        sec_matched_literal()
+        return
     if "cflag" in VARIANT:
         # `pkt` is reached from a copy (pending; prevByte unknown, so no literal blocks yet) or from the loop's
         # entry (nothing pending, blocks requested there): one flag says both
@@ -1299,6 +1322,14 @@ def sec_packet_general():
     label("litready")
     emit("s_cmp_ge_u32 %%[state], 7\ns_cbranch_scc1 %s" % L("mlit"))
     plain_literal()
+    sec_matched_literal()
+
+
+def pkm():
+    return "pkm" in VARIANT and "cflag" in VARIANT
+
+
+def sec_matched_literal():
     # ------------------------------------------------------------- matched literal (:59-114)
     # The matched half of the literal coder lives in HBM (xlz_format.h): ONE gather fetches the
     # eight probabilities the walk meets as long as the decoded bits follow matchByte (lane k =
@@ -1306,15 +1337,27 @@ def sec_packet_general():
     # bit that differs the walk carries on in the plain table (:116-165), whose blocks are
     # already in v50..v53.  s98 = levels decided in the matched table.
     label("mlit")
+    if ml4():
+        # ml4 (round 4): the per-lane shift counts are the loop constants of tree_update_rec (v19 = 8 - level, 31 in the lanes
+        # that are no level: their slot is 0; v18 = 7 - level): four instructions instead of nine
+        emit("""
+        s_xor_b32 s89, %[mb], 0x1ff
+        v_lshrrev_b32 v60, v19, s89
+        v_bfe_u32 v61, %[mb], v18, 1
+        v_lshl_or_b32 v60, v61, 8, v60
+        """)
+    else:
+        emit("""
+        v_min_u32 v55, 7, %[vlane]
+        s_xor_b32 s89, %[mb], 0x1ff
+        v_sub_u32 v60, 8, v55
+        v_lshrrev_b32 v60, v60, s89
+        v_sub_u32 v61, 7, v55
+        v_lshrrev_b32 v61, v61, %[mb]
+        v_and_b32 v61, 1, v61
+        v_lshl_or_b32 v60, v61, 8, v60
+        """)
     emit("""
-    v_min_u32 v55, 7, %[vlane]
-    s_xor_b32 s89, %[mb], 0x1ff
-    v_sub_u32 v60, 8, v55
-    v_lshrrev_b32 v60, v60, s89
-    v_sub_u32 v61, 7, v55
-    v_lshrrev_b32 v61, v61, %[mb]
-    v_and_b32 v61, 1, v61
-    v_lshl_or_b32 v60, v61, 8, v60
     MLBASE
     global_load_ushort v54, v57, %[mptr] offset:512
     s_waitcnt vmcnt(0)
@@ -1355,7 +1398,8 @@ def sec_packet_general():
         gather8(LIT_BLOCKS, dst="v33")
         emit("v_cmp_gt_u32 vcc, s98, %[vlane]\nv_cndmask_b32 v54, v33, v54, vcc")
     # lanes < s98 -> matched table (HBM; the rest to its unused slot 0), lanes s98..7 -> plain table
-    emit("v_cmp_gt_u32 vcc, s98, %[vlane]")
+    if not (ml4() and lgather() and "lit8" not in VARIANT):  # (ml4: VCC still holds it -- nothing since mlfin writes VCC)
+        emit("v_cmp_gt_u32 vcc, s98, %[vlane]")
     if lgather():
         tree_update_rec(8, "v39", store=False, issued=True, pending=2)
     else:
