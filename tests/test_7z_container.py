@@ -135,7 +135,20 @@ def test_archives_decode_as_one_batch(ctx):
         plain.append(p)
         rec, packed = lzma_folder(p, dict_size=1 << 16) if i % 3 else lzma2_folder(p, dict_byte=8)
         many.append((rec, packed, [p]))
-    assert lzma_amd.sevenzip_decode(ctx, archive(many, encoded_header=True, folder_crc=True)) == b"".join(plain)
+    big = archive(many, encoded_header=True, folder_crc=True)
+    assert lzma_amd.sevenzip_decode(ctx, big) == b"".join(plain)
+    # the same archive over three contexts (xlz_7z_decode_multi: folders dealt by compressed bytes; the encoded header is
+    # decoded on the first), plus one LZMA2 folder of many dictionary-reset units, which is dealt in slices
+    ctxs = [ctx, lzma_amd.Context(0), lzma_amd.Context(0)]
+    assert lzma_amd.sevenzip_decode_on(ctxs, big) == b"".join(plain)
+    segs = [corpus.plain("T", 5000 + k, 40_000) for k in range(24)]
+    packed = corpus.lzma2_concat(segs, dict_size=1 << 16)
+    rec = lzma2_folder(b"x", dict_byte=8)[0]      # (the coder record of an LZMA2 folder with a 64 KiB dictionary)
+    one = archive([(rec, packed, [b"".join(segs)])], folder_crc=True)
+    assert lzma_amd.sevenzip_decode_on(ctxs, one) == b"".join(segs) == lzma_amd.sevenzip_decode(ctx, one)
+    assert all(c.last_call_stats()["units"] > 0 for c in ctxs)
+    for c in ctxs[1:]:
+        c.close()
     # a wrong CRC is caught; a damaged packed stream too
     a = bytearray(archive(fo))
     hdr_at = 32 + struct.unpack("<Q", bytes(a[12:20]))[0]
