@@ -97,8 +97,9 @@ func lzma2Units(data []byte) int {
 
 // The reference's sentinels (errors.go:5-12, reader1.go:26, reader2.go:43, readcloser.go:14).
 var (
-	ErrResultError            = errors.New("result error")
-	ErrIncorrectProperties    = errors.New("incorrect LZMA properties")
+	// (the reference's own values: a reader below the break-even IS the reference's, and errors.Is must not care which side decoded)
+	ErrResultError            = ref.ErrResultError
+	ErrIncorrectProperties    = ref.ErrIncorrectProperties
 	errNeedOneReader          = errors.New("lzma: need exactly one reader")
 	errInsufficientProperties = errors.New("lzma2: not enough properties")
 	errAlreadyClosed          = errors.New("lzma: already closed")
