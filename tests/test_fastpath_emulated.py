@@ -80,7 +80,7 @@ def run_fast_loop(program, payload, lc, lp, pb, dict_size, size, expect, dpp=Tru
     m.lds[1:2 * n_probs:2] = 0x04          # every probability 1024 (state.go:79-121)
     out = bytearray(size + 1024)
     out[:base] = expect[:base]              # (base > 0: an LZMA2 unit whose dictionary epoch starts at `base`)
-    mp = bytearray(b"\x00\x04" * (256 + (0x200 << (lc + lp))))
+    mp = bytearray(b"\x00\x04" * (256 + ((0x400 if "mlv" in getattr(program, "variant", ()) else 0x200) << (lc + lp))))
     m.mem["outp"], m.mem["mptr"] = out, mp
     lane = np.arange(64, dtype=np.uint32)
     hc, hms, hm2, litnext = _head_vectors(lane, dpp)
@@ -173,7 +173,7 @@ NEXT = ("slot0", "vprev", "rmov", "nopos", "l7blk", "warel", "vreps")   # round 
                                         (("scode",), ("rlhoist", "wsb")), (("hsb",), ()), (("hsb", "scode"), ()), ((), ("lwait",)), (("dbr", "dbrs"), ()), (("pref",), ("db6",)),
                                         ((), ("db6",)), ((), ("tu8",)), ((), ("cchk",)), ((), ("lctx",)), ((), ("hiss",)),
                                         ((), ("db6", "tu8", "cchk", "lctx", "hiss", "g8", "hd2", "rmov2")), ((), ("tuc",)), ((), ("vperm",)),
-                                        ((), ("g8",)), ((), ("hd2",)), ((), ("rmov2",)), (("rot",), ()), ((), ("ml4",)), ((), ("pkm",)), ((), ("ml4", "pkm", "g8")), (("vcur",), ("hd2",)),
+                                        ((), ("g8",)), ((), ("hd2",)), ((), ("rmov2",)), (("rot",), ()), ((), ("ml4",)), ((), ("pkm",)), ((), ("ml4", "pkm", "g8")), (("mlv",), ()), (("vcur",), ("hd2",)),
                                         (("hoist0",), ("hd2",)), (("rot", "vcur", "hoist0"), ("hd2", "rmov2"))])
 def test_generator_switches_still_decode(add, remove):
     """the code paths kept in the generator as measured alternatives (profiles/r02/layout_scan.md)

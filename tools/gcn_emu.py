@@ -428,6 +428,9 @@ class Machine:
         r = s24(self.rv(o[1])) * s24(self.rv(o[2])) + self.rv(o[3]).astype(np.int64)
         self.wv(o[0], (r & M32).astype(np.uint64))
 
+    def i_v_and_or_b32(self, o, m):
+        self.wv(o[0], (self.rv(o[1]) & self.rv(o[2])) | self.rv(o[3]))
+
     def i_v_xor_b32(self, o, m):
         self._v2(o, lambda a, b: a ^ b)
 

@@ -116,6 +116,10 @@ def ml4():
     return "ml4" in VARIANT and g8()
 
 
+def mlv():
+    return "mlv" in VARIANT and ml4() and "lctx" in VARIANT
+
+
 def rot():
     """rot (round 4): the literal loop is rotated -- the literal's body lies in FRONT of the packet head that follows it, and
     the isMatch decision's branch is the loop's back edge (taken for a literal); a match falls through into the match path.
@@ -1337,7 +1341,26 @@ def sec_matched_literal():
     # bit that differs the walk carries on in the plain table (:116-165), whose blocks are
     # already in v50..v53.  s98 = levels decided in the matched table.
     label("mlit")
-    if ml4():
+    if mlv():
+        # mlv (A/B, xlz_format.h: XLZ_MLIT_VEB): cell = (slot << 1 | matchBit) for levels 0..3, and for levels 4..7 the level-4
+        # node's slot as the block number, the node's index inside that subtree and the match bit below it.  v26 = the bit that
+        # leads the index inside the subtree (0 for levels 0..3), v27 = a mask of the lanes of levels 4..7.
+        emit("""
+        s_xor_b32 s89, %[mb], 0x1ff
+        s_andn2_b32 s82, s89, 15
+        s_lshl_b32 s82, s82, 1
+        v_lshrrev_b32 v60, v19, s89
+        v_bfe_u32 v61, %[mb], v18, 1
+        v_lshl_or_b32 v60, v60, 1, v61
+        v_add_u32 v61, -1, v26
+        v_and_or_b32 v60, v60, v61, v26
+        v_and_or_b32 v60, s82, v27, v60
+        v_lshlrev_b32 v60, 1, v60
+        v_lshl_add_u32 v57, v39, 2, v60
+        global_load_ushort v54, v57, %[mptr] offset:512
+        s_waitcnt vmcnt(0)
+        """)
+    elif ml4():
         # ml4 (round 4): the per-lane shift counts are the loop constants of tree_update_rec (v19 = 8 - level, 31 in the lanes
         # that are no level: their slot is 0; v18 = 7 - level): four instructions instead of nine
         emit("""
@@ -1357,7 +1380,8 @@ def sec_matched_literal():
         v_and_b32 v61, 1, v61
         v_lshl_or_b32 v60, v61, 8, v60
         """)
-    emit("""
+    if not mlv():
+      emit("""
     MLBASE
     global_load_ushort v54, v57, %[mptr] offset:512
     s_waitcnt vmcnt(0)
@@ -1789,6 +1813,18 @@ def gen():
         emit("s_movk_i32 s85, -2017")
     if hd2():
         emit("s_movk_i32 s87, 2048\nv_mov_b32 v30, 5")
+    if mlv():
+        # lane k = level k: v26 = 1 << (k - 3) for k = 4..7, else 0; v27 = 0xffff in lanes 4..7, else 0
+        emit("""
+        v_add_u32 v26, -3, %[vlane]
+        v_lshlrev_b32 v26, v26, 1
+        v_add_u32 v27, -4, %[vlane]
+        v_cmp_gt_u32 vcc, 4, v27
+        v_mov_b32 v27, 0xffff
+        s_nop 1
+        v_cndmask_b32 v27, 0, v27, vcc
+        v_cndmask_b32 v26, 0, v26, vcc
+        """)
     if "vnorm" in VARIANT:
         emit("v_mov_b32 v17, 0x1000000")
     if "vperm" in VARIANT or "lctx" in VARIANT:
