@@ -843,7 +843,8 @@ namespace {
 // Launch `units` (already laid out against the batch's arenas) and fetch their results.  These are
 // always EXACT launches: every workgroup gets an epoch table, so copies that reach across an LZMA2
 // dictionary reset read the bytes the reference's uncleared window holds (window.go:135-140).
-int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResult> &res, bool big)
+// wide_lc_lp != 0: an HBM-model launch of its own with room for models up to that lc + lp (scratch allocated here)
+int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResult> &res, bool big, uint32_t wide_lc_lp = 0)
 {
     xlz_ctx *ctx = b->ctx;
     const size_t n = units.size();
@@ -858,6 +859,9 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
     const uint32_t grid = std::min<uint32_t>((uint32_t)n, big ? big_model_grid(ctx->num_cus)
                                                               : decode_grid(b->max_lc_lp, ctx->num_cus, (uint32_t)n));
     int st = XLZ_ERR_DEVICE;
+    uint16_t *d_wide = nullptr;
+    const uint32_t wide_stride = wide_lc_lp ? num_probs(wide_lc_lp) + num_matched_probs(wide_lc_lp) : 0;
+    if (wide_lc_lp && hipMalloc(&d_wide, (size_t)grid * wide_stride * sizeof(uint16_t)) != hipSuccess) return XLZ_ERR_DEVICE;
     if (hipMalloc(&d_units, n * sizeof(Unit)) == hipSuccess && hipMalloc(&d_order, n * sizeof(uint32_t)) == hipSuccess &&
         hipMalloc(&d_res, n * sizeof(UnitResult)) == hipSuccess &&
         hipMalloc(&d_epochs, (size_t)grid * kMaxEpochs * sizeof(Epoch)) == hipSuccess &&
@@ -873,9 +877,9 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
         p.results = d_res;
         p.queue = ctx->queue;
         p.n_units = (uint32_t)n;
-        p.max_lc_lp = big ? b->max_lc_lp_big : b->max_lc_lp;
-        p.scratch = big ? b->d_scratch : nullptr;
-        p.scratch_stride = big ? b->scratch_stride : 0;
+        p.max_lc_lp = wide_lc_lp ? wide_lc_lp : big ? b->max_lc_lp_big : b->max_lc_lp;
+        p.scratch = wide_lc_lp ? d_wide : big ? b->d_scratch : nullptr;
+        p.scratch_stride = wide_lc_lp ? wide_stride : big ? b->scratch_stride : 0;
         p.mlit = big ? nullptr : b->d_mlit;
         p.mlit_stride = big ? 0 : b->mlit_stride;
         p.order_base = 0;
@@ -889,6 +893,7 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
     if (d_order) (void)hipFree(d_order);
     if (d_res) (void)hipFree(d_res);
     if (d_epochs) (void)hipFree(d_epochs);
+    if (d_wide) (void)hipFree(d_wide);
     return st;
 }
 
@@ -1016,6 +1021,46 @@ int finish_collect(xlz_batch *b, const std::vector<size_t> &redo)
             r.status = res[k].status;
             r.out_len = res[k].out_len;
             r.in_consumed = res[k].in_consumed;
+        }
+    }
+    // The model's storage (LDS, or a workgroup's HBM slot) is sized by the host's scan of the chunk HEADERS.  A malformed stream
+    // whose real decode leaves its headers can walk into bytes that read as a chunk with larger properties than any the scan
+    // saw: the wave stops in front of that chunk with ST_ERR_UNSUPPORTED -- the reference (reader2.go:155-165) simply renews
+    // its model with whatever lc <= 8, lp <= 4 the byte says.  Such a stream is decoded once more, as ONE unit of an HBM-model
+    // launch with room for the largest model the reference accepts (found by tools/fuzz_gpu.py in round 4, seed 5501:
+    // tests/golden/fuzz_5501_18774.lzma2; sessions have had AUX_GROW for this since round 3, slices of a stream leave it
+    // to their caller).
+    {
+        std::vector<Unit> units;
+        std::vector<size_t> idx;
+        for (size_t i = 0; i < b->n; i++) {
+            const StreamPlan &pl = b->plans[i];
+            if (pl.host_status != 1 || !pl.lzma2 || pl.slice || b->final_results[i].status != XLZ_ERR_UNSUPPORTED) continue;
+            idx.push_back(i);
+            Unit u;
+            memset(&u, 0, sizeof u);
+            u.kind = UNIT_LZMA2;
+            u.in_off = pl.in_off;
+            u.in_len = pl.in_len;
+            u.out_off = pl.out_off;
+            u.out_cap = (uint32_t)pl.out_cap;
+            u.dict_size = pl.dict_size;
+            u.unpack_size = kUnknownSize;
+            u.stream = (uint32_t)i;
+            u.lc = (uint8_t)kMaxLcLp;
+            u.flags = UNIT_F_LAST | UNIT_F_BIG_MODEL;
+            units.push_back(u);
+        }
+        if (!units.empty()) {
+            std::vector<UnitResult> res;
+            int st = run_units(b, units, res, true, kMaxLcLp);
+            if (st != XLZ_OK) return st;
+            for (size_t k = 0; k < idx.size(); k++) {
+                xlz_result &r = b->final_results[idx[k]];
+                r.status = res[k].status;
+                r.out_len = res[k].out_len;
+                r.in_consumed = res[k].in_consumed;
+            }
         }
     }
     b->sum_in = b->sum_out = 0;

@@ -217,6 +217,36 @@ def _fuzz_find():
     return open(path, "rb").read(), 8192, 10671
 
 
+def _fuzz_find_wide():
+    """round 4's find (tools/fuzz_gpu.py seed 5501): a damaged stream whose real decode leaves its chunk headers and walks
+    into bytes that read as a chunk with LARGER properties than any header the host's scan saw.  The model's storage is sized
+    by that scan, so the wave stopped with "unsupported" where the reference renews its model (reader2.go:155-165) and
+    decodes on: 9481 bytes, no error.  Such a stream is now decoded once more with room for the largest model."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_5501_18774.lzma2")
+    return open(path, "rb").read(), 8192, 9481
+
+
+def walks_into_larger_props():
+    """the same on purpose: the first chunk announces ONE byte less compressed data than its payload has, so the next
+    "chunk header" the walker reads starts one byte early -- the payload's last byte as the control byte -- and what
+    follows is laid out so that this reads as a dictionary-reset chunk with lc 8 / lp 4 (props 44: a model of 6 MiB)"""
+    e = Encoder()
+    for b in b"abcabcabcabc":
+        e.literal(b)
+    pay = bytearray(e.payload())
+    pay[-1] = 0xE0                       # (range-coder flush bytes: not needed for the twelve literals)
+    first = lzma2_lzma_chunk(0xE0, 12, bytes(pay), props_byte(3, 0, 2))
+    first = first[:3] + (len(pay) - 2).to_bytes(2, "big") + first[5:]   # comp size = len - 1: one byte short
+    e2 = Encoder(lc=8, lp=4, pb=0)
+    for b in b"xyzzy":
+        e2.literal(b)
+    p2 = e2.payload()
+    # read from the payload's last byte (0xE0): unc = (0 << 16 | h1 << 8 | h2) + 1, comp, props
+    second = bytes([0, 4]) + (len(p2) - 1).to_bytes(2, "big") + bytes([props_byte(8, 4, 0)]) + p2
+    return first + second + b"\x00", 1 << 16, 100
+
+
 def crafted_lzma2_framing():
     """first LZMA chunk behind stored chunks: Reader2.lzmaReader is still nil there, so an EOF inside
     rangeDec.Init is a constructor error (reader2.go:146-153)"""
@@ -246,6 +276,14 @@ def test_crafted_streams_cpu_expectations():
             assert sum(1 for b in tail if 97 <= b <= 122) > 100, name
     for name, blob, cap in crafted_lzma1():
         oracle.lzma1_alone(blob, cap)  # must not crash; statuses are compared on the GPU
+    # a real decode that walks into a chunk the header scan jumps over (larger properties: round 4's fuzzer find)
+    blob, ds, cap = walks_into_larger_props()
+    assert oracle.lzma2_raw(blob, ds, cap) == (b"abcabcabcabcxyzzy", 0, 39)
+    import lzma_amd
+    assert [u["out_len"] for u in lzma_amd.lzma2_units(blob)] == [12]
+    blob, ds, cap = _fuzz_find_wide()
+    out, status, consumed = oracle.lzma2_raw(blob, ds, cap)
+    assert (status, len(out), consumed) == (0, 9481, 930)
 
 
 def test_random_crafted_lzma2_streams_cpu():
@@ -321,6 +359,8 @@ def test_crafted_streams_on_gpu(ctx):
     p = corpus.plain("T", 77, 50_000)
     extra = Stream(corpus.compress_raw_lzma2(p), FMT_LZMA2_RAW, out_cap=len(p), dict_size=1 << 16)
     c2.append(("fuzz find 424242/45182",) + _fuzz_find())
+    c2.append(("fuzz find 5501/18774",) + _fuzz_find_wide())
+    c2.append(("off the headers into lc 8 / lp 4",) + walks_into_larger_props())
     streams = [Stream(b, FMT_LZMA2_RAW, out_cap=cap, dict_size=ds) for _, b, ds, cap in c2]
     got = lzma_amd.decode_batch(ctx, streams + [extra])
     for (name, b, ds, cap), g in zip(c2, got):

@@ -28,7 +28,7 @@ def test_cut_chunks_and_stale_windows():
 
 
 def test_fuzzer_finds():
-    for fn, ds in (("fuzz_424242_45182.lzma2", 8192), ("fuzz_reader_11_316.lzma2", 65536)):
+    for fn, ds in (("fuzz_424242_45182.lzma2", 8192), ("fuzz_reader_11_316.lzma2", 65536), ("fuzz_5501_18774.lzma2", 8192)):
         _same(open(os.path.join(HERE, "golden", fn), "rb").read(), ds, fn)
 
 
