@@ -228,23 +228,23 @@ def _fuzz_find_wide():
 
 
 def walks_into_larger_props():
-    """the same on purpose: the first chunk announces ONE byte less compressed data than its payload has, so the next
-    "chunk header" the walker reads starts one byte early -- the payload's last byte as the control byte -- and what
-    follows is laid out so that this reads as a dictionary-reset chunk with lc 8 / lp 4 (props 44: a model of 6 MiB)"""
+    """the same on purpose.  A chunk ends when its announced output is there (decompress.go:14-20); what its header
+    announced as compressed size beyond that stays in the source, and startChunk reads the next control byte from
+    THERE (reader2.go:100-128: the limitedByteReader only caps the chunk's reads).  The first chunk here announces more
+    compressed bytes than its twelve literals need, so the host's header scan jumps over what follows -- a chunk that
+    resets the dictionary and renews the model with lc 8 / lp 4 (a model of 6 MiB) -- while the real decode walks
+    into it."""
     e = Encoder()
     for b in b"abcabcabcabc":
         e.literal(b)
-    pay = bytearray(e.payload())
-    pay[-1] = 0xE0                       # (range-coder flush bytes: not needed for the twelve literals)
-    first = lzma2_lzma_chunk(0xE0, 12, bytes(pay), props_byte(3, 0, 2))
-    first = first[:3] + (len(pay) - 2).to_bytes(2, "big") + first[5:]   # comp size = len - 1: one byte short
+    p1 = e.payload()
     e2 = Encoder(lc=8, lp=4, pb=0)
     for b in b"xyzzy":
         e2.literal(b)
-    p2 = e2.payload()
-    # read from the payload's last byte (0xE0): unc = (0 << 16 | h1 << 8 | h2) + 1, comp, props
-    second = bytes([0, 4]) + (len(p2) - 1).to_bytes(2, "big") + bytes([props_byte(8, 4, 0)]) + p2
-    return first + second + b"\x00", 1 << 16, 100
+    second = lzma2_lzma_chunk(0xE0, 5, e2.payload(), props_byte(8, 4, 0))
+    body = p1 + second
+    hdr = bytes([0xE0, 0, 11]) + (len(body) + 7 - 1).to_bytes(2, "big") + bytes([props_byte(3, 0, 2)])
+    return hdr + body + b"\x00" * 8, 1 << 16, 100
 
 
 def crafted_lzma2_framing():
