@@ -1993,14 +1993,21 @@ int session_grow_model(xlz_reader *r, uint32_t need, hipStream_t stream)
 int session_make_shadow(xlz_reader *r)
 {
     Session *ss = r->ss;
-    if (ss->d_shadow) return XLZ_OK;
-    const size_t n = ss->unit.dict_size;
-    if (hipMalloc(&ss->d_shadow, n) != hipSuccess) return XLZ_ERR_DEVICE;
+    if (!ss->d_shadow) {
+        const size_t n = ss->unit.dict_size;
+        uint8_t *img = nullptr;
+        if (hipMalloc(&img, n) != hipSuccess) return XLZ_ERR_DEVICE;
+        if (hipMemset(img, 0, n) != hipSuccess) {
+            (void)hipFree(img);
+            return XLZ_ERR_DEVICE;
+        }
+        ss->d_shadow = img;
+        r->n_shadow++;
+    }
+    // (written whenever the wave asks: a call that failed behind the allocation must not leave the wave asking for ever)
     const uint64_t addr = (uint64_t)ss->d_shadow;
-    if (hipMemset(ss->d_shadow, 0, n) != hipSuccess ||
-        hipMemcpy(ss->d_ctl + ss->off_state + (size_t)kStateShadowWord * 4, &addr, 8, hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy(ss->d_ctl + ss->off_state + (size_t)kStateShadowWord * 4, &addr, 8, hipMemcpyHostToDevice) != hipSuccess)
         return XLZ_ERR_DEVICE;
-    r->n_shadow++;
     return XLZ_OK;
 }
 
