@@ -188,8 +188,20 @@ typedef struct xlz_call_stats {
     uint32_t sub_batches;  /* > 1: the call ran as a pipeline (upload k+1 / decode k / download k-1); then
                               upload_ms = until the first sub-batch was on the device, decode_ms = first
                               launch to last results, download_ms = what was left after that            */
+    uint32_t slices;       /* > 1: a call of ONE wave round ran as a sequence of launches, each advancing every
+                              unit by a share of its output, the download of share k-1 under the decode of
+                              share k (the reference's Read pump in batch form, reader1.go:223-254); then
+                              decode_ms = the launches (HIP events), download_ms = what was left after them;
+                              slot_occupancy = the mean over the launches                                 */
+    uint32_t reserved;
 } xlz_call_stats;
 int xlz_ctx_last_call_stats(xlz_ctx *ctx, xlz_call_stats *out);
+/* Tuning of xlz_decode_batch's sliced form (xlz_call_stats.slices): a call of one wave round with at least
+ * min_call_bytes of output room runs as one launch for every slice_bytes of it, at most max_slices (<= 64).
+ * 0 = the default of that argument (256 MiB, 128 MiB, 8); max_slices = 1 turns slicing off.  The decoded
+ * bytes, statuses and consumed input do not depend on it.  The reference's counterpart is the size of the
+ * buffer its caller hands to Read (reader1.go:223-254: decompress(need) runs until `need` bytes are pending). */
+int xlz_ctx_set_slicing(xlz_ctx *ctx, uint64_t min_call_bytes, uint64_t slice_bytes, uint32_t max_slices);
 
 /* ---- device-resident batch: upload once, decode many times ---------------- */
 typedef struct xlz_batch xlz_batch;

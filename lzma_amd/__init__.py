@@ -84,6 +84,13 @@ class Context:
             raise LzmaError(st, "xlz_ctx_last_call_stats")
         return {k: getattr(cs, k) for k, _ in N.CallStats._fields_}
 
+    def set_slicing(self, min_call_bytes=0, slice_bytes=0, max_slices=0):
+        """when a decode_batch of one wave round runs as a sequence of launches whose downloads overlap the decode
+        (xlz_ctx_set_slicing; 0 = default, max_slices=1: never)"""
+        st = N.lib().xlz_ctx_set_slicing(self._h, min_call_bytes, slice_bytes, max_slices)
+        if st != OK:
+            raise LzmaError(st, "xlz_ctx_set_slicing")
+
     def event_record(self, slot):
         st = N.lib().xlz_ctx_event_record(self._h, slot)
         if st != OK:

@@ -169,10 +169,47 @@ struct LaunchParams {
     // one word per hardware wave slot of the device (kPrioTabWords): the compressed bytes the wave in
     // that slot still has to decode, 0 when idle -- the waves of a SIMD rank themselves by it (rotate_priority)
     uint32_t *prio_tab;
+    // Sliced launches (a call of ONE wave round whose download overlaps its decode, xlz_host.hip: decode_batch):
+    // launch k of a sequence advances every unit to the first packet / chunk boundary at or behind
+    // slice_bound(out_cap, slice_frac) and saves its state in the unit's state block (Unit.state; all blocks sized for
+    // max_lc_lp); launch k + 1 resumes the units that paused (results[].status == ST_PAUSED) and skips the others.  The units
+    // are batch units: whole input and output in the arenas, no requests to the host (AUX_GROW, AUX_SHADOW), copies behind a
+    // dictionary reset are flagged (AUX_STALE) and settled by the exact re-run.  Between two launches the bytes in front of the bound are final and visible
+    // (a kernel boundary), so the host downloads them while the next launch decodes: the reference's Read pump in
+    // batch form (reader1.go:223-254 drains window.pending while the decoder keeps its state, window.go:97-133).
+    uint32_t slice_frac;   // 0: not a sliced launch; else the bound of this launch in 1/65536 of out_cap (65536: run to the end)
+    uint32_t slice_k;      // index of the launch in its sequence (0: every unit starts, > 0: paused units resume)
+    uint32_t head_frac;    // slice_k == 0 only: the launch sees the first slice_head(in_len, head_frac) bytes of every unit's
+                           // input (the rest is still being uploaded) and pauses a unit that runs out of them; 0: all of it
+    uint32_t pad_;
 };
+constexpr uint32_t kSliceOne = 65536;
+// output position (relative to the unit) at which a sliced launch with this slice_frac pauses a unit of out_cap bytes
+static inline constexpr uint32_t slice_bound(uint32_t out_cap, uint32_t frac)
+{
+    return frac >= kSliceOne ? 0xFFFFFFFFu : (uint32_t)(((uint64_t)out_cap * frac) >> 16) & ~255u;
+}
+// input bytes of a unit that are on the device when the first launch of a sequence starts
+static inline constexpr uint32_t slice_head(uint32_t in_len, uint32_t frac)
+{
+    return (frac == 0 || frac >= kSliceOne) ? in_len
+           : (uint32_t)((((uint64_t)in_len * frac) >> 16) + 4096u) < in_len ? (uint32_t)(((((uint64_t)in_len * frac) >> 16) + 4096u) & ~255u) : in_len;
+}
 constexpr uint32_t kPrioTabWords = 1u << 20; // XCC_ID[3:0] : HW_ID[15:0]
 
+// One piece of a sliced batch's download: `len` bytes at `src_off` of the output arena (what one launch finished of one
+// unit) go to `pack_off` of the launch's packed image (multiples of 256 both), which ONE linear copy then takes to the host:
+// thousands of strided copies cost this stack 12 us each, a 2-D copy wants equal rows, a packed image wants neither
+// (tools/ubench/copy2d.hip, profiles/r05/copy2d.txt).
+struct SlicePiece {
+    uint64_t src_off, pack_off;
+    uint32_t len, unit;
+};
+static_assert(sizeof(SlicePiece) == 24, "SlicePiece layout is shared with the host");
+
 // implemented in xlz_kernel.hip
+int launch_gather(const SlicePiece *pieces, uint32_t n_pieces, const uint8_t *arena, uint8_t *pack, uint64_t pack_bytes, int num_cus,
+                  void *stream /* hipStream_t */);
 int launch_decode(const LaunchParams &p, int num_cus, void *stream /* hipStream_t */);
 uint32_t decode_lds_bytes(uint32_t max_lc_lp);
 uint32_t big_model_grid(int num_cus);

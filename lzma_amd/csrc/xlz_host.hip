@@ -39,6 +39,11 @@ constexpr size_t kStoredUnitBytes = 256 * 1024; // scan_lzma2: a run of stored c
                                                // per-unit work than their evener tail gives back, profiles/r03/ab_stored_unit.txt)
 constexpr size_t kArenaTailPad = 1024; // the 256-byte input window may start near a unit's end
 constexpr size_t kOutTailPad = 64;    // wave_copy stores whole 64-lane rows: scratch bytes past a unit's end
+// xlz_decode_batch, a call of one wave round: run it as a sequence of launches (slices) from this much output on, a slice
+// for every kSliceBytes of it, at most kMaxSlices (profiles/r05/slices_scan.txt)
+constexpr uint64_t kSlicedCallBytes = 256ull << 20;
+constexpr uint64_t kSliceBytes = 128ull << 20;
+constexpr uint64_t kMaxSlices = 8;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -90,6 +95,9 @@ struct xlz_ctx {
     HostPipe pipe;
     xlz_call_stats last_call = {}; // of the most recent xlz_decode_batch on this context (xlz_ctx_last_call_stats)
     bool have_last_call = false;
+    // xlz_ctx_set_slicing: when a call of one wave round runs as a sequence of launches, and as how many
+    uint64_t sliced_call_bytes = kSlicedCallBytes, slice_bytes = kSliceBytes;
+    uint32_t max_slices = kMaxSlices;
 };
 
 // per-stream bookkeeping of a batch
@@ -135,6 +143,19 @@ struct xlz_batch {
     std::vector<UnitResult> unit_results; // of the main launch (timestamps: xlz_batch_unit_trace)
     bool collected = false;
     uint64_t sum_in = 0, sum_out = 0;
+    std::vector<size_t> rewritten; // streams whose bytes a re-run of collect() wrote again (exact / widest-model launches)
+    // A SLICED batch (xlz_decode_batch, a call of one wave round: LaunchParams.slice_*): the run is a sequence of launches,
+    // launch k advances every unit to its k-th output bound; every unit has a state block; slice_ev[k] is recorded behind
+    // launch k, and the bytes in front of the k-th bounds are downloaded while launch k + 1 decodes (download_sliced).
+    std::vector<uint32_t> slice_fracs; // bound of launch k in 1/65536 of a unit's out_cap; the last one is kSliceOne
+    std::vector<hipEvent_t> slice_ev;
+    uint8_t *d_states = nullptr;
+    size_t state_stride = 0;
+    std::vector<std::vector<SlicePiece>> slice_pieces; // per launch: what it finishes of every unit, packed back to back
+    std::vector<uint64_t> slice_pack_bytes;
+    SlicePiece *d_pieces = nullptr; // all launches' tables, one after the other
+    uint8_t *d_pack = nullptr;      // the packed image of one launch's pieces (xlz_gather_kernel), downloaded linearly
+    UnitResult *pin_res = nullptr;  // pinned: the unit results behind every launch (slice_fracs.size() x units)
 };
 
 // ---------------------------------------------------------------- helpers ----
@@ -553,13 +574,27 @@ int batch_free(xlz_batch *b)
     if (b->d_mlit) (void)hipFree(b->d_mlit);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
+    for (hipEvent_t e : b->slice_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (b->d_states) (void)hipFree(b->d_states);
+    if (b->d_pieces) (void)hipFree(b->d_pieces);
+    if (b->d_pack) (void)hipFree(b->d_pack);
+    if (b->pin_res) (void)hipHostFree(b->pin_res);
     delete b;
     return XLZ_OK;
 }
 
 } // namespace
 
+static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **out, uint32_t want_slices);
+
 extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **out)
+{
+    return batch_create_ex(ctx, streams, n, out, 1);
+}
+
+// want_slices > 1: make the batch a sliced one (xlz_batch: slice_*) if every unit's model fits LDS
+static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **out, uint32_t want_slices)
 {
     if (!ctx || !out || (!streams && n)) return XLZ_ERR_BAD_ARG;
     *out = nullptr;
@@ -716,6 +751,48 @@ extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, si
         const size_t slots = (size_t)decode_grid(b->max_lc_lp, ctx->num_cus, ~0u);
         if (hipMalloc(&b->d_mlit, slots * b->mlit_stride * sizeof(uint16_t)) != hipSuccess) return fail(XLZ_ERR_DEVICE);
     }
+    if (want_slices > 1 && nu && b->n_normal == nu) {
+        // sliced batch: equal shares of every unit's output per launch; a state block per unit; per launch the table of
+        // the pieces it finishes (unit order = arena order, packed back to back on 256-byte boundaries)
+        const uint32_t K = std::min<uint32_t>(want_slices, 64);
+        for (uint32_t k = 1; k <= K; k++) b->slice_fracs.push_back(k == K ? kSliceOne : (uint32_t)((uint64_t)kSliceOne * k / K));
+        b->state_stride = align_up(state_bytes(b->max_lc_lp), kArenaAlign);
+        if (hipMalloc(&b->d_states, nu * b->state_stride) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+        for (size_t k = 0; k < nu; k++) b->units[k].state = (uint64_t)(uintptr_t)(b->d_states + k * b->state_stride);
+        b->slice_pieces.resize(K);
+        b->slice_pack_bytes.assign(K, 0);
+        size_t total_pieces = 0;
+        uint64_t max_pack = 0;
+        for (uint32_t k = 0; k < K; k++) {
+            uint64_t cursor = 0;
+            for (size_t ui = 0; ui < nu; ui++) {
+                const Unit &u = b->units[ui];
+                const uint32_t lo = k == 0 ? 0u : std::min(slice_bound(u.out_cap, b->slice_fracs[k - 1]), u.out_cap);
+                const uint32_t hi = std::min(slice_bound(u.out_cap, b->slice_fracs[k]), u.out_cap);
+                if (hi <= lo) continue;
+                b->slice_pieces[k].push_back(SlicePiece{u.out_off + lo, cursor, hi - lo, (uint32_t)ui});
+                cursor += align_up(hi - lo, kArenaAlign);
+            }
+            b->slice_pack_bytes[k] = cursor;
+            max_pack = std::max(max_pack, cursor);
+            total_pieces += b->slice_pieces[k].size();
+        }
+        b->slice_ev.assign(K, nullptr);
+        for (uint32_t k = 0; k < K; k++)
+            if (hipEventCreateWithFlags(&b->slice_ev[k], hipEventDisableTiming) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+        if (hipMalloc(&b->d_pieces, std::max<size_t>(total_pieces, 1) * sizeof(SlicePiece)) != hipSuccess ||
+            hipMalloc(&b->d_pack, (size_t)max_pack + kArenaAlign) != hipSuccess ||
+            hipHostMalloc(&b->pin_res, (size_t)K * nu * sizeof(UnitResult), hipHostMallocDefault) != hipSuccess)
+            return fail(XLZ_ERR_DEVICE);
+        size_t at = 0;
+        for (uint32_t k = 0; k < K; k++) {
+            const std::vector<SlicePiece> &pv = b->slice_pieces[k];
+            if (!pv.empty() &&
+                hipMemcpy(b->d_pieces + at, pv.data(), pv.size() * sizeof(SlicePiece), hipMemcpyHostToDevice) != hipSuccess)
+                return fail(XLZ_ERR_DEVICE);
+            at += pv.size();
+        }
+    }
     {
         // pack the payloads into the context's pinned image (several host threads), one H2D copy
         HostPipe &hp = ctx->pipe;
@@ -802,7 +879,20 @@ extern "C" int xlz_batch_run(xlz_batch *b)
         p.mlit = b->d_mlit;
         p.mlit_stride = b->mlit_stride;
         p.order_base = 0;
-        if (launch_decode(p, ctx->num_cus, ctx->stream) != 0) return XLZ_ERR_DEVICE;
+        if (b->slice_fracs.empty()) {
+            if (launch_decode(p, ctx->num_cus, ctx->stream) != 0) return XLZ_ERR_DEVICE;
+        } else { // a sequence of launches, each up to the next output bound of every unit (all queued at once)
+            for (size_t k = 0; k < b->slice_fracs.size(); k++) {
+                if (k) HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
+                p.slice_frac = b->slice_fracs[k];
+                p.slice_k = (uint32_t)k;
+                p.head_frac = 0;
+                if (launch_decode(p, ctx->num_cus, ctx->stream) != 0) return XLZ_ERR_DEVICE;
+                HIP_TRY(hipEventRecord(b->slice_ev[k], ctx->stream));
+            }
+            p.slice_frac = 0;
+            p.slice_k = 0;
+        }
     }
     if (nu > b->n_normal) { // models in HBM (lc+lp > 6)
         HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
@@ -915,6 +1005,7 @@ int collect(xlz_batch *b)
     if (!ur.empty())
         HIP_TRY(hipMemcpy(ur.data(), b->d_results, ur.size() * sizeof(UnitResult), hipMemcpyDeviceToHost));
     b->final_results.assign(b->n, xlz_result{});
+    b->rewritten.clear();
     std::vector<size_t> redo;
     fold_streams(b, 0, b->n, redo);
     return finish_collect(b, redo);
@@ -1021,6 +1112,7 @@ int finish_collect(xlz_batch *b, const std::vector<size_t> &redo)
             r.status = res[k].status;
             r.out_len = res[k].out_len;
             r.in_consumed = res[k].in_consumed;
+            b->rewritten.push_back(idx[k]);
         }
     }
     // The model's storage (LDS, or a workgroup's HBM slot) is sized by the host's scan of the chunk HEADERS.  A malformed stream
@@ -1060,9 +1152,12 @@ int finish_collect(xlz_batch *b, const std::vector<size_t> &redo)
                 r.status = res[k].status;
                 r.out_len = res[k].out_len;
                 r.in_consumed = res[k].in_consumed;
+                b->rewritten.push_back(idx[k]);
             }
         }
     }
+    std::sort(b->rewritten.begin(), b->rewritten.end());
+    b->rewritten.erase(std::unique(b->rewritten.begin(), b->rewritten.end()), b->rewritten.end());
     b->sum_in = b->sum_out = 0;
     for (size_t i = 0; i < b->n; i++) {
         const StreamPlan &pl = b->plans[i];
@@ -1156,9 +1251,8 @@ namespace {
 // at most HostPipe::kRingBytes (whole stream regions where they fit, pieces of a region where one
 // does not), each chunk is copied D2H into a slot of the pinned ring on the copy stream, and host
 // threads scatter the chunks that have arrived while the next ones are in flight.
-int download_all(xlz_batch *b, const xlz_stream_desc *streams, const xlz_result *results)
+int download_all(xlz_batch *b, const xlz_stream_desc *streams, const xlz_result *results, const std::vector<size_t> *only = nullptr)
 {
-    const size_t s0 = 0, s1 = b->n;
     xlz_ctx *ctx = b->ctx;
     HostPipe &hp = ctx->pipe;
     struct Piece {
@@ -1172,7 +1266,9 @@ int download_all(xlz_batch *b, const xlz_stream_desc *streams, const xlz_result 
         std::vector<Piece> pieces;
     };
     std::vector<Chunk> chunks;
-    for (size_t i = s0; i < s1; i++) {
+    const size_t n_take = only ? only->size() : b->n; // (`only`: ascending stream indices)
+    for (size_t t = 0; t < n_take; t++) {
+        const size_t i = only ? (*only)[t] : t;
         const StreamPlan &pl = b->plans[i];
         size_t len = (size_t)results[i].out_len;
         if (pl.host_status != 1 || len == 0) continue;
@@ -1279,6 +1375,159 @@ int download_all(xlz_batch *b, const xlz_stream_desc *streams, const xlz_result 
     return st;
 }
 
+// The download of a SLICED batch (xlz_batch: slice_*), running while the launches decode.  Behind launch k (slice_ev[k])
+// the copy stream fetches the unit results, packs the pieces the launch finished into one image (xlz_gather_kernel, next
+// to the running launch k + 1) and brings the image to the pinned ring in chunks; host threads scatter the chunks into the
+// callers' buffers, every piece clamped to what its unit had produced by then (a unit that ended early, or in an error).
+// This is the reference's Read pump in batch form: window.ReadPending drains what is there while the decoder keeps its
+// state (reader1.go:223-254, window.go:97-133).  What a later re-run writes again (collect(): malformed LZMA2 streams) is
+// fetched once more by the caller (xlz_batch::rewritten).  per_slice (optional): slot occupancy of every launch.
+int download_sliced(xlz_batch *b, const xlz_stream_desc *streams, std::vector<double> *per_slice)
+{
+    xlz_ctx *ctx = b->ctx;
+    HostPipe &hp = ctx->pipe;
+    const size_t K = b->slice_fracs.size(), nu = b->units.size();
+    struct Chunk {
+        uint32_t k;
+        uint64_t off;
+        size_t len;
+    };
+    std::vector<Chunk> chunks;
+    for (size_t k = 0; k < K; k++)
+        for (uint64_t off = 0; off < b->slice_pack_bytes[k]; off += HostPipe::kRingBytes)
+            chunks.push_back({(uint32_t)k, off, (size_t)std::min<uint64_t>(HostPipe::kRingBytes, b->slice_pack_bytes[k] - off)});
+
+    std::lock_guard<std::mutex> pl(hp.mu_out);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!hp.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&hp.copy_stream, hipStreamNonBlocking));
+    for (int r = 0; r < HostPipe::kRing; r++) {
+        if (!hp.ring[r]) HIP_TRY(hipHostMalloc(&hp.ring[r], HostPipe::kRingBytes, hipHostMallocDefault));
+        if (!hp.ring_ev[r]) HIP_TRY(hipEventCreateWithFlags(&hp.ring_ev[r], hipEventDisableTiming));
+    }
+    auto scatter = [&](const Chunk &c, const uint8_t *ring) {
+        const std::vector<SlicePiece> &pv = b->slice_pieces[c.k];
+        const UnitResult *res = b->pin_res + (size_t)c.k * nu;
+        size_t lo = 0, hi = pv.size(); // the piece the chunk starts in
+        while (hi - lo > 1) {
+            const size_t mid = (lo + hi) / 2;
+            if (pv[mid].pack_off <= c.off)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        for (size_t i = lo; i < pv.size() && pv[i].pack_off < c.off + c.len; i++) {
+            const SlicePiece &pc = pv[i];
+            const Unit &u = b->units[pc.unit];
+            const uint64_t lo_in_unit = pc.src_off - u.out_off;
+            const uint64_t got = res[pc.unit].out_len; // the unit's output behind this launch
+            const uint64_t valid = got > lo_in_unit ? std::min<uint64_t>(got - lo_in_unit, pc.len) : 0;
+            const uint64_t a = std::max<uint64_t>(pc.pack_off, c.off), e = std::min<uint64_t>(pc.pack_off + valid, c.off + c.len);
+            if (e <= a) continue;
+            uint8_t *dst = streams[u.stream].out + (u.out_off - b->plans[u.stream].out_off) + lo_in_unit + (a - pc.pack_off);
+            memcpy(dst, ring + (a - c.off), (size_t)(e - a));
+        }
+    };
+    const unsigned nworkers = std::min<unsigned>(host_threads(b->out_bytes), HostPipe::kRing);
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t issued = 0, next_claim = 0, n_done = 0;
+    std::vector<char> done(chunks.size(), 0);
+    bool failed = false;
+    auto worker = [&] {
+        (void)hipSetDevice(ctx->device);
+        for (;;) {
+            size_t j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return next_claim < issued || next_claim >= chunks.size() || failed; });
+                if (failed || next_claim >= chunks.size()) return;
+                j = next_claim++;
+            }
+            const int slot = (int)(j % HostPipe::kRing);
+            const bool ok = hipEventSynchronize(hp.ring_ev[slot]) == hipSuccess;
+            if (ok) scatter(chunks[j], hp.ring[slot]);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                done[j] = 1;
+                n_done++;
+                if (!ok) failed = true;
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nworkers; t++) th.emplace_back(worker);
+    int st = XLZ_OK;
+    size_t piece_base = 0;
+    uint32_t slice_begun = ~0u;
+    for (size_t j = 0; j <= chunks.size() && st == XLZ_OK; j++) {
+        // the launches behind the last chunk's one (and launches that finish no byte at all) still deliver their results
+        const uint32_t upto = j < chunks.size() ? chunks[j].k : (uint32_t)(K - 1);
+        while (slice_begun == ~0u || slice_begun < upto) {
+            const uint32_t k = slice_begun + 1;
+            if (hipStreamWaitEvent(hp.copy_stream, b->slice_ev[k], 0) != hipSuccess ||
+                hipMemcpyAsync(b->pin_res + (size_t)k * nu, b->d_results, nu * sizeof(UnitResult), hipMemcpyDeviceToHost,
+                               hp.copy_stream) != hipSuccess ||
+                launch_gather(b->d_pieces + piece_base, (uint32_t)b->slice_pieces[k].size(), b->d_out, b->d_pack,
+                              b->slice_pack_bytes[k], ctx->num_cus, hp.copy_stream) != 0)
+                st = XLZ_ERR_DEVICE;
+            piece_base += b->slice_pieces[k].size();
+            slice_begun = k;
+            if (st != XLZ_OK) break;
+        }
+        if (j == chunks.size() || st != XLZ_OK) break;
+        const int slot = (int)(j % HostPipe::kRing);
+        if (j >= (size_t)HostPipe::kRing) { // the slot's previous chunk must have been scattered
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return done[j - HostPipe::kRing] || failed; });
+            if (failed) break;
+        }
+        if (hipMemcpyAsync(hp.ring[slot], b->d_pack + chunks[j].off, chunks[j].len, hipMemcpyDeviceToHost, hp.copy_stream) != hipSuccess ||
+            hipEventRecord(hp.ring_ev[slot], hp.copy_stream) != hipSuccess) {
+            st = XLZ_ERR_DEVICE;
+            break;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            issued = j + 1;
+        }
+        cv.notify_all();
+    }
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (st != XLZ_OK) failed = true;
+        if (!failed) cv.wait(lk, [&] { return n_done == chunks.size() || failed; });
+        if (failed) st = XLZ_ERR_DEVICE;
+        next_claim = std::max(next_claim, chunks.size()); // release idle workers
+    }
+    cv.notify_all();
+    for (auto &x : th) x.join();
+    if (hipStreamSynchronize(hp.copy_stream) != hipSuccess) st = XLZ_ERR_DEVICE;
+    if (st == XLZ_OK && per_slice) { // slot occupancy of every launch, from the stamps of the units it ran
+        per_slice->assign(K, 0.0);
+        uint32_t slots = 0;
+        (void)xlz_batch_launch_info(b, &slots, nullptr);
+        for (size_t k = 0; k < K && slots; k++) {
+            const UnitResult *res = b->pin_res + k * nu, *prev = k ? res - nu : nullptr;
+            uint32_t t0 = 0, span = 0;
+            uint64_t busy = 0;
+            bool any = false;
+            for (size_t ui = 0; ui < nu; ui++) {
+                if (prev && prev[ui].t_end == res[ui].t_end && prev[ui].t_start == res[ui].t_start) continue; // did not run
+                if (!any || (int32_t)(res[ui].t_start - t0) < 0) t0 = res[ui].t_start;
+                any = true;
+            }
+            for (size_t ui = 0; ui < nu && any; ui++) {
+                if (prev && prev[ui].t_end == res[ui].t_end && prev[ui].t_start == res[ui].t_start) continue;
+                busy += (uint32_t)(res[ui].t_end - res[ui].t_start);
+                span = std::max(span, (uint32_t)(res[ui].t_end - t0));
+            }
+            if (span) (*per_slice)[k] = (double)busy / ((double)slots * span);
+        }
+    }
+    return st;
+}
+
 } // namespace
 
 static int decode_oversize(xlz_ctx *ctx, const xlz_stream_desc *streams, xlz_result *results, const std::vector<size_t> &idx);
@@ -1305,6 +1554,16 @@ static void launch_occupancy(xlz_batch *b, xlz_call_stats &cs)
     if (span == 0) return;
     cs.kernel_span_ms = span / 1e5; // 100 MHz ticks
     cs.slot_occupancy = (double)busy / ((double)slots * span);
+}
+
+extern "C" int xlz_ctx_set_slicing(xlz_ctx *ctx, uint64_t min_call_bytes, uint64_t slice_bytes, uint32_t max_slices)
+{
+    if (!ctx) return XLZ_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->sliced_call_bytes = min_call_bytes ? min_call_bytes : kSlicedCallBytes;
+    ctx->slice_bytes = slice_bytes ? slice_bytes : kSliceBytes;
+    ctx->max_slices = max_slices ? std::min<uint32_t>(max_slices, 64) : (uint32_t)kMaxSlices;
+    return XLZ_OK;
 }
 
 extern "C" int xlz_ctx_last_call_stats(xlz_ctx *ctx, xlz_call_stats *out)
@@ -1363,6 +1622,16 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     cs.streams = n;
     cs.sub_batches = (uint32_t)S;
 
+    // A call of ONE wave round has no second sub-batch to overlap its copies with: it runs as a sequence of launches that
+    // each advance every unit by a share of its output, and share k - 1 is downloaded while share k decodes.
+    uint32_t want_slices = 1;
+    if (S == 1) {
+        uint64_t total = 0;
+        for (size_t i = 0; i < n; i++) total += streams[i].out_cap;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        if (total >= ctx->sliced_call_bytes) want_slices = (uint32_t)std::min<uint64_t>(ctx->max_slices, total / ctx->slice_bytes);
+    }
+
     std::vector<xlz_batch *> sub(S, nullptr);
     std::mutex mu;
     std::condition_variable cv;
@@ -1378,7 +1647,7 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
                 if (abort_all) return;
             }
             xlz_batch *b = nullptr;
-            const int st = xlz_batch_create(ctx, streams + cuts[k], cuts[k + 1] - cuts[k], &b);
+            const int st = batch_create_ex(ctx, streams + cuts[k], cuts[k + 1] - cuts[k], &b, want_slices);
             if (dbg) fprintf(stderr, "xlz_decode_batch: sub-batch %zu uploaded at %.1f ms\n", k, now_ms());
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -1449,12 +1718,31 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
         cv.notify_all();
         return e;
     };
+    double sliced_kernel_ms = -1;
     if (S == 1) {
         uploader();
         st = st_up;
         if (st == XLZ_OK) st = xlz_batch_run(sub[0]);
-        if (st == XLZ_OK) st = collect_one(0);
-        if (st == XLZ_OK) downloader(), st = st_down;
+        if (st == XLZ_OK && !sub[0]->slice_fracs.empty()) {
+            // sliced: all launches are queued; download what each one finishes while the next one decodes
+            std::vector<double> occ;
+            st = download_sliced(sub[0], streams, &occ);
+            if (dbg) fprintf(stderr, "xlz_decode_batch: %zu slices downloaded at %.1f ms\n", sub[0]->slice_fracs.size(), now_ms());
+            if (st == XLZ_OK) st = collect_one(0);
+            if (st == XLZ_OK && !sub[0]->rewritten.empty()) // bytes a re-run wrote after their slices had gone out
+                st = download_all(sub[0], streams, results, &sub[0]->rewritten);
+            float ms = 0;
+            if (st == XLZ_OK && xlz_batch_last_kernel_ms(sub[0], &ms) == XLZ_OK) sliced_kernel_ms = ms;
+            cs.slices = (uint32_t)sub[0]->slice_fracs.size();
+            if (st == XLZ_OK && !occ.empty()) {
+                occ_busy = 0;
+                for (double o : occ) occ_busy += o;
+                occ_span = (double)occ.size();
+            }
+        } else {
+            if (st == XLZ_OK) st = collect_one(0);
+            if (st == XLZ_OK) downloader(), st = st_down;
+        }
     } else {
         for (size_t k = 0; k < S && st == XLZ_OK; k++) {
             {
@@ -1484,6 +1772,10 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     cs.upload_ms = t_first_up;             // until the first sub-batch was on the device
     cs.decode_ms = t_decoded - t_first_up; // first launch to the last results (uploads and downloads of the others inside)
     cs.download_ms = t_end - t_decoded;    // what was left to download when the last sub-batch had decoded
+    if (sliced_kernel_ms >= 0) {           // sliced: the launches by their HIP events, the rest of the call is copies
+        cs.decode_ms = sliced_kernel_ms;
+        cs.download_ms = std::max(0.0, t_end - t_first_up - sliced_kernel_ms);
+    }
     cs.total_ms = t_end;
     cs.slot_occupancy = occ_span > 0 ? occ_busy / occ_span : 0;
     {

@@ -1133,23 +1133,33 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
 
         const uint32_t ui = RFL(p.order[p.order_base + q]);
         const Unit *up = p.units + ui;
+        // a later launch of a sliced sequence: only the units the launch before left paused go on (the others are settled:
+        // their results stay as they are)
+        const bool slice_resume = p.slice_frac != 0 && p.slice_k != 0;
+        if (slice_resume && RFL((uint32_t)p.results[ui].status) != (uint32_t)ST_PAUSED) continue;
         Dec d;
         Walk w;
         const uint64_t in_off = rfl64(up->in_off);
         const uint64_t out_off = rfl64(up->out_off);
         const uint64_t unpack = rfl64(up->unpack_size);
         const uint64_t state_addr = rfl64(up->state);
-        const uint32_t in_len = RFL(up->in_len);
+        const uint32_t in_all = RFL(up->in_len);
         const bool lzma2 = RFL(up->kind) == UNIT_LZMA2;
-        const uint32_t flags = RFL(up->flags);
+        const bool sliced = p.slice_frac != 0; // (the host gives every unit of such a launch a state block)
+        // the first launch of a sequence may start while the tails of the inputs are still on their way (head_frac)
+        const uint32_t in_len = (sliced && p.slice_k == 0) ? slice_head(in_all, p.head_frac) : in_all;
+        const uint32_t flags = (RFL(up->flags) & ~(slice_resume ? 0u : (uint32_t)UNIT_F_RESUME)) | (slice_resume ? (uint32_t)UNIT_F_RESUME : 0u) |
+                               (in_len < in_all ? (uint32_t)UNIT_F_MORE_INPUT : 0u);
         d.out_cap = RFL(up->out_cap);
         d.dict_size = RFL(up->dict_size);
         const uint32_t lc = RFL(up->lc), lp = RFL(up->lp), pb = RFL(up->pb);
         uint8_t *__restrict__ out = p.out_arena + out_off;
         // a resumable unit keeps the matched-literal half of its model in its own state block
         uint32_t *const st = reinterpret_cast<uint32_t *>(state_addr);
+        // (the state blocks of a sliced launch are all sized for the launch's largest model, like the LDS: a chunk of a
+        //  damaged LZMA2 stream may bring larger properties than the unit's own headers announced)
         uint16_t *__restrict__ mprobs =
-            st ? reinterpret_cast<uint16_t *>(state_addr + state_mprobs_off(lc + lp)) : wg_mprobs;
+            st ? reinterpret_cast<uint16_t *>(state_addr + state_mprobs_off(sliced ? p.max_lc_lp : lc + lp)) : wg_mprobs;
         const bool resume = (flags & UNIT_F_RESUME) != 0;
 
         d.dump = reinterpret_cast<uint8_t *>(p.queue + 64);
@@ -1161,7 +1171,7 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
         d.epochs = p.epochs ? p.epochs + (size_t)blockIdx.x * kMaxEpochs : nullptr;
         d.n_epochs = 0;
         d.epoch0_clean = !lzma2 || !(flags & UNIT_F_NOT_FIRST);
-        d.pause_at = st ? RFL(up->pause_at) : 0xFFFFFFFFu;
+        d.pause_at = sliced ? slice_bound(d.out_cap, p.slice_frac) : st ? RFL(up->pause_at) : 0xFFFFFFFFu;
         d.in_margin = (!lzma2 && (flags & UNIT_F_MORE_INPUT)) ? kLzma1InputMargin : 0u;
         d.need_input = 0;
         d.in_base = resume ? RFL(up->in_skip) : 0u;
@@ -1170,10 +1180,12 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
         d.work_end = w.unit_end;
         w.last_unit = (flags & UNIT_F_LAST) != 0;
         w.more_input = lzma2 && (flags & UNIT_F_MORE_INPUT);
-        w.model_lc_lp = st ? lc + lp : 0xFFu; // only a saved state block is sized per unit (LDS: per launch)
-        w.resumable = st != nullptr;
-        d.shadow = (st && lzma2) ? reinterpret_cast<uint8_t *>(rfl64(*reinterpret_cast<const uint64_t *>(st + SV_SHADOW_LO)))
-                                 : nullptr;
+        // only a pull reader's state block is sized per unit (LDS, and the blocks of a sliced launch: per launch)
+        w.model_lc_lp = (st && !sliced) ? lc + lp : 0xFFu;
+        w.resumable = st != nullptr && !sliced; // (a unit of a sliced launch asks the host for nothing)
+        d.shadow = (st && lzma2 && !sliced)
+                       ? reinterpret_cast<uint8_t *>(rfl64(*reinterpret_cast<const uint64_t *>(st + SV_SHADOW_LO)))
+                       : nullptr;
 
         uint32_t phase = PH_NEXT;
         uint32_t aux = 0;
@@ -1344,6 +1356,50 @@ __global__ __launch_bounds__(64) void xlz_decode_kernel_hbm_model(LaunchParams p
 {
     uint16_t *slot = p.scratch + (size_t)blockIdx.x * p.scratch_stride; // model, then its matched part
     decode_units<true>(p, slot, slot + num_probs(p.max_lc_lp));
+}
+
+// Pieces of the output arena -> one packed image (xlz_format.h: SlicePiece).  A workgroup takes 16 KiB tiles of the packed
+// image: it finds the piece its tile starts in (the table is sorted by pack_off, entry 0 starts at 0) and copies what the
+// tile holds of that piece and the following ones, 16 bytes per lane (source and destination offsets are multiples of 16
+// inside a piece: both ends of a piece are multiples of 256) and the last bytes of a piece one by one.  Runs on the copy
+// stream NEXT TO the persistent decode grid (which leaves wave slots, registers and LDS free: 16 of 32 waves per CU).
+constexpr uint64_t kGatherTile = 16384;
+__global__ __launch_bounds__(256) void xlz_gather_kernel(const SlicePiece *__restrict__ pc, uint32_t n, const uint8_t *__restrict__ arena,
+                                                          uint8_t *__restrict__ pack, uint64_t pack_bytes)
+{
+    const uint64_t tiles = (pack_bytes + kGatherTile - 1) / kGatherTile;
+    for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const uint64_t t0 = t * kGatherTile, t1 = min(t0 + kGatherTile, pack_bytes);
+        uint32_t lo = 0, hi = n; // pc[lo].pack_off <= t0 < pc[hi].pack_off
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pc[mid].pack_off <= t0)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        for (uint32_t i = lo; i < n; i++) {
+            const SlicePiece q = pc[i];
+            if (q.pack_off >= t1) break;
+            const uint64_t a = max(q.pack_off, t0), e = min(q.pack_off + q.len, t1);
+            if (e <= a) continue;
+            const uint8_t *__restrict__ src = arena + q.src_off + (a - q.pack_off);
+            uint8_t *__restrict__ dst = pack + a;
+            const uint32_t nb = (uint32_t)(e - a), nv = nb >> 4;
+            for (uint32_t j = threadIdx.x; j < nv; j += 256) reinterpret_cast<uint4 *>(dst)[j] = reinterpret_cast<const uint4 *>(src)[j];
+            for (uint32_t j = (nv << 4) + threadIdx.x; j < nb; j += 256) dst[j] = src[j];
+        }
+    }
+}
+
+int launch_gather(const SlicePiece *pieces, uint32_t n_pieces, const uint8_t *arena, uint8_t *pack, uint64_t pack_bytes, int num_cus,
+                  void *stream)
+{
+    if (!n_pieces || !pack_bytes) return 0;
+    const uint64_t tiles = (pack_bytes + kGatherTile - 1) / kGatherTile;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, (uint64_t)num_cus * 4);
+    hipLaunchKernelGGL(xlz_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pieces, n_pieces, arena, pack, pack_bytes);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 uint32_t decode_lds_bytes(uint32_t max_lc_lp) { return num_probs(max_lc_lp) * 2u + 128u; }

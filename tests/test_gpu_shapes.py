@@ -125,3 +125,77 @@ def test_a_call_of_several_wave_rounds_runs_as_a_pipeline(ctx):
     assert all(res[i].status == 0 for i in range(n) if i not in bad)
     got = lzma_amd.decode_batch(ctx, [Stream(cs[0], FMT_LZMA_ALONE, out_cap=size)])
     assert got[0][0] == ps[0] and ctx.last_call_stats()["sub_batches"] == 1
+
+
+def test_a_call_of_one_wave_round_runs_in_slices(ctx):
+    """xlz_decode_batch's sliced form (xlz_call_stats.slices; forced on a small call with xlz_ctx_set_slicing): the call is
+    a sequence of launches that each advance every unit by a share of its output, and share k - 1 goes to the callers'
+    buffers while share k decodes -- the reference's Read pump in batch form (reader1.go:223-254, window.go:97-133).
+    Streams of every kind in ONE call, against the oracle on bytes, status and consumed input: all four plaintext
+    families at several sizes, known sizes without end marker, output room that is too small, streams cut short or
+    with a flipped byte, an empty one, tiny ones (shorter than a slice's 256-byte grain), LZMA2 streams of several
+    units, of stored chunks and damaged, and crafted LZMA2 streams whose copies read behind dictionary resets (settled
+    by the exact re-run AFTER their slices have gone out: those bytes are fetched again)."""
+    import random
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import lzma_craft
+    from lzma_amd import FMT_LZMA2_RAW
+    rnd = random.Random(5005)
+    jobs = []  # (Stream, oracle call)
+
+    def alone(c, cap):
+        jobs.append((Stream(c, FMT_LZMA_ALONE, out_cap=cap), lambda c=c, cap=cap: oracle.lzma1_alone(c, cap)))
+
+    def raw2(c, cap, dict_size=65536):
+        jobs.append((Stream(c, FMT_LZMA2_RAW, out_cap=cap, dict_size=dict_size),
+                     lambda c=c, cap=cap, d=dict_size: oracle.lzma2_raw(c, d, cap)))
+
+    for i in range(160):
+        size = rnd.choice([300, 5_000, 70_000, 200_000, 333_333])
+        p = corpus.plain("TMZR"[i % 4], 95_000 + i, size)
+        c = corpus.compress_alone(p, preset=0, known_size=(i % 5 == 0))
+        kind = i % 8
+        if kind == 5:
+            c = bytearray(c)
+            c[13 + (len(c) - 13) * rnd.randrange(1, 9) // 10] ^= 1 << rnd.randrange(8)
+            c = bytes(c)
+        elif kind == 6:
+            c = c[: 13 + (len(c) - 13) * rnd.randrange(1, 9) // 10]
+        alone(c, size if kind != 7 else size * rnd.randrange(1, 9) // 10)   # kind 7: not enough room
+    for i in range(12):                                                         # the a.lzma flavour
+        p = corpus.plain("T", 95_500 + i, 60_000)
+        c = corpus.alone_known_size_no_eos(p)
+        if c:
+            alone(c, len(p))
+    alone(b"", 100)
+    alone(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "a.lzma"), "rb").read(), 4096)
+    for i in range(24):                                                         # LZMA2: units, stored chunks, damage
+        segs = [corpus.plain("TRMZ"[(i + j) % 4], 96_000 + 10 * i + j, rnd.choice([40_000, 150_000, 262_144]))
+                for j in range(rnd.randrange(1, 6))]
+        c = corpus.lzma2_concat(segs, preset=0)
+        total = sum(len(s) for s in segs)
+        if i % 4 == 1:
+            c = bytearray(c)
+            c[len(c) * rnd.randrange(1, 9) // 10] ^= 0x10
+            c = bytes(c)
+        elif i % 4 == 2:
+            c = c[: len(c) * rnd.randrange(3, 9) // 10]
+        raw2(c, total if i % 6 else total - 1000)
+    for i in range(40):                                                         # copies behind dictionary resets
+        c, want = lzma_craft.random_lzma2_stream(rnd, dict_size=4096)
+        raw2(c, len(want) + 64, dict_size=4096)
+    ctx.set_slicing(1, 1 << 20, 5)
+    try:
+        got = lzma_amd.decode_batch(ctx, [j[0] for j in jobs])
+        st = ctx.last_call_stats()
+        assert st["slices"] == 5 and st["sub_batches"] == 1 and 0 < st["slot_occupancy"] <= 1.0
+        for i, (_, want) in enumerate(jobs):
+            assert got[i] == want(), i
+        # two slices, and the plain call: the same results
+        ctx.set_slicing(1, 1 << 20, 2)
+        assert lzma_amd.decode_batch(ctx, [j[0] for j in jobs]) == got and ctx.last_call_stats()["slices"] == 2
+        ctx.set_slicing(0, 0, 1)
+        assert lzma_amd.decode_batch(ctx, [j[0] for j in jobs]) == got and ctx.last_call_stats()["slices"] <= 1
+    finally:
+        ctx.set_slicing(0, 0, 0)

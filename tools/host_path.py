@@ -1,20 +1,27 @@
-"""Dev tool: host-buffers-in, host-buffers-out rate of xlz_decode_batch (the PCIe-inclusive path that a
-drop-in caller sees), next to the device-resident kernel rate.
-usage: python tools/host_path.py [family] [streams] [size] [distinct]"""
-import ctypes, hashlib, os, sys, time
+"""Dev tool (GPU box): host-buffers-in, host-buffers-out rate of xlz_decode_batch (the PCIe-inclusive path that a
+drop-in caller sees) for several settings of the sliced form (xlz_ctx_set_slicing), with the call's phase times.
+usage: python tools/host_path.py [family] [streams] [size] [distinct] [--slices 1,4,8] [--reps 4] [--preset6]
+The corpus is bench.py's (liblzma MODE_FAST / HC3) unless --preset6."""
+import hashlib, os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import corpus, lzma_amd
 from lzma_amd import _native as N
 
-fam = sys.argv[1] if len(sys.argv) > 1 else "T"
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-size = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
-nd = int(sys.argv[4]) if len(sys.argv) > 4 else min(n, 256)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+opts = sys.argv[1:]
+fam = args[0] if len(args) > 0 else "T"
+n = int(args[1]) if len(args) > 1 else 4096
+size = int(args[2]) if len(args) > 2 else 1 << 20
+nd = int(args[3]) if len(args) > 3 else min(n, 512)
+slices = [int(x) for x in opts[opts.index("--slices") + 1].split(",")] if "--slices" in opts else [1, 2, 4, 8]
+reps = int(opts[opts.index("--reps") + 1]) if "--reps" in opts else 4
+preset = 6 if "--preset6" in opts else {"mode": 1, "mf": 3, "nice_len": 32, "depth": 2}
 t0 = time.time()
-cs, hs = corpus.make_alone_batch(fam, nd, size, workers=min(os.cpu_count() or 1, 64))
-print("corpus %d distinct x %d B in %.1f s" % (nd, size, time.time() - t0), flush=True)
+cs, hs = corpus.make_alone_batch(fam, nd, size, workers=min(os.cpu_count() or 1, 64), preset=preset)
+print("corpus %d distinct x %d B in %.1f s, ratio %.3f" % (nd, size, time.time() - t0, sum(map(len, cs)) / (nd * size)), flush=True)
 ctx = lzma_amd.Context(0)
+print("library:", N.library_info(), flush=True)
 ins = [np.frombuffer(cs[i % nd], dtype=np.uint8) for i in range(n)]
 out = np.zeros((n, size), dtype=np.uint8)  # one host buffer per stream (rows), touched
 descs = (N.StreamDesc * n)()
@@ -25,15 +32,25 @@ for i in range(n):
     descs[i].out_cap = size
     descs[i].format = lzma_amd.FMT_LZMA_ALONE
 res = (N.Result * n)()
-for rep in range(4):
-    out[:] = 0
-    t0 = time.perf_counter()
-    st = N.lib().xlz_decode_batch(ctx._h, descs, n, res)
-    dt = time.perf_counter() - t0
-    assert st == 0, st
-    print("xlz_decode_batch run %d: %.1f ms -> %.2f GiB/s host to host" % (rep, dt * 1e3, n * size / dt / 2**30), flush=True)
-bad = [i for i in range(n) if res[i].status != 0 or res[i].out_len != size]
-assert not bad, bad[:5]
-for i in list(range(0, n, max(1, n // 64))) + [n - 1]:
-    assert hashlib.sha256(out[i].tobytes()).digest() == hs[i % nd], i
-print("verified sample bit-exact")
+for k in slices:
+    ctx.set_slicing(1 if k > 1 else 0, max(1, n * size // max(k, 1)), k)
+    times = []
+    for rep in range(reps + 1):
+        out[:] = 0
+        t0 = time.perf_counter()
+        st = N.lib().xlz_decode_batch(ctx._h, descs, n, res)
+        dt = time.perf_counter() - t0
+        assert st == 0, st
+        c = ctx.last_call_stats()
+        if rep:
+            times.append(dt)
+        print("  slices %2d run %d: %.1f ms = %.2f GiB/s | upload %.1f decode %.1f download %.1f ms, slices %d, sub-batches %d, "
+              "slot occupancy %.3f" % (k, rep, dt * 1e3, n * size / dt / 2**30, c["upload_ms"], c["decode_ms"], c["download_ms"],
+                                      c["slices"], c["sub_batches"], c["slot_occupancy"]), flush=True)
+    bad = [i for i in range(n) if res[i].status != 0 or res[i].out_len != size]
+    assert not bad, bad[:5]
+    for i in list(range(0, n, max(1, n // 128))) + [n - 1]:
+        assert hashlib.sha256(out[i].tobytes()).digest() == hs[i % nd], i
+    med = statistics.median(times)
+    print("slices %2d: median %.1f ms = %.2f GiB/s host to host (best %.2f), sample verified" % (
+        k, med * 1e3, n * size / med / 2**30, n * size / min(times) / 2**30), flush=True)
