@@ -40,10 +40,10 @@ import (
 )
 
 // ---- the CPU side of the break-even ------------------------------------------------------------------
-// One GPU wave decodes one unit -- an LZMA1 stream, one dictionary-reset unit of an LZMA2 stream -- about 18 times
+// One GPU wave decodes one unit -- an LZMA1 stream, one dictionary-reset unit of an LZMA2 stream -- about 16 times
 // slower than one host core decodes it (include/xlz.h: xlz_batch_advice; bench.py: stream_count_sweep), so the GPU
-// only wins when a call or a set of concurrent readers brings at least 16 units per host thread the application
-// could use instead.  libxlz.so has no CPU decoder (and must not have one: the product path fails loudly without
+// only wins when a set of concurrent LZMA1 readers brings at least 16 units per host thread the application
+// could use instead -- or when ONE LZMA2 stream is many units: on the host it is one goroutine whatever it holds.  libxlz.so has no CPU decoder (and must not have one: the product path fails loudly without
 // a device); the shim's fallback is the reference's OWN readers (reader1.go:18-24, reader2.go:26-41): below the
 // break-even the constructors return a Reader1 / Reader2 that wraps lzma.NewReader1 / lzma.NewReader2.
 //
@@ -69,30 +69,69 @@ func SetExpectedConcurrency(n int) {
 	expectedReaders.Store(int64(n))
 }
 
-// BreakEvenUnits is xlz_batch_advice's rule: 16 units per host thread.
+// BreakEvenUnits is xlz_batch_advice's break-even for EQUAL LZMA1 streams: 16 units per host thread.
 func BreakEvenUnits() int {
+	return coreOverWave * hostThreads()
+}
+
+func hostThreads() int {
 	t := HostThreads
 	if t <= 0 {
 		t = runtime.GOMAXPROCS(0)
 	}
-	return 16 * t
+	return t
 }
 
-// worthTheDevice: `units` of this reader plus one unit for each of the other readers expected in flight.
-func worthTheDevice(units int) bool {
-	return ForceGPU || units+int(expectedReaders.Load())-1 >= BreakEvenUnits()
+// coreOverWave: a host core decodes a stream this many times as fast as one wave decodes a unit; waveSlots: units an
+// MI355X decodes at once (xlz_batch_advice: kCoreOverWave, wave_slots).
+const (
+	coreOverWave = 16
+	waveSlots    = 4096
+)
+
+// worthTheDevice is xlz_batch_advice's rule for ONE reader among the readers expected in flight: two estimated times in
+// compressed bytes of serial work.  On the host this reader's stream is ONE goroutine whatever its format (reader1.go,
+// reader2.go:216-250: the units of an LZMA2 stream are parallel work for the device only), and the readers share the
+// threads; on the device every unit is a wave.  streamBytes: the stream (or the part of it at hand), maxUnit: its longest
+// unit (= streamBytes for LZMA1 and for an LZMA2 stream without inner dictionary resets).  Round 4 compared a unit COUNT
+// with 16 x threads: one LZMA2 stream of 100 units on 16 threads went to one host thread.
+func worthTheDevice(streamBytes, maxUnit int) bool {
+	if ForceGPU {
+		return true
+	}
+	e, t := float64(expectedReaders.Load()), float64(hostThreads())
+	perThread := 1.0 // readers per host thread, at least the one
+	if e > t {
+		perThread = e / t
+	}
+	cpu := float64(streamBytes) * perThread / coreOverWave
+	gpu := float64(maxUnit)
+	if all := e * float64(streamBytes) / waveSlots; all > gpu {
+		gpu = all
+	}
+	return gpu <= cpu
 }
 
-// lzma2Units counts the units the device would launch for the part of a raw LZMA2 stream at hand (xlz_lzma2_units,
-// host only): a stream written by a multi-threaded encoder is hundreds of units although it is one reader.
-func lzma2Units(data []byte) int {
+// lzma2LongestUnit is the longest unit the device would launch for the part of a raw LZMA2 stream at hand
+// (xlz_lzma2_units, host only): a stream written by a multi-threaded encoder is hundreds of units although it is one reader.
+func lzma2LongestUnit(data []byte) int {
 	p, n := cbuf(data)
 	var units C.size_t
-	if st := C.xlz_lzma2_units(p, n, nil, 0, &units); st != C.XLZ_OK {
-		return 1
+	if st := C.xlz_lzma2_units(p, n, nil, 0, &units); st != C.XLZ_OK || units == 0 {
+		return len(data)
+	}
+	plan := make([]C.xlz_lzma2_unit, int(units))
+	if st := C.xlz_lzma2_units(p, n, &plan[0], units, &units); st != C.XLZ_OK {
+		return len(data)
 	}
 	runtime.KeepAlive(data)
-	return int(units)
+	longest := 0
+	for i := range plan {
+		if l := int(plan[i].in_len); l > longest {
+			longest = l
+		}
+	}
+	return longest
 }
 
 // The reference's sentinels (errors.go:5-12, reader1.go:26, reader2.go:43, readcloser.go:14).
@@ -342,7 +381,7 @@ func cbuf(b []byte) (*C.uint8_t, C.size_t) {
 
 // NewReader1 replaces lzma.NewReader1 (reader1.go:18-24).
 func NewReader1(inStream io.ByteReader) (*Reader1, error) {
-	if !worthTheDevice(1) { // one LZMA1 stream is one unit: the reference's own reader (reader1.go:18-24), untouched source
+	if !worthTheDevice(1, 1) { // one LZMA1 stream is one unit of its own length: the reference's own reader (reader1.go:18-24), untouched source
 		cpu, err := ref.NewReader1(inStream)
 		if err != nil {
 			return nil, err
@@ -396,7 +435,7 @@ func NewReader2(inStream io.Reader, dictSize int) (*Reader2, error) {
 	}
 	// The units of the part at hand (the whole stream when it is shorter than a piece; a lower bound otherwise): one
 	// LZMA2 stream of many dictionary-reset units fills the chip by itself, one without inner resets is one wave.
-	if !worthTheDevice(lzma2Units(data)) {
+	if !worthTheDevice(len(data), lzma2LongestUnit(data)) {
 		var src io.Reader = bytes.NewReader(data)
 		if rest != nil {
 			src = io.MultiReader(src, rest)
@@ -448,14 +487,14 @@ func sevenzip(lzma2 bool, props []byte, unpackSize uint64, readers []io.ReadClos
 	if lzma2 && len(props) != 1 {
 		return nil, errInsufficientProperties // reader2.go:54-56
 	}
-	if !lzma2 && !worthTheDevice(1) { // an LZMA folder is one unit: the reference's constructor (reader1.go:32-61)
+	if !lzma2 && !worthTheDevice(1, 1) { // an LZMA folder is one unit of its own length: the reference's constructor (reader1.go:32-61)
 		return ref.NewLZMADecompressorForSevenZip(props, unpackSize, readers)
 	}
 	data, rest, err := firstPiece(readers[0])
 	if err != nil {
 		return nil, err
 	}
-	if lzma2 && !worthTheDevice(lzma2Units(data)) { // reader2.go:49-75 on what has been pulled + the rest of the source
+	if lzma2 && !worthTheDevice(len(data), lzma2LongestUnit(data)) { // reader2.go:49-75 on what has been pulled + the rest of the source
 		var src io.Reader = bytes.NewReader(data)
 		if rest != nil {
 			src = io.MultiReader(src, rest)

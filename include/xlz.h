@@ -150,21 +150,31 @@ int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz
 
 /* BEFORE uploading anything: how much of a GPU would this call fill, and is the host the faster
  * decoder for it?  Host only (reads stream and LZMA2 chunk headers; no device needed; `ctx` may be
- * NULL: an MI355X's 4096 wave slots are assumed).  One wave decodes one unit -- an LZMA1 stream, or
- * one unit of an LZMA2 stream's plan (xlz_lzma2_units) -- about 18 times slower than one host core
- * decodes it with the reference's algorithm (4-6 MB/s against 65-80), so the GPU wins from about
- * 16 units per host thread the caller could use instead (bench.py: stream_count_sweep; 256 units
- * for 16 threads).  `host_threads` = 0: the hardware concurrency of this machine.  The library has
- * no CPU decoder: a caller that is told prefer_cpu = 1 decodes with the reference's own readers
- * (reader1.go:18-24, reader2.go:26-41; the Go shim does that by itself) or gathers more streams. */
+ * NULL: an MI355X's 4096 wave slots are assumed).  Two estimated times are compared, in compressed
+ * bytes of serial work (decode time tracks them):
+ *   GPU: one wave decodes one unit -- an LZMA1 stream, or one unit of an LZMA2 stream's plan
+ *        (xlz_lzma2_units) -- and `wave_slots` units run at once:
+ *        gpu_cost = max(largest unit, all bytes / wave_slots);
+ *   CPU: a host core decodes about 16 times as fast as a wave (65-80 MB/s of output against 4-6), but
+ *        ONE stream is ONE thread whatever its format -- the reference's Reader2 is one goroutine
+ *        (reader2.go:216-250), the units of an LZMA2 stream are parallel work for the GPU only:
+ *        cpu_cost = max(largest stream, all bytes / host_threads) / 16.
+ * prefer_cpu = cpu_cost < gpu_cost.  For equal LZMA1 streams that is "fewer than 16 units per host
+ * thread" (break_even_units; bench.py: stream_count_sweep, 256 units for 16 threads); one LZMA2 stream
+ * of 100 units is the GPU's job on any host, 64 big LZMA1 streams are the host's.  `host_threads` = 0:
+ * the hardware concurrency of this machine.  The library has no CPU decoder: a caller that is told
+ * prefer_cpu = 1 decodes with the reference's own readers (reader1.go:18-24, reader2.go:26-41; the Go
+ * shim does that by itself) or gathers more streams. */
 typedef struct xlz_advice {
     uint64_t units;            /* independent work units the call would launch                    */
     uint64_t in_bytes;         /* compressed bytes of all streams                                  */
     uint32_t wave_slots;       /* units a GPU decodes at once (resident single-wave workgroups)    */
-    uint32_t break_even_units; /* 16 x host_threads                                                */
+    uint32_t break_even_units; /* 16 x host_threads: the break-even for EQUAL LZMA1 streams         */
     double   fill;             /* min(1, units / wave_slots): the share of the chip the call uses  */
-    int32_t  prefer_cpu;       /* 1: units < break_even_units                                      */
+    int32_t  prefer_cpu;       /* 1: cpu_cost < gpu_cost (or nothing to decode)                    */
     uint32_t reserved;
+    double   cpu_cost;         /* estimated serial work per host thread, in wave-equivalent bytes  */
+    double   gpu_cost;         /* estimated serial work per wave slot, in compressed bytes         */
 } xlz_advice;
 int xlz_batch_advice(const xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, uint32_t host_threads,
                      xlz_advice *out);

@@ -124,6 +124,8 @@ class Advice(ctypes.Structure):
         ("fill", ctypes.c_double),
         ("prefer_cpu", ctypes.c_int32),
         ("reserved", ctypes.c_uint32),
+        ("cpu_cost", ctypes.c_double),
+        ("gpu_cost", ctypes.c_double),
     ]
 
 

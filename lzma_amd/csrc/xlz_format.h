@@ -189,16 +189,20 @@ static inline constexpr uint32_t slice_bound(uint32_t out_cap, uint32_t frac)
 {
     return frac >= kSliceOne ? 0xFFFFFFFFu : (uint32_t)(((uint64_t)out_cap * frac) >> 16) & ~255u;
 }
-// input bytes of a unit that are on the device when the first launch of a sequence starts
-static inline constexpr uint32_t slice_head(uint32_t in_len, uint32_t frac)
+// input bytes of a unit that are on the device when the first launch of a sequence starts: its share + 4 KiB; an LZMA2
+// unit + 72 KiB (its wave wants a whole chunk -- 6 bytes of header, 64 KiB of payload -- in front of it before it starts one:
+// a small unit would only pause); a multiple of 256, or everything
+static inline constexpr uint32_t slice_head(uint32_t in_len, uint32_t frac, bool lzma2)
 {
-    return (frac == 0 || frac >= kSliceOne) ? in_len
-           : (uint32_t)((((uint64_t)in_len * frac) >> 16) + 4096u) < in_len ? (uint32_t)(((((uint64_t)in_len * frac) >> 16) + 4096u) & ~255u) : in_len;
+    if (frac == 0 || frac >= kSliceOne) return in_len;
+    const uint64_t h = ((((uint64_t)in_len * frac) >> 16) + (lzma2 ? 73728u : 4096u)) & ~(uint64_t)255;
+    return h < in_len ? (uint32_t)h : in_len;
 }
+
 constexpr uint32_t kPrioTabWords = 1u << 20; // XCC_ID[3:0] : HW_ID[15:0]
 
 // One piece of a sliced batch's download: `len` bytes at `src_off` of the output arena (what one launch finished of one
-// unit) go to `pack_off` of the launch's packed image (multiples of 256 both), which ONE linear copy then takes to the host:
+// unit) go to `pack_off` of the launch's packed image (equal modulo 256), which ONE linear copy then takes to the host:
 // thousands of strided copies cost this stack 12 us each, a 2-D copy wants equal rows, a packed image wants neither
 // (tools/ubench/copy2d.hip, profiles/r05/copy2d.txt).
 struct SlicePiece {
@@ -208,8 +212,9 @@ struct SlicePiece {
 static_assert(sizeof(SlicePiece) == 24, "SlicePiece layout is shared with the host");
 
 // implemented in xlz_kernel.hip
-int launch_gather(const SlicePiece *pieces, uint32_t n_pieces, const uint8_t *arena, uint8_t *pack, uint64_t pack_bytes, int num_cus,
-                  void *stream /* hipStream_t */);
+// scatter = false: arena -> packed image (download); true: packed image -> arena (the upload's heads / tails)
+int launch_gather(const SlicePiece *pieces, uint32_t n_pieces, uint8_t *arena, uint8_t *pack, uint64_t pack_bytes, int num_cus,
+                  void *stream /* hipStream_t */, bool scatter = false);
 int launch_decode(const LaunchParams &p, int num_cus, void *stream /* hipStream_t */);
 uint32_t decode_lds_bytes(uint32_t max_lc_lp);
 uint32_t big_model_grid(int num_cus);

@@ -15,6 +15,8 @@
 #include <condition_variable>
 #include <cstdio>
 #include <deque>
+#include <functional>
+#include <memory>
 #include <thread>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +46,13 @@ constexpr size_t kOutTailPad = 64;    // wave_copy stores whole 64-lane rows: sc
 constexpr uint64_t kSlicedCallBytes = 256ull << 20;
 constexpr uint64_t kSliceBytes = 128ull << 20;
 constexpr uint64_t kMaxSlices = 8;
+// ... and its first launch starts when 1.5 x the first slice's share of the output (+ 4 KiB, xlz_format.h: slice_head) is
+// there of every unit's INPUT -- a stream's first bytes compress worst; a unit that runs out of input pauses and goes on
+// with the second launch
+// xlz_batch_advice: a host core decodes a stream this many times as fast as one wave decodes a unit (65-80 MB/s of output
+// against 4-6: bench.py's stream_count_sweep puts the break-even of equal LZMA1 streams at 256 units per 16 threads)
+constexpr uint32_t kCoreOverWave = 16;
+static inline uint32_t head_frac_for(uint32_t slices) { return slices >= 2 ? (uint32_t)(65536ull * 3 / (2 * slices)) : 0; }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -73,7 +82,9 @@ constexpr int kEventSlots = 64; // xlz_ctx_event_record: enough for one event pe
 struct HostPipe {
     static constexpr int kRing = 4;
     static constexpr size_t kRingBytes = 64u << 20;
-    std::mutex mu_in;  // the pinned input image: one pack + upload at a time per context
+    std::mutex mu_in;  // the pinned input image: one pack + upload at a time per context (PinLease)
+    std::condition_variable cv_in;
+    bool in_busy = false;
     std::mutex mu_out; // the pinned output ring: one download at a time per context
     uint8_t *pin_in = nullptr;
     size_t pin_in_cap = 0;
@@ -81,6 +92,33 @@ struct HostPipe {
     hipEvent_t ring_ev[kRing] = {};
     hipStream_t copy_stream = nullptr;
     hipStream_t up_stream = nullptr; // H2D of the pinned input image, piece by piece while the rest is still being packed
+};
+
+// The pinned input image is taken for one pack + upload; a sliced batch keeps it until the tails of its inputs have left it
+// (they are uploaded while the first launch decodes), which may be on another thread than the one that took it.
+struct PinLease {
+    HostPipe *hp = nullptr;
+    void take(HostPipe &h)
+    {
+        std::unique_lock<std::mutex> lk(h.mu_in);
+        h.cv_in.wait(lk, [&] { return !h.in_busy; });
+        h.in_busy = true;
+        hp = &h;
+    }
+    void release()
+    {
+        if (!hp) return;
+        {
+            std::lock_guard<std::mutex> lk(hp->mu_in);
+            hp->in_busy = false;
+        }
+        hp->cv_in.notify_one();
+        hp = nullptr;
+    }
+    PinLease() = default;
+    PinLease(const PinLease &) = delete;
+    PinLease &operator=(const PinLease &) = delete;
+    ~PinLease() { release(); }
 };
 
 struct xlz_ctx {
@@ -156,6 +194,15 @@ struct xlz_batch {
     SlicePiece *d_pieces = nullptr; // all launches' tables, one after the other
     uint8_t *d_pack = nullptr;      // the packed image of one launch's pieces (xlz_gather_kernel), downloaded linearly
     UnitResult *pin_res = nullptr;  // pinned: the unit results behind every launch (slice_fracs.size() x units)
+    // heads first: the first launch starts when the first head_frac / 65536 (+ 4 KiB) of every unit's input is on the
+    // device (LaunchParams.head_frac); the tails follow while it decodes.  The pinned image and the device staging range
+    // are packed heads | tails; a scatter kernel puts each part into the input arena.
+    uint32_t head_frac = 0;
+    uint8_t *d_stage = nullptr;
+    SlicePiece *d_up_pieces = nullptr;
+    hipEvent_t ev_heads = nullptr, ev_tails = nullptr;
+    std::function<int()> upload_tails; // pending second half of the upload, run by xlz_batch_run behind the first launch
+    PinLease in_lease;
 };
 
 // ---------------------------------------------------------------- helpers ----
@@ -535,27 +582,41 @@ extern "C" int xlz_batch_advice(const xlz_ctx *ctx, const xlz_stream_desc *strea
 {
     if (!out || (!streams && n)) return XLZ_ERR_BAD_ARG;
     memset(out, 0, sizeof *out);
+    // work is counted in compressed bytes (decode time tracks the number of binary decisions, which tracks them: the key
+    // of the kernel's own work queue)
+    uint64_t max_unit = 0, max_stream = 0;
     for (size_t i = 0; i < n; i++) {
         const xlz_stream_desc &s = streams[i];
         if (!s.in && s.in_len) return XLZ_ERR_BAD_ARG;
         out->in_bytes += s.in_len;
+        size_t units = 0;
         if (s.format == XLZ_FMT_LZMA2_RAW) { // the plan a decode would launch: units between dictionary resets
             std::vector<Lz2Unit> lu;
             uint32_t mx = 0;
             scan_lzma2(s.in, s.in_len, lu, mx);
-            out->units += lu.size();
+            units = lu.size();
+            for (const Lz2Unit &u : lu) max_unit = std::max<uint64_t>(max_unit, u.in_len);
         } else if (s.format == XLZ_FMT_LZMA_ALONE) {
-            out->units += s.in_len > 13 ? 1 : 0; // (a header alone is settled on the host)
+            units = s.in_len > 13 ? 1 : 0; // (a header alone is settled on the host)
+            if (units) max_unit = std::max<uint64_t>(max_unit, s.in_len);
         } else {
-            out->units += s.in_len ? 1 : 0;
+            units = s.in_len ? 1 : 0;
+            if (units) max_unit = std::max<uint64_t>(max_unit, s.in_len);
         }
+        out->units += units;
+        if (units) max_stream = std::max<uint64_t>(max_stream, s.in_len);
     }
     const uint32_t cus = ctx ? (uint32_t)ctx->num_cus : 256u;
     out->wave_slots = cus * 16u;
     if (!host_threads) host_threads = std::max(1u, std::thread::hardware_concurrency());
-    out->break_even_units = 16u * host_threads;
+    out->break_even_units = kCoreOverWave * host_threads;
     out->fill = out->wave_slots ? std::min(1.0, (double)out->units / out->wave_slots) : 0.0;
-    out->prefer_cpu = out->units < out->break_even_units ? 1 : 0;
+    // The host decodes ONE stream on ONE thread whatever its format (a Reader2 is one goroutine, reader2.go:216-250: the
+    // units of an LZMA2 stream are parallel work for the GPU only), kCoreOverWave times as fast as a wave decodes a unit;
+    // both sides are list-scheduled: the longest piece of serial work, or the whole call over the workers
+    out->cpu_cost = (double)std::max<uint64_t>(max_stream, (out->in_bytes + host_threads - 1) / host_threads) / kCoreOverWave;
+    out->gpu_cost = (double)std::max<uint64_t>(max_unit, out->wave_slots ? (out->in_bytes + out->wave_slots - 1) / out->wave_slots : 0);
+    out->prefer_cpu = (out->units == 0 || out->cpu_cost < out->gpu_cost) ? 1 : 0;
     return XLZ_OK;
 }
 
@@ -576,6 +637,11 @@ int batch_free(xlz_batch *b)
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     for (hipEvent_t e : b->slice_ev)
         if (e) (void)hipEventDestroy(e);
+    if (b->d_stage) (void)hipFree(b->d_stage); // (hipFree waits for the device: a pending upload has left the pinned image)
+    if (b->d_up_pieces) (void)hipFree(b->d_up_pieces);
+    if (b->ev_heads) (void)hipEventDestroy(b->ev_heads);
+    if (b->ev_tails) (void)hipEventDestroy(b->ev_tails);
+    b->in_lease.release();
     if (b->d_states) (void)hipFree(b->d_states);
     if (b->d_pieces) (void)hipFree(b->d_pieces);
     if (b->d_pack) (void)hipFree(b->d_pack);
@@ -586,15 +652,19 @@ int batch_free(xlz_batch *b)
 
 } // namespace
 
-static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **out, uint32_t want_slices);
+static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **out, uint32_t want_slices,
+                           uint32_t head_frac);
 
 extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **out)
 {
-    return batch_create_ex(ctx, streams, n, out, 1);
+    return batch_create_ex(ctx, streams, n, out, 1, 0);
 }
 
-// want_slices > 1: make the batch a sliced one (xlz_batch: slice_*) if every unit's model fits LDS
-static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **out, uint32_t want_slices)
+// want_slices > 1: make the batch a sliced one (xlz_batch: slice_*) if every unit's model fits LDS; head_frac != 0: such a
+// batch's first launch may start when that share (in 1/65536, + 4 KiB) of every unit's input is on the device -- the rest
+// is uploaded by xlz_batch_run behind the first launch, and `streams` must stay valid until then
+static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **out, uint32_t want_slices,
+                           uint32_t head_frac)
 {
     if (!ctx || !out || (!streams && n)) return XLZ_ERR_BAD_ARG;
     *out = nullptr;
@@ -611,7 +681,8 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
     b->plans.resize(n);
 
     // ---- plan: parse headers, lay out the arenas -------------------------
-    std::vector<size_t> unit_src_off; // where each unit's payload starts in its stream
+    auto unit_src_off_p = std::make_shared<std::vector<size_t>>(); // where each unit's payload starts in its stream
+    std::vector<size_t> &unit_src_off = *unit_src_off_p;
     size_t in_cursor = 0, out_cursor = 0;
     for (size_t i = 0; i < n; i++) {
         const xlz_stream_desc &s = streams[i];
@@ -770,8 +841,11 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
                 const uint32_t lo = k == 0 ? 0u : std::min(slice_bound(u.out_cap, b->slice_fracs[k - 1]), u.out_cap);
                 const uint32_t hi = std::min(slice_bound(u.out_cap, b->slice_fracs[k]), u.out_cap);
                 if (hi <= lo) continue;
-                b->slice_pieces[k].push_back(SlicePiece{u.out_off + lo, cursor, hi - lo, (uint32_t)ui});
-                cursor += align_up(hi - lo, kArenaAlign);
+                // (a piece sits in the packed image at its source's offset modulo 256: both ends of a 16-byte access are
+                //  aligned or neither is -- the units of an LZMA2 stream begin at any byte)
+                const uint64_t po = align_up(cursor, kArenaAlign) + ((u.out_off + lo) & (kArenaAlign - 1));
+                b->slice_pieces[k].push_back(SlicePiece{u.out_off + lo, po, hi - lo, (uint32_t)ui});
+                cursor = po + (hi - lo);
             }
             b->slice_pack_bytes[k] = cursor;
             max_pack = std::max(max_pack, cursor);
@@ -793,10 +867,92 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
             at += pv.size();
         }
     }
-    {
+    if (!b->slice_fracs.empty() && head_frac && head_frac < kSliceOne) {
+        // heads first (xlz_batch: head_frac): pinned image and device staging hold heads | tails, each packed; a scatter
+        // kernel puts a part into the input arena when its bytes have arrived; the tails' half runs behind the first launch
+        HostPipe &hp = ctx->pipe;
+        b->head_frac = head_frac;
+        auto heads = std::make_shared<std::vector<SlicePiece>>(), tails = std::make_shared<std::vector<SlicePiece>>();
+        uint64_t A = 0, B = 0;
+        auto place = [](std::vector<SlicePiece> &v, uint64_t &cur, uint64_t src, uint32_t len, uint32_t ui) {
+            if (!len) return;
+            const uint64_t po = align_up(cur, kArenaAlign) + (src & (kArenaAlign - 1));
+            v.push_back(SlicePiece{src, po, len, ui});
+            cur = po + len;
+        };
+        for (size_t ui = 0; ui < nu; ui++) {
+            const Unit &u = b->units[ui];
+            const uint32_t h = slice_head(u.in_len, head_frac, u.kind == UNIT_LZMA2);
+            place(*heads, A, u.in_off, h, (uint32_t)ui);
+            place(*tails, B, u.in_off + h, u.in_len - h, (uint32_t)ui);
+        }
+        A = align_up(A, kArenaAlign);
+        B = align_up(B, kArenaAlign);
+        if (hipMalloc(&b->d_stage, A + B + kArenaAlign) != hipSuccess ||
+            hipMalloc(&b->d_up_pieces, std::max<size_t>(heads->size() + tails->size(), 1) * sizeof(SlicePiece)) != hipSuccess ||
+            hipEventCreateWithFlags(&b->ev_heads, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&b->ev_tails, hipEventDisableTiming) != hipSuccess)
+            return fail(XLZ_ERR_DEVICE);
+        if ((!heads->empty() && hipMemcpy(b->d_up_pieces, heads->data(), heads->size() * sizeof(SlicePiece), hipMemcpyHostToDevice) != hipSuccess) ||
+            (!tails->empty() && hipMemcpy(b->d_up_pieces + heads->size(), tails->data(), tails->size() * sizeof(SlicePiece),
+                                          hipMemcpyHostToDevice) != hipSuccess))
+            return fail(XLZ_ERR_DEVICE);
+        b->in_lease.take(hp);
+        if (hp.pin_in_cap < A + B) {
+            if (hp.pin_in) (void)hipHostFree(hp.pin_in);
+            hp.pin_in = nullptr;
+            hp.pin_in_cap = 0;
+            const size_t want = (size_t)(A + B) + (size_t)(A + B) / 4 + (1u << 20);
+            if (hipHostMalloc(&hp.pin_in, want, hipHostMallocDefault) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+            hp.pin_in_cap = want;
+        }
+        if (!hp.up_stream && hipStreamCreateWithFlags(&hp.up_stream, hipStreamNonBlocking) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+        // one part of the upload: pack its pieces into the pinned image (several host threads, each a contiguous run of the
+        // pieces, ~16 MiB to the device at a time while the packing goes on), then scatter the part into the arena
+        auto upload_part = [b, ctx, streams, unit_src_off_p](const std::vector<SlicePiece> &pv, size_t table_at, uint64_t zone,
+                                                             uint64_t zone_bytes, hipEvent_t done) -> int {
+            HostPipe &hp = ctx->pipe;
+            uint8_t *stage = hp.pin_in + zone;
+            const unsigned nth = host_threads((size_t)zone_bytes);
+            std::atomic<bool> copy_failed{false};
+            const size_t np = pv.size();
+            auto pack = [&](unsigned t) {
+                (void)hipSetDevice(ctx->device);
+                const size_t k0 = np * t / nth, k1 = np * (t + 1) / nth;
+                if (k0 >= k1) return;
+                uint64_t sent = pv[k0].pack_off;
+                auto flush_to = [&](uint64_t end) {
+                    if (end > sent && hipMemcpyAsync(b->d_stage + zone + sent, stage + sent, (size_t)(end - sent), hipMemcpyHostToDevice,
+                                                     hp.up_stream) != hipSuccess)
+                        copy_failed = true;
+                    sent = end;
+                };
+                for (size_t k = k0; k < k1; k++) {
+                    const SlicePiece &pc = pv[k];
+                    const Unit &u = b->units[pc.unit];
+                    memcpy(stage + pc.pack_off, streams[u.stream].in + (*unit_src_off_p)[pc.unit] + (pc.src_off - u.in_off), pc.len);
+                    if (pc.pack_off + pc.len - sent >= (16u << 20)) flush_to(pc.pack_off + pc.len);
+                }
+                flush_to(pv[k1 - 1].pack_off + pv[k1 - 1].len);
+            };
+            run_threads(nth, pack);
+            if (copy_failed) return XLZ_ERR_DEVICE;
+            if (launch_gather(b->d_up_pieces + table_at, (uint32_t)np, b->d_in, b->d_stage + zone, zone_bytes, ctx->num_cus, hp.up_stream,
+                              true) != 0)
+                return XLZ_ERR_DEVICE;
+            return hipEventRecord(done, hp.up_stream) == hipSuccess ? XLZ_OK : XLZ_ERR_DEVICE;
+        };
+        // (the arena's padding reads as zeros: the decoder's input window may run into it)
+        if (hipMemsetAsync(b->d_in, 0, b->in_bytes, hp.up_stream) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+        const int st_heads = upload_part(*heads, 0, 0, A, b->ev_heads);
+        if (st_heads != XLZ_OK) return fail(st_heads);
+        const size_t n_heads = heads->size();
+        b->upload_tails = [upload_part, tails, n_heads, A, B, b]() { return upload_part(*tails, n_heads, A, B, b->ev_tails); };
+    } else {
         // pack the payloads into the context's pinned image (several host threads), one H2D copy
         HostPipe &hp = ctx->pipe;
-        std::lock_guard<std::mutex> pl(hp.mu_in);
+        PinLease lease;
+        lease.take(hp);
         if (hp.pin_in_cap < b->in_bytes) {
             if (hp.pin_in) (void)hipHostFree(hp.pin_in);
             hp.pin_in = nullptr;
@@ -884,14 +1040,27 @@ extern "C" int xlz_batch_run(xlz_batch *b)
         } else { // a sequence of launches, each up to the next output bound of every unit (all queued at once)
             for (size_t k = 0; k < b->slice_fracs.size(); k++) {
                 if (k) HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
+                if (k == 0 && b->upload_tails) HIP_TRY(hipStreamWaitEvent(ctx->stream, b->ev_heads, 0)); // the heads are on their way
+                if (k == 1 && b->upload_tails) { // the first launch is queued: now pack and upload the rest of the inputs
+                    const int st = b->upload_tails();
+                    b->upload_tails = nullptr;
+                    if (st != XLZ_OK) return st;
+                    HIP_TRY(hipStreamWaitEvent(ctx->stream, b->ev_tails, 0));
+                }
                 p.slice_frac = b->slice_fracs[k];
                 p.slice_k = (uint32_t)k;
-                p.head_frac = 0;
+                p.head_frac = k == 0 ? b->head_frac : 0;
                 if (launch_decode(p, ctx->num_cus, ctx->stream) != 0) return XLZ_ERR_DEVICE;
                 HIP_TRY(hipEventRecord(b->slice_ev[k], ctx->stream));
             }
             p.slice_frac = 0;
             p.slice_k = 0;
+            p.head_frac = 0;
+            if (b->head_frac) { // the pinned image is free again when the tails have left it
+                HIP_TRY(hipEventSynchronize(b->ev_tails));
+                b->in_lease.release();
+                b->head_frac = 0; // (a second run of the batch finds all input in the arena)
+            }
         }
     }
     if (nu > b->n_normal) { // models in HBM (lc+lp > 6)
@@ -1381,8 +1550,10 @@ int download_all(xlz_batch *b, const xlz_stream_desc *streams, const xlz_result 
 // callers' buffers, every piece clamped to what its unit had produced by then (a unit that ended early, or in an error).
 // This is the reference's Read pump in batch form: window.ReadPending drains what is there while the decoder keeps its
 // state (reader1.go:223-254, window.go:97-133).  What a later re-run writes again (collect(): malformed LZMA2 streams) is
-// fetched once more by the caller (xlz_batch::rewritten).  per_slice (optional): slot occupancy of every launch.
-int download_sliced(xlz_batch *b, const xlz_stream_desc *streams, std::vector<double> *per_slice)
+// fetched once more by the caller (xlz_batch::rewritten), and so are the streams in `gaps`: a unit of theirs fell short of
+// a launch's bound (its head ran out in the first launch, xlz_batch: head_frac) and produced the bytes up to it only
+// later, when that bound's pieces had gone out.  per_slice (optional): slot occupancy of every launch.
+int download_sliced(xlz_batch *b, const xlz_stream_desc *streams, std::vector<double> *per_slice, std::vector<size_t> &gaps)
 {
     xlz_ctx *ctx = b->ctx;
     HostPipe &hp = ctx->pipe;
@@ -1503,6 +1674,18 @@ int download_sliced(xlz_batch *b, const xlz_stream_desc *streams, std::vector<do
     cv.notify_all();
     for (auto &x : th) x.join();
     if (hipStreamSynchronize(hp.copy_stream) != hipSuccess) st = XLZ_ERR_DEVICE;
+    gaps.clear();
+    for (size_t ui = 0; ui < nu && st == XLZ_OK && K > 1; ui++) {
+        const Unit &u = b->units[ui];
+        const uint64_t fin = b->pin_res[(K - 1) * nu + ui].out_len;
+        for (size_t k = 0; k + 1 < K; k++) {
+            const uint64_t hi = std::min(slice_bound(u.out_cap, b->slice_fracs[k]), u.out_cap);
+            if (b->pin_res[k * nu + ui].out_len < std::min<uint64_t>(hi, fin)) {
+                if (gaps.empty() || gaps.back() != u.stream) gaps.push_back(u.stream); // (units are in stream order)
+                break;
+            }
+        }
+    }
     if (st == XLZ_OK && per_slice) { // slot occupancy of every launch, from the stamps of the units it ran
         per_slice->assign(K, 0.0);
         uint32_t slots = 0;
@@ -1647,7 +1830,7 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
                 if (abort_all) return;
             }
             xlz_batch *b = nullptr;
-            const int st = batch_create_ex(ctx, streams + cuts[k], cuts[k + 1] - cuts[k], &b, want_slices);
+            const int st = batch_create_ex(ctx, streams + cuts[k], cuts[k + 1] - cuts[k], &b, want_slices, head_frac_for(want_slices));
             if (dbg) fprintf(stderr, "xlz_decode_batch: sub-batch %zu uploaded at %.1f ms\n", k, now_ms());
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -1726,11 +1909,18 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
         if (st == XLZ_OK && !sub[0]->slice_fracs.empty()) {
             // sliced: all launches are queued; download what each one finishes while the next one decodes
             std::vector<double> occ;
-            st = download_sliced(sub[0], streams, &occ);
-            if (dbg) fprintf(stderr, "xlz_decode_batch: %zu slices downloaded at %.1f ms\n", sub[0]->slice_fracs.size(), now_ms());
+            std::vector<size_t> again; // streams to fetch once more: units that fell short of a bound, ...
+            st = download_sliced(sub[0], streams, &occ, again);
+            if (dbg)
+                fprintf(stderr, "xlz_decode_batch: %zu slices downloaded at %.1f ms, %zu streams with gaps\n", sub[0]->slice_fracs.size(),
+                        now_ms(), again.size());
             if (st == XLZ_OK) st = collect_one(0);
-            if (st == XLZ_OK && !sub[0]->rewritten.empty()) // bytes a re-run wrote after their slices had gone out
-                st = download_all(sub[0], streams, results, &sub[0]->rewritten);
+            if (st == XLZ_OK) { // ... and bytes a re-run wrote after their slices had gone out
+                again.insert(again.end(), sub[0]->rewritten.begin(), sub[0]->rewritten.end());
+                std::sort(again.begin(), again.end());
+                again.erase(std::unique(again.begin(), again.end()), again.end());
+                if (!again.empty()) st = download_all(sub[0], streams, results, &again);
+            }
             float ms = 0;
             if (st == XLZ_OK && xlz_batch_last_kernel_ms(sub[0], &ms) == XLZ_OK) sliced_kernel_ms = ms;
             cs.slices = (uint32_t)sub[0]->slice_fracs.size();

@@ -1147,9 +1147,8 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
         const bool lzma2 = RFL(up->kind) == UNIT_LZMA2;
         const bool sliced = p.slice_frac != 0; // (the host gives every unit of such a launch a state block)
         // the first launch of a sequence may start while the tails of the inputs are still on their way (head_frac)
-        const uint32_t in_len = (sliced && p.slice_k == 0) ? slice_head(in_all, p.head_frac) : in_all;
-        const uint32_t flags = (RFL(up->flags) & ~(slice_resume ? 0u : (uint32_t)UNIT_F_RESUME)) | (slice_resume ? (uint32_t)UNIT_F_RESUME : 0u) |
-                               (in_len < in_all ? (uint32_t)UNIT_F_MORE_INPUT : 0u);
+        const uint32_t in_len = (sliced && p.slice_k == 0) ? slice_head(in_all, p.head_frac, lzma2) : in_all;
+        const uint32_t flags = RFL(up->flags) | (slice_resume ? (uint32_t)UNIT_F_RESUME : 0u) | (in_len < in_all ? (uint32_t)UNIT_F_MORE_INPUT : 0u);
         d.out_cap = RFL(up->out_cap);
         d.dict_size = RFL(up->dict_size);
         const uint32_t lc = RFL(up->lc), lp = RFL(up->lp), pb = RFL(up->pb);
@@ -1358,19 +1357,21 @@ __global__ __launch_bounds__(64) void xlz_decode_kernel_hbm_model(LaunchParams p
     decode_units<true>(p, slot, slot + num_probs(p.max_lc_lp));
 }
 
-// Pieces of the output arena -> one packed image (xlz_format.h: SlicePiece).  A workgroup takes 16 KiB tiles of the packed
-// image: it finds the piece its tile starts in (the table is sorted by pack_off, entry 0 starts at 0) and copies what the
-// tile holds of that piece and the following ones, 16 bytes per lane (source and destination offsets are multiples of 16
-// inside a piece: both ends of a piece are multiples of 256) and the last bytes of a piece one by one.  Runs on the copy
+// Pieces of an arena <-> one packed image (xlz_format.h: SlicePiece; SCATTER = false: arena -> image, the download of a
+// sliced batch; true: image -> arena, the heads / tails of its upload).  A workgroup takes 16 KiB tiles of the packed
+// image: it finds the piece its tile starts in (the table is sorted by pack_off) and copies what the tile holds of that
+// piece and the following ones -- 16 bytes per lane once both sides are on a 16-byte boundary (a piece sits in the image at
+// its arena offset modulo 256, so they get there together), the bytes in front and behind one by one.  Runs on a copy
 // stream NEXT TO the persistent decode grid (which leaves wave slots, registers and LDS free: 16 of 32 waves per CU).
 constexpr uint64_t kGatherTile = 16384;
-__global__ __launch_bounds__(256) void xlz_gather_kernel(const SlicePiece *__restrict__ pc, uint32_t n, const uint8_t *__restrict__ arena,
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void xlz_gather_kernel(const SlicePiece *__restrict__ pc, uint32_t n, uint8_t *__restrict__ arena,
                                                           uint8_t *__restrict__ pack, uint64_t pack_bytes)
 {
     const uint64_t tiles = (pack_bytes + kGatherTile - 1) / kGatherTile;
     for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         const uint64_t t0 = t * kGatherTile, t1 = min(t0 + kGatherTile, pack_bytes);
-        uint32_t lo = 0, hi = n; // pc[lo].pack_off <= t0 < pc[hi].pack_off
+        uint32_t lo = 0, hi = n; // the last piece that starts at or in front of t0 (piece 0 if none does)
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
             if (pc[mid].pack_off <= t0)
@@ -1383,22 +1384,31 @@ __global__ __launch_bounds__(256) void xlz_gather_kernel(const SlicePiece *__res
             if (q.pack_off >= t1) break;
             const uint64_t a = max(q.pack_off, t0), e = min(q.pack_off + q.len, t1);
             if (e <= a) continue;
-            const uint8_t *__restrict__ src = arena + q.src_off + (a - q.pack_off);
-            uint8_t *__restrict__ dst = pack + a;
-            const uint32_t nb = (uint32_t)(e - a), nv = nb >> 4;
-            for (uint32_t j = threadIdx.x; j < nv; j += 256) reinterpret_cast<uint4 *>(dst)[j] = reinterpret_cast<const uint4 *>(src)[j];
-            for (uint32_t j = (nv << 4) + threadIdx.x; j < nb; j += 256) dst[j] = src[j];
+            uint8_t *__restrict__ in_arena = arena + q.src_off + (a - q.pack_off);
+            uint8_t *__restrict__ in_pack = pack + a;
+            const uint8_t *__restrict__ src = SCATTER ? in_pack : in_arena;
+            uint8_t *__restrict__ dst = SCATTER ? in_arena : in_pack;
+            const uint32_t nb = (uint32_t)(e - a);
+            const uint32_t peel = min((16u - (uint32_t)(a & 15u)) & 15u, nb); // a is the image offset: the arena's is congruent
+            const uint32_t nv = (nb - peel) >> 4;
+            if (threadIdx.x < peel) dst[threadIdx.x] = src[threadIdx.x];
+            for (uint32_t j = threadIdx.x; j < nv; j += 256)
+                reinterpret_cast<uint4 *>(dst + peel)[j] = reinterpret_cast<const uint4 *>(src + peel)[j];
+            for (uint32_t j = peel + (nv << 4) + threadIdx.x; j < nb; j += 256) dst[j] = src[j];
         }
     }
 }
 
-int launch_gather(const SlicePiece *pieces, uint32_t n_pieces, const uint8_t *arena, uint8_t *pack, uint64_t pack_bytes, int num_cus,
-                  void *stream)
+int launch_gather(const SlicePiece *pieces, uint32_t n_pieces, uint8_t *arena, uint8_t *pack, uint64_t pack_bytes, int num_cus,
+                  void *stream, bool scatter)
 {
     if (!n_pieces || !pack_bytes) return 0;
     const uint64_t tiles = (pack_bytes + kGatherTile - 1) / kGatherTile;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, (uint64_t)num_cus * 4);
-    hipLaunchKernelGGL(xlz_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pieces, n_pieces, arena, pack, pack_bytes);
+    if (scatter)
+        hipLaunchKernelGGL(xlz_gather_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, pieces, n_pieces, arena, pack, pack_bytes);
+    else
+        hipLaunchKernelGGL(xlz_gather_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, pieces, n_pieces, arena, pack, pack_bytes);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -134,8 +134,9 @@ def test_a_call_of_one_wave_round_runs_in_slices(ctx):
     Streams of every kind in ONE call, against the oracle on bytes, status and consumed input: all four plaintext
     families at several sizes, known sizes without end marker, output room that is too small, streams cut short or
     with a flipped byte, an empty one, tiny ones (shorter than a slice's 256-byte grain), LZMA2 streams of several
-    units, of stored chunks and damaged, and crafted LZMA2 streams whose copies read behind dictionary resets (settled
-    by the exact re-run AFTER their slices have gone out: those bytes are fetched again)."""
+    units, of stored chunks and damaged, crafted LZMA2 streams whose copies read behind dictionary resets (settled
+    by the exact re-run AFTER their slices have gone out: those bytes are fetched again), and streams whose head
+    compresses so badly that the first launch -- which starts on a share of every input -- falls short of its bound."""
     import random
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -163,6 +164,11 @@ def test_a_call_of_one_wave_round_runs_in_slices(ctx):
         elif kind == 6:
             c = c[: 13 + (len(c) - 13) * rnd.randrange(1, 9) // 10]
         alone(c, size if kind != 7 else size * rnd.randrange(1, 9) // 10)   # kind 7: not enough room
+    for i in range(6):   # an incompressible head, then long repeats: the first launch sees a share of the INPUT (the rest
+        # is still being uploaded), runs out of it far in front of its output bound and pauses -- the bytes up to the bound
+        # come out of a later launch, when that bound's pieces have gone out: the stream is fetched again
+        p = corpus.plain("R", 95_400 + i, 60_000 + 10_000 * i) + corpus.plain("Z", 95_410 + i, 400_000)
+        alone(corpus.compress_alone(p, preset=0), len(p))
     for i in range(12):                                                         # the a.lzma flavour
         p = corpus.plain("T", 95_500 + i, 60_000)
         c = corpus.alone_known_size_no_eos(p)

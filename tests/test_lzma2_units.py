@@ -160,14 +160,19 @@ def test_a_stream_beyond_4_gib_is_planned_with_64_bit_offsets():
 
 
 def test_batch_advice_counts_the_units_a_call_would_launch():
-    """xlz_batch_advice (VERDICT r3 #6): a C caller asks BEFORE uploading how much of the chip a call fills and whether
-    the host's cores are the faster decoder -- units = streams for LZMA1, the plan of xlz_lzma2_units for LZMA2;
-    break-even = 16 units per host thread (bench.py's stream_count_sweep: 256 for 16 threads); no GPU needed"""
+    """xlz_batch_advice (VERDICT r3 #6, r4 #3): a C caller asks BEFORE uploading how much of the chip a call fills and whether
+    the host's cores are the faster decoder -- units = streams for LZMA1, the plan of xlz_lzma2_units for LZMA2.  The rule
+    compares estimated times: the host decodes ONE stream on ONE thread whatever its format (a Reader2 is one goroutine,
+    reader2.go:216-250), 16 times as fast as a wave decodes a unit; for equal LZMA1 streams that is 16 units per host
+    thread (bench.py's stream_count_sweep: 256 for 16 threads).  No GPU needed"""
     import corpus
     one = corpus.compress_alone(corpus.plain("T", 1, 5000), dict_size=1 << 16)
     a = lzma_amd.batch_advice([lzma_amd.Stream(one, out_cap=5000)] * 40, host_threads=16)
     assert a["units"] == 40 and a["break_even_units"] == 256 and a["prefer_cpu"] == 1
     assert a["wave_slots"] == 4096 and abs(a["fill"] - 40 / 4096) < 1e-9 and a["in_bytes"] == 40 * len(one)
+    assert a["gpu_cost"] == len(one) and abs(a["cpu_cost"] - -(-40 * len(one) // 16) / 16) < 1e-9
+    # 100 small LZMA1 streams on 16 threads: the host's
+    assert lzma_amd.batch_advice([lzma_amd.Stream(one, out_cap=5000)] * 100, host_threads=16)["prefer_cpu"] == 1
     a = lzma_amd.batch_advice([lzma_amd.Stream(one, out_cap=5000)] * 300, host_threads=16)
     assert a["units"] == 300 and a["prefer_cpu"] == 0
     assert lzma_amd.batch_advice([lzma_amd.Stream(one, out_cap=5000)] * 300, host_threads=64)["prefer_cpu"] == 1
@@ -178,6 +183,23 @@ def test_batch_advice_counts_the_units_a_call_would_launch():
     assert a["units"] == len(units) == 600 and a["prefer_cpu"] == 0
     both = lzma_amd.batch_advice([s2, lzma_amd.Stream(one, out_cap=5000)], host_threads=16)
     assert both["units"] == 601 and both["in_bytes"] == len(blob) + len(one)
+    # ... and so is one of 100 units on a host of 16 threads ("100 units < 256" sent it to ONE host thread --
+    # 100 units of serial work there, one unit's worth on the GPU), on any number of threads
+    seg = corpus.compress_raw_lzma2(corpus.plain("T", 7, 20_000), dict_size=1 << 16)[:-1]
+    hundred = seg * 100 + b"\0"
+    sh = lzma_amd.Stream(hundred, lzma_amd.FMT_LZMA2_RAW, out_cap=100 * 20_000, dict_size=1 << 16)
+    for threads in (1, 16, 256):
+        a = lzma_amd.batch_advice([sh], host_threads=threads)
+        assert a["units"] == 100 and a["prefer_cpu"] == 0, threads
+        assert a["gpu_cost"] == len(seg) + 1 and abs(a["cpu_cost"] - len(hundred) / 16) < 1e-9   # (the last unit holds the end byte)
+    # few big LZMA1 streams -- the shape of bench.py's cfg5-wrap, 64 streams -- are the host's: nothing inside LZMA1 is parallel
+    big = corpus.compress_alone(corpus.plain("T", 9, 400_000), dict_size=1 << 23, lc=2, lp=1, pb=1)
+    a = lzma_amd.batch_advice([lzma_amd.Stream(big, out_cap=400_000)] * 64, host_threads=16)
+    assert a["units"] == 64 and a["prefer_cpu"] == 1
+    # ... and one big stream among many small ones is still one thread's work on the host: 300 small streams + one that is
+    # 20 times the others' sum
+    a = lzma_amd.batch_advice([lzma_amd.Stream(one, out_cap=5000)] * 10 + [lzma_amd.Stream(big, out_cap=400_000)], host_threads=16)
+    assert a["prefer_cpu"] == 1 and a["gpu_cost"] == len(big) and abs(a["cpu_cost"] - len(big) / 16) < 1e-9
     # one LZMA2 stream without inner resets is one unit -- one wave: decode it on the host
     single = corpus.compress_raw_lzma2(corpus.plain("T", 3, 300_000), dict_size=1 << 20)
     assert lzma_amd.lzma2_units(single)[0]["in_len"] == len(single)
