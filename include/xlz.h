@@ -78,8 +78,9 @@ typedef struct xlz_stream_desc {
                              argument of NewReader2 (values < 4096 mean 8 MiB, reader2.go:88-91)  */
     uint64_t unpack_size; /* LZMA_RAW only; all-ones = unknown (state.go:135-151)                 */
     uint8_t props;        /* LZMA_RAW only: the lc/lp/pb byte                                     */
-    uint8_t flags;        /* XLZ_STREAM_F_*                                                       */
-    uint8_t reserved[6];
+    uint8_t flags;        /* XLZ_STREAM_F_* (0 for an ordinary stream); any other bit, or the slice flag
+                             on a format that has no slices: XLZ_ERR_BAD_ARG for the call           */
+    uint8_t reserved[6];  /* must be zero (memset the descriptor): XLZ_ERR_BAD_ARG otherwise        */
 } xlz_stream_desc;
 
 /* LZMA2_RAW: `in` is a SLICE of a longer stream that does not begin at the stream's start -- it begins
@@ -385,9 +386,11 @@ int xlz_xz_decode_multi(xlz_ctx *const *ctxs, size_t n_ctx, const uint8_t *file,
                         size_t out_cap, uint64_t *out_len, int verify, size_t *unverified);
 
 /* ---- .7z container front-end ----------------------------
- * (The parser was written from 7-Zip's published format description and has only been exercised
- * on archives built from that description by tests/sevenzip_craft.py and on their mutations:
- * the build image has no 7-Zip to write or cross-check real archives with.)
+ * (The parser was written from 7-Zip's published format description.  It is exercised on archives
+ * built from that description by tests/sevenzip_craft.py and their mutations AND on archives by an
+ * independent writer -- libarchive's 7zip writer, which `cmake -E tar cf x.7z --format=7zip` drives
+ * in this image: solid LZMA1 folders, LZMA-encoded headers, per-file CRCs, an 8 MiB dictionary that
+ * wraps; tests/golden/libarchive_solid.7z is one of them.  7-Zip's own binary is not in the image.)
  * Outside the reference, which only offers the two bodgit/sevenzip decompressor constructors
  * (reader1.go:28-61 method 03 01 01, reader2.go:45-75 method 21).  A .7z archive keeps its data in
  * folders, each ONE compressed stream with out-of-band properties -- exactly what those

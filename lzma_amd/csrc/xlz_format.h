@@ -181,7 +181,8 @@ struct LaunchParams {
     uint32_t slice_k;      // index of the launch in its sequence (0: every unit starts, > 0: paused units resume)
     uint32_t head_frac;    // slice_k == 0 only: the launch sees the first slice_head(in_len, head_frac) bytes of every unit's
                            // input (the rest is still being uploaded) and pauses a unit that runs out of them; 0: all of it
-    uint32_t pad_;
+    uint32_t many_rounds;  // != 0: one of a sequence of launches that follow each other without a gap (the sub-batches of a
+                           // pipelined call): as many workgroups per CU as a launch of many rounds takes, whatever n_units
 };
 constexpr uint32_t kSliceOne = 65536;
 // output position (relative to the unit) at which a sliced launch with this slice_frac pauses a unit of out_cap bytes
@@ -215,7 +216,7 @@ static_assert(sizeof(SlicePiece) == 24, "SlicePiece layout is shared with the ho
 // scatter = false: arena -> packed image (download); true: packed image -> arena (the upload's heads / tails)
 int launch_gather(const SlicePiece *pieces, uint32_t n_pieces, uint8_t *arena, uint8_t *pack, uint64_t pack_bytes, int num_cus,
                   void *stream /* hipStream_t */, bool scatter = false);
-int launch_decode(const LaunchParams &p, int num_cus, void *stream /* hipStream_t */);
+int launch_decode(const LaunchParams &p, int num_cus, void *stream /* hipStream_t */, uint32_t max_grid = 0 /* HBM-model launch: at most that many workgroups */);
 uint32_t decode_lds_bytes(uint32_t max_lc_lp);
 uint32_t big_model_grid(int num_cus);
 uint32_t decode_grid(uint32_t max_lc_lp, int num_cus, uint32_t n_units); // resident workgroups of the LDS-model launch over n_units units (~0u: the most)

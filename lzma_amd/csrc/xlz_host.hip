@@ -43,6 +43,8 @@ constexpr size_t kArenaTailPad = 1024; // the 256-byte input window may start ne
 constexpr size_t kOutTailPad = 64;    // wave_copy stores whole 64-lane rows: scratch bytes past a unit's end
 // xlz_decode_batch, a call of one wave round: run it as a sequence of launches (slices) from this much output on, a slice
 // for every kSliceBytes of it, at most kMaxSlices (profiles/r05/slices_scan.txt)
+constexpr uint32_t kWideGrid = 32;                // workgroups of the widest-model re-run (6 MiB of model each)
+constexpr int XLZ_ERR_NO_MEMORY_INTERNAL = -1000; // run_units: the widest models could not be allocated (never leaves this file)
 constexpr uint64_t kSlicedCallBytes = 256ull << 20;
 constexpr uint64_t kSliceBytes = 128ull << 20;
 constexpr uint64_t kMaxSlices = 8;
@@ -127,6 +129,11 @@ struct xlz_ctx {
     int num_cus = 0;
     hipStream_t stream = nullptr;
     uint32_t *queue = nullptr; // work-queue head, re-zeroed on the stream before each launch
+    // the sub-batches of a pipelined xlz_decode_batch alternate between two streams (each with a queue of its own): launch
+    // k + 1 is not held behind launch k, its workgroups take the wave slots that k's workgroups leave when k's queue has
+    // run dry -- no round of a sub-batch ends with idle slots while the next sub-batch waits
+    hipStream_t stream2 = nullptr;
+    uint32_t *queue2 = nullptr;
     uint32_t *prio_tab = nullptr; // LaunchParams.prio_tab: one word per hardware wave slot, zero when idle
     hipEvent_t ev[kEventSlots] = {};
     std::mutex mu;
@@ -174,6 +181,9 @@ struct xlz_batch {
     uint16_t *d_mlit = nullptr;    // LDS-model launch: matched-literal part per workgroup
     uint32_t mlit_stride = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t run_stream = nullptr; // where the batch's launches go (the context's stream, or its second one)
+    uint32_t *queue = nullptr;        // ... and their work-queue head
+    bool many_rounds = false; // a sub-batch of a pipelined call: the launch takes as many wave slots as a call of many rounds
     bool ran = false;
     uint64_t algo_in = 0; // compressed payload bytes handed to the device
     // per-stream results of the latest run (filled lazily by collect())
@@ -182,6 +192,7 @@ struct xlz_batch {
     bool collected = false;
     uint64_t sum_in = 0, sum_out = 0;
     std::vector<size_t> rewritten; // streams whose bytes a re-run of collect() wrote again (exact / widest-model launches)
+    std::vector<char> wants_wide;  // per stream: it ended in front of a chunk whose properties need a larger model (AUX_GROW)
     // A SLICED batch (xlz_decode_batch, a call of one wave round: LaunchParams.slice_*): the run is a sequence of launches,
     // launch k advances every unit to its k-th output bound; every unit has a state block; slice_ev[k] is recorded behind
     // launch k, and the bytes in front of the k-th bounds are downloaded while launch k + 1 decodes (download_sliced).
@@ -322,9 +333,14 @@ extern "C" int xlz_ctx_create(int device, xlz_ctx **out)
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&c->queue, 512) != hipSuccess || hipMalloc(&c->prio_tab, kPrioTabWords * sizeof(uint32_t)) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&c->queue, 512) != hipSuccess || hipMalloc(&c->queue2, 512) != hipSuccess ||
+        hipMalloc(&c->prio_tab, kPrioTabWords * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(c->prio_tab, 0, kPrioTabWords * sizeof(uint32_t)) != hipSuccess) {
         if (c->queue) (void)hipFree(c->queue);
+        if (c->queue2) (void)hipFree(c->queue2);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        if (c->stream2) (void)hipStreamDestroy(c->stream2);
         if (c->prio_tab) (void)hipFree(c->prio_tab);
         delete c;
         return XLZ_ERR_DEVICE;
@@ -339,6 +355,7 @@ extern "C" void xlz_ctx_destroy(xlz_ctx *c)
     if (c->batcher) batcher_shutdown(c->batcher);
     (void)hipSetDevice(c->device);
     if (c->queue) (void)hipFree(c->queue);
+    if (c->queue2) (void)hipFree(c->queue2);
     if (c->prio_tab) (void)hipFree(c->prio_tab);
     if (c->pipe.pin_in) (void)hipHostFree(c->pipe.pin_in);
     for (int i = 0; i < HostPipe::kRing; i++) {
@@ -350,6 +367,7 @@ extern "C" void xlz_ctx_destroy(xlz_ctx *c)
     for (hipEvent_t e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
 }
 
@@ -652,24 +670,39 @@ int batch_free(xlz_batch *b)
 
 } // namespace
 
-static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **out, uint32_t want_slices,
-                           uint32_t head_frac);
+// How xlz_decode_batch wants a (sub-)batch made.  want_slices > 1: a sliced batch (xlz_batch: slice_*) if every unit's model
+// fits LDS and the units are ONE wave round (a launch per slice and round would pay every round's tail per slice);
+// head_frac != 0: such a batch's first launch may start when that share (in 1/65536, + 4 KiB) of every unit's input is on
+// the device -- the rest is uploaded by xlz_batch_run behind the first launch, and `streams` must stay valid until then.
+struct BatchOpts {
+    uint32_t want_slices = 1;
+    uint32_t head_frac = 0;
+    bool many_rounds = false;        // xlz_batch::many_rounds
+    hipStream_t run_stream = nullptr; // xlz_batch::run_stream / queue (nullptr: the context's)
+    uint32_t *queue = nullptr;
+};
+static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **out, const BatchOpts &opts);
 
 extern "C" int xlz_batch_create(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **out)
 {
-    return batch_create_ex(ctx, streams, n, out, 1, 0);
+    return batch_create_ex(ctx, streams, n, out, BatchOpts{});
 }
 
-// want_slices > 1: make the batch a sliced one (xlz_batch: slice_*) if every unit's model fits LDS; head_frac != 0: such a
-// batch's first launch may start when that share (in 1/65536, + 4 KiB) of every unit's input is on the device -- the rest
-// is uploaded by xlz_batch_run behind the first launch, and `streams` must stay valid until then
-static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **out, uint32_t want_slices,
-                           uint32_t head_frac)
+static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_batch **out, const BatchOpts &opts)
 {
+    const uint32_t want_slices = opts.want_slices, head_frac = opts.head_frac;
     if (!ctx || !out || (!streams && n)) return XLZ_ERR_BAD_ARG;
     *out = nullptr;
-    for (size_t i = 0; i < n; i++)
+    for (size_t i = 0; i < n; i++) {
         if (!streams[i].in && streams[i].in_len) return XLZ_ERR_BAD_ARG;
+        // flags: only the bits the header defines, and a slice is a slice of a raw LZMA2 stream (the field was
+        // `reserved` before round 4 -- a caller's stale bytes must not silently change what a stream means)
+        if ((streams[i].flags & ~XLZ_STREAM_F_LZMA2_SLICE) ||
+            ((streams[i].flags & XLZ_STREAM_F_LZMA2_SLICE) && streams[i].format != XLZ_FMT_LZMA2_RAW))
+            return XLZ_ERR_BAD_ARG;
+        for (size_t k = 0; k < sizeof streams[i].reserved; k++)
+            if (streams[i].reserved[k]) return XLZ_ERR_BAD_ARG;
+    }
     // (no ctx->mu here: planning touches only the new batch, the pinned staging image has its own mutex -- a pipelined
     //  xlz_decode_batch creates sub-batch k+1 while sub-batch k is launched and collected)
     HIP_TRY(hipSetDevice(ctx->device));
@@ -679,6 +712,9 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
     b->ctx = ctx;
     b->n = n;
     b->plans.resize(n);
+    b->many_rounds = opts.many_rounds;
+    b->run_stream = opts.run_stream;
+    b->queue = opts.queue;
 
     // ---- plan: parse headers, lay out the arenas -------------------------
     auto unit_src_off_p = std::make_shared<std::vector<size_t>>(); // where each unit's payload starts in its stream
@@ -708,7 +744,7 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
         if (u.kind == UNIT_LZMA2) {
             if (s.in_len > kMaxUnitBytes || s.out_cap > kMaxUnitBytes) {
                 pl.host_status = XLZ_ERR_UNSUPPORTED; // (xlz_decode_batch decodes these as sessions)
-                pl.oversize = true;
+                pl.oversize = !pl.slice; // ... but not a slice: a session knows nothing of the units in front of it
                 continue;
             }
             std::vector<Lz2Unit> lu;
@@ -822,7 +858,7 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
         const size_t slots = (size_t)decode_grid(b->max_lc_lp, ctx->num_cus, ~0u);
         if (hipMalloc(&b->d_mlit, slots * b->mlit_stride * sizeof(uint16_t)) != hipSuccess) return fail(XLZ_ERR_DEVICE);
     }
-    if (want_slices > 1 && nu && b->n_normal == nu) {
+    if (want_slices > 1 && nu && b->n_normal == nu && nu <= decode_grid(b->max_lc_lp, ctx->num_cus, b->many_rounds ? ~0u : (uint32_t)nu)) {
         // sliced batch: equal shares of every unit's output per launch; a state block per unit; per launch the table of
         // the pieces it finishes (unit order = arena order, packed back to back on 256-byte boundaries)
         const uint32_t K = std::min<uint32_t>(want_slices, 64);
@@ -1014,8 +1050,10 @@ extern "C" int xlz_batch_run(xlz_batch *b)
     xlz_ctx *ctx = b->ctx;
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
-    HIP_TRY(hipEventRecord(b->ev0, ctx->stream));
+    const hipStream_t rs = b->run_stream ? b->run_stream : ctx->stream;
+    uint32_t *const rq = b->queue ? b->queue : ctx->queue;
+    HIP_TRY(hipMemsetAsync(rq, 0, 256, rs));
+    HIP_TRY(hipEventRecord(b->ev0, rs));
     const uint32_t nu = (uint32_t)b->units.size();
     LaunchParams p;
     memset(&p, 0, sizeof p); // (ready, epochs, ...: off unless set below)
@@ -1024,8 +1062,9 @@ extern "C" int xlz_batch_run(xlz_batch *b)
     p.units = b->d_units;
     p.order = b->d_order;
     p.results = b->d_results;
-    p.queue = ctx->queue;
+    p.queue = rq;
     p.prio_tab = ctx->prio_tab;
+    p.many_rounds = b->many_rounds ? 1u : 0u;
     p.epochs = nullptr; // ordinary launch: copies that reach across a dictionary reset are only flagged
     if (b->n_normal) { // models in LDS
         p.n_units = b->n_normal;
@@ -1036,22 +1075,22 @@ extern "C" int xlz_batch_run(xlz_batch *b)
         p.mlit_stride = b->mlit_stride;
         p.order_base = 0;
         if (b->slice_fracs.empty()) {
-            if (launch_decode(p, ctx->num_cus, ctx->stream) != 0) return XLZ_ERR_DEVICE;
+            if (launch_decode(p, ctx->num_cus, rs) != 0) return XLZ_ERR_DEVICE;
         } else { // a sequence of launches, each up to the next output bound of every unit (all queued at once)
             for (size_t k = 0; k < b->slice_fracs.size(); k++) {
-                if (k) HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
-                if (k == 0 && b->upload_tails) HIP_TRY(hipStreamWaitEvent(ctx->stream, b->ev_heads, 0)); // the heads are on their way
+                if (k) HIP_TRY(hipMemsetAsync(rq, 0, 256, rs));
+                if (k == 0 && b->upload_tails) HIP_TRY(hipStreamWaitEvent(rs, b->ev_heads, 0)); // the heads are on their way
                 if (k == 1 && b->upload_tails) { // the first launch is queued: now pack and upload the rest of the inputs
                     const int st = b->upload_tails();
                     b->upload_tails = nullptr;
                     if (st != XLZ_OK) return st;
-                    HIP_TRY(hipStreamWaitEvent(ctx->stream, b->ev_tails, 0));
+                    HIP_TRY(hipStreamWaitEvent(rs, b->ev_tails, 0));
                 }
                 p.slice_frac = b->slice_fracs[k];
                 p.slice_k = (uint32_t)k;
                 p.head_frac = k == 0 ? b->head_frac : 0;
-                if (launch_decode(p, ctx->num_cus, ctx->stream) != 0) return XLZ_ERR_DEVICE;
-                HIP_TRY(hipEventRecord(b->slice_ev[k], ctx->stream));
+                if (launch_decode(p, ctx->num_cus, rs) != 0) return XLZ_ERR_DEVICE;
+                HIP_TRY(hipEventRecord(b->slice_ev[k], rs));
             }
             p.slice_frac = 0;
             p.slice_k = 0;
@@ -1064,7 +1103,7 @@ extern "C" int xlz_batch_run(xlz_batch *b)
         }
     }
     if (nu > b->n_normal) { // models in HBM (lc+lp > 6)
-        HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
+        HIP_TRY(hipMemsetAsync(rq, 0, 256, rs));
         p.n_units = nu - b->n_normal;
         p.max_lc_lp = b->max_lc_lp_big;
         p.scratch = b->d_scratch;
@@ -1072,9 +1111,9 @@ extern "C" int xlz_batch_run(xlz_batch *b)
         p.mlit = nullptr;
         p.mlit_stride = 0;
         p.order_base = b->n_normal;
-        if (launch_decode(p, ctx->num_cus, ctx->stream) != 0) return XLZ_ERR_DEVICE;
+        if (launch_decode(p, ctx->num_cus, rs) != 0) return XLZ_ERR_DEVICE;
     }
-    HIP_TRY(hipEventRecord(b->ev1, ctx->stream));
+    HIP_TRY(hipEventRecord(b->ev1, rs));
     b->ran = true;
     b->collected = false;
     return XLZ_OK;
@@ -1084,7 +1123,7 @@ extern "C" int xlz_batch_sync(xlz_batch *b)
 {
     if (!b) return XLZ_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(b->ctx->device));
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->run_stream ? b->run_stream : b->ctx->stream));
     return XLZ_OK;
 }
 
@@ -1115,12 +1154,16 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
     Epoch *d_epochs = nullptr;
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
-    const uint32_t grid = std::min<uint32_t>((uint32_t)n, big ? big_model_grid(ctx->num_cus)
-                                                              : decode_grid(b->max_lc_lp, ctx->num_cus, (uint32_t)n));
+    uint32_t grid = std::min<uint32_t>((uint32_t)n, big ? big_model_grid(ctx->num_cus)
+                                                        : decode_grid(b->max_lc_lp, ctx->num_cus, (uint32_t)n));
+    if (wide_lc_lp) grid = std::min(grid, kWideGrid); // (the launch's grid follows p.n_units: see below)
     int st = XLZ_ERR_DEVICE;
     uint16_t *d_wide = nullptr;
     const uint32_t wide_stride = wide_lc_lp ? num_probs(wide_lc_lp) + num_matched_probs(wide_lc_lp) : 0;
-    if (wide_lc_lp && hipMalloc(&d_wide, (size_t)grid * wide_stride * sizeof(uint16_t)) != hipSuccess) return XLZ_ERR_DEVICE;
+    if (wide_lc_lp && hipMalloc(&d_wide, (size_t)grid * wide_stride * sizeof(uint16_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        return XLZ_ERR_NO_MEMORY_INTERNAL;
+    }
     if (hipMalloc(&d_units, n * sizeof(Unit)) == hipSuccess && hipMalloc(&d_order, n * sizeof(uint32_t)) == hipSuccess &&
         hipMalloc(&d_res, n * sizeof(UnitResult)) == hipSuccess &&
         hipMalloc(&d_epochs, (size_t)grid * kMaxEpochs * sizeof(Epoch)) == hipSuccess &&
@@ -1144,7 +1187,7 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
         p.order_base = 0;
         p.epochs = d_epochs;
         p.prio_tab = ctx->prio_tab;
-        if (launch_decode(p, ctx->num_cus, ctx->stream) == 0 && hipStreamSynchronize(ctx->stream) == hipSuccess &&
+        if (launch_decode(p, ctx->num_cus, ctx->stream, wide_lc_lp ? grid : 0) == 0 && hipStreamSynchronize(ctx->stream) == hipSuccess &&
             hipMemcpy(res.data(), d_res, n * sizeof(UnitResult), hipMemcpyDeviceToHost) == hipSuccess)
             st = XLZ_OK;
     }
@@ -1175,6 +1218,7 @@ int collect(xlz_batch *b)
         HIP_TRY(hipMemcpy(ur.data(), b->d_results, ur.size() * sizeof(UnitResult), hipMemcpyDeviceToHost));
     b->final_results.assign(b->n, xlz_result{});
     b->rewritten.clear();
+    b->wants_wide.assign(b->n, 0);
     std::vector<size_t> redo;
     fold_streams(b, 0, b->n, redo);
     return finish_collect(b, redo);
@@ -1224,6 +1268,7 @@ void fold_streams(xlz_batch *b, size_t s0, size_t s1, std::vector<size_t> &redo)
             const Unit &un = b->units[pl.first_unit + k];
             const UnitResult &u = ur[pl.first_unit + k];
             const bool last = k + 1 == pl.n_units;
+            if (u.status == ST_ERR_UNSUPPORTED && (u.aux & AUX_GROW)) b->wants_wide[i] = 1;
             if (last) {
                 r.status = u.status;
                 r.out_len = out + u.out_len;
@@ -1282,6 +1327,7 @@ int finish_collect(xlz_batch *b, const std::vector<size_t> &redo)
             r.out_len = res[k].out_len;
             r.in_consumed = res[k].in_consumed;
             b->rewritten.push_back(idx[k]);
+            b->wants_wide[idx[k]] = (res[k].status == ST_ERR_UNSUPPORTED && (res[k].aux & AUX_GROW)) ? 1 : 0;
         }
     }
     // The model's storage (LDS, or a workgroup's HBM slot) is sized by the host's scan of the chunk HEADERS.  A malformed stream
@@ -1296,7 +1342,8 @@ int finish_collect(xlz_batch *b, const std::vector<size_t> &redo)
         std::vector<size_t> idx;
         for (size_t i = 0; i < b->n; i++) {
             const StreamPlan &pl = b->plans[i];
-            if (pl.host_status != 1 || !pl.lzma2 || pl.slice || b->final_results[i].status != XLZ_ERR_UNSUPPORTED) continue;
+            // (only streams that stopped in front of LARGER PROPERTIES: a re-run cannot help a full epoch table -- ADVICE r4)
+            if (pl.host_status != 1 || !pl.lzma2 || pl.slice || b->final_results[i].status != XLZ_ERR_UNSUPPORTED || !b->wants_wide[i]) continue;
             idx.push_back(i);
             Unit u;
             memset(&u, 0, sizeof u);
@@ -1315,7 +1362,10 @@ int finish_collect(xlz_batch *b, const std::vector<size_t> &redo)
         if (!units.empty()) {
             std::vector<UnitResult> res;
             int st = run_units(b, units, res, true, kMaxLcLp);
-            if (st != XLZ_OK) return st;
+            // no memory for the widest models (6 MiB per workgroup): these streams stay at XLZ_ERR_UNSUPPORTED, the call and
+            // the other streams' results stand -- one crafted stream must not fail a batch
+            if (st == XLZ_ERR_NO_MEMORY_INTERNAL) idx.clear();
+            else if (st != XLZ_OK) return st;
             for (size_t k = 0; k < idx.size(); k++) {
                 xlz_result &r = b->final_results[idx[k]];
                 r.status = res[k].status;
@@ -1385,7 +1435,7 @@ extern "C" int xlz_batch_unit_trace(xlz_batch *b, uint32_t *t_start, uint32_t *t
 extern "C" int xlz_batch_launch_info(xlz_batch *b, uint32_t *workgroups, uint32_t *lds_bytes)
 {
     if (!b) return XLZ_ERR_BAD_ARG;
-    const uint32_t grid = std::min<uint32_t>(b->n_normal, decode_grid(b->max_lc_lp, b->ctx->num_cus, b->n_normal));
+    const uint32_t grid = std::min<uint32_t>(b->n_normal, decode_grid(b->max_lc_lp, b->ctx->num_cus, b->many_rounds ? ~0u : b->n_normal));
     if (workgroups) *workgroups = grid;
     if (lds_bytes) *lds_bytes = decode_lds_bytes(b->max_lc_lp);
     return XLZ_OK;
@@ -1407,7 +1457,7 @@ extern "C" int xlz_batch_download(xlz_batch *b, size_t i, uint8_t *dst, size_t l
     if (pl.host_status != 1 || len == 0) return XLZ_OK;
     if (len > pl.out_cap) len = (size_t)pl.out_cap;
     HIP_TRY(hipSetDevice(b->ctx->device));
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->run_stream ? b->run_stream : b->ctx->stream));
     HIP_TRY(hipMemcpy(dst, b->d_out + pl.out_off, len, hipMemcpyDeviceToHost));
     return XLZ_OK;
 }
@@ -1759,16 +1809,18 @@ extern "C" int xlz_ctx_last_call_stats(xlz_ctx *ctx, xlz_call_stats *out)
 }
 
 // Where a call of several wave rounds is cut into sub-batches whose upload, decode and download overlap: equal
-// shares of the output, each at least one wave round of streams and half a GiB, at most eight (what stays exposed is
-// the first sub-batch's upload and the last one's download: the smaller they are, the less).  One sub-batch =
-// the plain sequence (a single wave round has nothing to overlap: every stream needs the whole launch).
+// shares of the output, each at least one wave round of streams and a quarter of a GiB, at most sixteen (what stays
+// exposed is the first sub-batch's upload and the last one's download: the smaller they are, the less; the launches of
+// consecutive sub-batches overlap on two streams, so a sub-batch need not be a whole number of rounds).  One sub-batch =
+// the call is one wave round (or too small to bother): it overlaps its copies with its own decode (slices).
 static void plan_sub_batches(const xlz_stream_desc *streams, size_t n, std::vector<size_t> &cuts)
 {
     cuts.assign(1, 0);
     uint64_t total = 0;
     for (size_t i = 0; i < n; i++) total += streams[i].out_cap;
     const size_t k_round = 4096; // streams of one wave round (16 waves on each of 256 CUs)
-    size_t n_sub = std::min<size_t>(std::min<size_t>(8, n / k_round), (size_t)(total >> 29));
+    size_t n_sub = std::min<size_t>(std::min<size_t>(16, n / k_round), (size_t)(total >> 28));
+    if (total < (1ull << 30)) n_sub = 1; // (below a GiB a call is one sub-batch, as before)
     if (n_sub >= 2) {
         uint64_t acc = 0;
         size_t next = 1;
@@ -1805,22 +1857,29 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     cs.streams = n;
     cs.sub_batches = (uint32_t)S;
 
-    // A call of ONE wave round has no second sub-batch to overlap its copies with: it runs as a sequence of launches that
-    // each advance every unit by a share of its output, and share k - 1 is downloaded while share k decodes.
-    uint32_t want_slices = 1;
-    if (S == 1) {
-        uint64_t total = 0;
-        for (size_t i = 0; i < n; i++) total += streams[i].out_cap;
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        if (total >= ctx->sliced_call_bytes) want_slices = (uint32_t)std::min<uint64_t>(ctx->max_slices, total / ctx->slice_bytes);
+    // A sub-batch of ONE wave round can also overlap its OWN copies with its decode: it runs as a sequence of launches
+    // (slices) that each advance every unit by a share of its output; share k - 1 is downloaded while share k decodes, and
+    // the first launch starts on the heads of the inputs.  A call of one sub-batch is that sub-batch; in a pipeline the
+    // first sub-batch (its upload is the exposed one) and the last (its download is).
+    uint64_t sliced_call_bytes, slice_bytes, max_slices;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu); // (once: the launching thread holds this lock most of the call)
+        sliced_call_bytes = ctx->sliced_call_bytes, slice_bytes = ctx->slice_bytes, max_slices = ctx->max_slices;
     }
+    auto slices_for = [&](size_t k) -> uint32_t {
+        if (S > 1 && k != 0 && k + 1 != S) return 1;
+        uint64_t total = 0;
+        for (size_t i = cuts[k]; i < cuts[k + 1]; i++) total += streams[i].out_cap;
+        return total >= sliced_call_bytes ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(max_slices, total / slice_bytes)) : 1u;
+    };
 
     std::vector<xlz_batch *> sub(S, nullptr);
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<int> created(S, 0), decoded(S, 0); // 0 pending, 1 done, -1 failed
+    std::vector<int> created(S, 0), launched(S, 0), decoded(S, 0); // 0 pending, 1 done, -1 failed
     int st_up = XLZ_OK, st_down = XLZ_OK;
     bool abort_all = false;
+    const bool threaded = S > 1;
     double t_first_up = 0, t_decoded = 0, occ_busy = 0, occ_span = 0;
 
     auto uploader = [&] {
@@ -1830,7 +1889,12 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
                 if (abort_all) return;
             }
             xlz_batch *b = nullptr;
-            const int st = batch_create_ex(ctx, streams + cuts[k], cuts[k + 1] - cuts[k], &b, want_slices, head_frac_for(want_slices));
+            BatchOpts o;
+            o.want_slices = slices_for(k);
+            o.head_frac = k == 0 ? head_frac_for(o.want_slices) : 0; // (only the first sub-batch's upload is exposed)
+            o.many_rounds = S > 1;
+            if (S > 1 && k % 2) o.run_stream = ctx->stream2, o.queue = ctx->queue2; // (xlz_ctx: stream2)
+            const int st = batch_create_ex(ctx, streams + cuts[k], cuts[k + 1] - cuts[k], &b, o);
             if (dbg) fprintf(stderr, "xlz_decode_batch: sub-batch %zu uploaded at %.1f ms\n", k, now_ms());
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -1843,18 +1907,80 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
             if (st != XLZ_OK) return;
         }
     };
+    // this thread: launch sub-batch k as soon as it is uploaded, then collect k - 1
+    int st = XLZ_OK;
+    auto collect_one = [&](size_t k) {
+        int e = xlz_batch_results(sub[k], results + cuts[k]);
+        if (e == XLZ_OK) {
+            xlz_call_stats one;
+            memset(&one, 0, sizeof one);
+            launch_occupancy(sub[k], one);
+            cs.units += one.units;
+            cs.wave_slots = std::max(cs.wave_slots, one.wave_slots);
+            cs.kernel_span_ms += one.kernel_span_ms;
+            if (sub[k]->slice_fracs.empty()) { // (a sliced sub-batch: the mean over its launches, from download_sliced)
+                occ_busy += one.slot_occupancy * one.kernel_span_ms;
+                occ_span += one.kernel_span_ms;
+            }
+        }
+        if (dbg) fprintf(stderr, "xlz_decode_batch: sub-batch %zu decoded at %.1f ms\n", k, now_ms());
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            decoded[k] = e == XLZ_OK ? 1 : -1;
+            if (e != XLZ_OK) abort_all = true;
+            t_decoded = now_ms();
+        }
+        cv.notify_all();
+        return e;
+    };
+    // true when sub-batch k's results are on the host (threaded: the launching thread collects them; else: do it here)
+    auto await_decoded = [&](size_t k) {
+        if (!threaded) {
+            if (decoded[k] == 0) {
+                const int e = collect_one(k);
+                if (e != XLZ_OK) st_down = e;
+            }
+            return decoded[k] == 1;
+        }
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return decoded[k] != 0 || abort_all; });
+        return decoded[k] == 1;
+    };
     auto downloader = [&] {
         for (size_t k = 0; k < S; k++) {
-            {
+            int e = XLZ_OK;
+            if (threaded) {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return decoded[k] != 0 || abort_all; });
-                if (decoded[k] != 1) return;
+                cv.wait(lk, [&] { return launched[k] != 0 || abort_all; });
+                if (launched[k] != 1) return;
             }
-            const int st = download_all(sub[k], streams + cuts[k], results + cuts[k]);
-            if (dbg) fprintf(stderr, "xlz_decode_batch: sub-batch %zu downloaded at %.1f ms\n", k, now_ms());
-            if (st != XLZ_OK) {
+            xlz_batch *b = sub[k];
+            if (!b->slice_fracs.empty()) {
+                // sliced: all launches are queued; fetch what each one finishes while the next one decodes
+                std::vector<double> occ;
+                std::vector<size_t> again; // streams to fetch once more: units that fell short of a bound, ...
+                e = download_sliced(b, streams + cuts[k], &occ, again);
+                if (dbg)
+                    fprintf(stderr, "xlz_decode_batch: sub-batch %zu: %zu slices downloaded at %.1f ms, %zu streams with gaps\n", k,
+                            b->slice_fracs.size(), now_ms(), again.size());
+                if (e == XLZ_OK && !await_decoded(k)) return;
+                if (e == XLZ_OK) { // ... and bytes a re-run wrote after their slices had gone out
+                    again.insert(again.end(), b->rewritten.begin(), b->rewritten.end());
+                    std::sort(again.begin(), again.end());
+                    again.erase(std::unique(again.begin(), again.end()), again.end());
+                    if (!again.empty()) e = download_all(b, streams + cuts[k], results + cuts[k], &again);
+                }
                 std::lock_guard<std::mutex> lk(mu);
-                st_down = st;
+                cs.slices = std::max<uint32_t>(cs.slices, (uint32_t)b->slice_fracs.size());
+                for (double o : occ) occ_busy += o * 1.0, occ_span += 1.0; // (weight: one launch = 1 ms; good enough for a mean)
+            } else {
+                if (!await_decoded(k)) return;
+                e = download_all(b, streams + cuts[k], results + cuts[k]);
+            }
+            if (dbg) fprintf(stderr, "xlz_decode_batch: sub-batch %zu downloaded at %.1f ms\n", k, now_ms());
+            if (e != XLZ_OK) {
+                std::lock_guard<std::mutex> lk(mu);
+                st_down = e;
                 abort_all = true;
                 cv.notify_all();
                 return;
@@ -1862,7 +1988,7 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
         }
     };
     std::thread th_up, th_down;
-    if (S > 1) {
+    if (threaded) {
         try {
             th_up = std::thread(uploader);
             th_down = std::thread(downloader);
@@ -1877,61 +2003,17 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
             return XLZ_ERR_DEVICE;
         }
     }
-    // this thread: launch sub-batch k as soon as it is uploaded (queued behind k-1 on the stream), then collect k-1
-    int st = XLZ_OK;
-    auto collect_one = [&](size_t k) {
-        int e = xlz_batch_results(sub[k], results + cuts[k]);
-        if (e == XLZ_OK) {
-            xlz_call_stats one;
-            memset(&one, 0, sizeof one);
-            launch_occupancy(sub[k], one);
-            cs.units += one.units;
-            cs.wave_slots = std::max(cs.wave_slots, one.wave_slots);
-            cs.kernel_span_ms += one.kernel_span_ms;
-            occ_busy += one.slot_occupancy * one.kernel_span_ms;
-            occ_span += one.kernel_span_ms;
-        }
-        if (dbg) fprintf(stderr, "xlz_decode_batch: sub-batch %zu decoded at %.1f ms\n", k, now_ms());
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            decoded[k] = e == XLZ_OK ? 1 : -1;
-            if (e != XLZ_OK) abort_all = true;
-            t_decoded = now_ms();
-        }
-        cv.notify_all();
-        return e;
-    };
     double sliced_kernel_ms = -1;
-    if (S == 1) {
+    if (!threaded) {
         uploader();
         st = st_up;
         if (st == XLZ_OK) st = xlz_batch_run(sub[0]);
-        if (st == XLZ_OK && !sub[0]->slice_fracs.empty()) {
-            // sliced: all launches are queued; download what each one finishes while the next one decodes
-            std::vector<double> occ;
-            std::vector<size_t> again; // streams to fetch once more: units that fell short of a bound, ...
-            st = download_sliced(sub[0], streams, &occ, again);
-            if (dbg)
-                fprintf(stderr, "xlz_decode_batch: %zu slices downloaded at %.1f ms, %zu streams with gaps\n", sub[0]->slice_fracs.size(),
-                        now_ms(), again.size());
-            if (st == XLZ_OK) st = collect_one(0);
-            if (st == XLZ_OK) { // ... and bytes a re-run wrote after their slices had gone out
-                again.insert(again.end(), sub[0]->rewritten.begin(), sub[0]->rewritten.end());
-                std::sort(again.begin(), again.end());
-                again.erase(std::unique(again.begin(), again.end()), again.end());
-                if (!again.empty()) st = download_all(sub[0], streams, results, &again);
-            }
+        if (st == XLZ_OK) {
+            launched[0] = 1;
+            downloader(); // (collects the results when it needs them)
+            st = st_down;
             float ms = 0;
-            if (st == XLZ_OK && xlz_batch_last_kernel_ms(sub[0], &ms) == XLZ_OK) sliced_kernel_ms = ms;
-            cs.slices = (uint32_t)sub[0]->slice_fracs.size();
-            if (st == XLZ_OK && !occ.empty()) {
-                occ_busy = 0;
-                for (double o : occ) occ_busy += o;
-                occ_span = (double)occ.size();
-            }
-        } else {
-            if (st == XLZ_OK) st = collect_one(0);
-            if (st == XLZ_OK) downloader(), st = st_down;
+            if (st == XLZ_OK && !sub[0]->slice_fracs.empty() && xlz_batch_last_kernel_ms(sub[0], &ms) == XLZ_OK) sliced_kernel_ms = ms;
         }
     } else {
         for (size_t k = 0; k < S && st == XLZ_OK; k++) {
@@ -1941,12 +2023,18 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
                 if (created[k] != 1) break;
             }
             st = xlz_batch_run(sub[k]);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                launched[k] = st == XLZ_OK ? 1 : -1;
+                if (st != XLZ_OK) abort_all = true;
+            }
+            cv.notify_all();
             if (st == XLZ_OK && k > 0) st = collect_one(k - 1);
         }
         bool all_launched;
         {
             std::lock_guard<std::mutex> lk(mu);
-            all_launched = created[S - 1] == 1 && !abort_all;
+            all_launched = created[S - 1] == 1 && launched[S - 1] == 1 && !abort_all;
         }
         if (st == XLZ_OK && all_launched) st = collect_one(S - 1);
         {
@@ -2009,7 +2097,9 @@ void multi_split(const xlz_stream_desc &s, size_t stream, size_t pieces, std::ve
 {
     std::vector<Lz2Unit> lu;
     uint32_t mx = 0;
-    if (pieces >= 2 && s.in_len <= kMaxUnitBytes) scan_lzma2(s.in, s.in_len, lu, mx);
+    // (a stream with more room than a unit can address is dealt whole: its last slice would inherit that room and run as a
+    //  session, which knows no slices -- ADVICE r4)
+    if (pieces >= 2 && s.in_len <= kMaxUnitBytes && s.out_cap <= kMaxUnitBytes) scan_lzma2(s.in, s.in_len, lu, mx);
     uint64_t announced = 0;
     for (const Lz2Unit &u : lu) announced += u.expect_out;
     if (lu.size() < 2 || announced > s.out_cap) { // one unit, or the caller's room is short of the headers: whole
@@ -2502,6 +2592,10 @@ int sessions_step(xlz_ctx *ctx, const std::vector<xlz_reader *> &all)
 {
     if (all.empty()) return XLZ_OK;
     std::lock_guard<std::mutex> lock(ctx->mu);
+    // (every way out of this function leaves a status in every reader: the batcher looks at nothing else -- ADVICE r4: an
+    //  early return in front of the first assignment left the readers at their previous XLZ_OK, reader_refill came back
+    //  with an empty chunk and xlz_reader_read span)
+    for (xlz_reader *r : all) r->step_status = XLZ_ERR_DEVICE;
     HIP_TRY(hipSetDevice(ctx->device));
     std::vector<xlz_reader *> normal, bigs; // one that cannot be prepared ends alone
     for (xlz_reader *r : all) {

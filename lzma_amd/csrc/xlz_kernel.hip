@@ -1057,8 +1057,12 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
             // NewReader1ForReader2 / Renew: props from header[5] (reader2.go:146-165)
             if (w.h5 >= 225) return ST_ERR_PROPS; // DecodeProp, reader1.go:211-213
             const uint32_t lc = w.h5 % 9, r = w.h5 / 9, lp = r % 5, pb = r / 5;
-            if (lc + lp > max_lc_lp || lc + lp > w.model_lc_lp)
-                return ST_ERR_UNSUPPORTED; // LDS / the saved state are sized by the host's header scan
+            if (lc + lp > max_lc_lp || lc + lp > w.model_lc_lp) {
+                // LDS / the saved state are sized by the host's header scan; AUX_GROW tells the host that a launch with
+                // room for this model would go on (and not, say, a full epoch table: ADVICE r4)
+                aux = (aux & ~AUX_GROW_MASK) | AUX_GROW | ((lc + lp) << AUX_GROW_SHIFT);
+                return ST_ERR_UNSUPPORTED;
+            }
             d.lc = lc;
             d.lp_mask = (1u << lp) - 1;
             d.pos_mask = (1u << pb) - 1;
@@ -1444,18 +1448,19 @@ uint32_t decode_grid(uint32_t max_lc_lp, int num_cus, uint32_t n_units)
     return decode_per_cu(max_lc_lp, n_units, num_cus) * (uint32_t)num_cus;
 }
 
-int launch_decode(const LaunchParams &p, int num_cus, void *stream)
+int launch_decode(const LaunchParams &p, int num_cus, void *stream, uint32_t max_grid)
 {
     if (p.scratch) { // HBM-resident model
         uint32_t grid = big_model_grid(num_cus);
         if (grid > p.n_units) grid = p.n_units;
+        if (max_grid && grid > max_grid) grid = max_grid; // (the caller allocated scratch slots for that many workgroups)
         if (grid == 0) return 0;
         hipLaunchKernelGGL(xlz_decode_kernel_hbm_model, dim3(grid), dim3(kWave), 0, (hipStream_t)stream, p);
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
     const uint32_t lds = decode_lds_bytes(p.max_lc_lp);
     if (lds > kMaxLdsBytes) return -1;
-    uint32_t grid = decode_grid(p.max_lc_lp, num_cus, p.n_units);
+    uint32_t grid = decode_grid(p.max_lc_lp, num_cus, p.many_rounds ? ~0u : p.n_units);
     if (grid > p.n_units) grid = p.n_units;
     if (grid == 0) return 0;
     if (lds > 64u * 1024u &&

@@ -1,5 +1,5 @@
 """Test infrastructure: a minimal .7z WRITER (7-Zip's published 7zFormat.txt restated), used to build
-the archives the .7z front-end is tested on -- the image has no 7z tool and no py7zr.  Folders hold
+most of the archives the .7z front-end is tested on (test_7z_container.py also writes archives with libarchive, through cmake).  Folders hold
 ONE coder each (LZMA, LZMA2 or Copy), which is what the reference's sevenzip constructors take
 (reader1.go:28-61, reader2.go:45-75); solid folders with several files, per-file CRCs, plain and
 encoded (LZMA-compressed) headers."""

@@ -1,7 +1,7 @@
 """The .7z front-end (include/xlz.h: xlz_7z_index / xlz_7z_decode).
-The archives are hand-built by tests/sevenzip_craft.py from 7-Zip's published format description
-(no 7z tool and no py7zr in the image); the packed streams come from liblzma, so the expected output
-of every folder is known.  CPU: the index.  GPU: whole archives as one batch, CRC verification,
+Most archives are hand-built by tests/sevenzip_craft.py from 7-Zip's published format description; the
+packed streams come from liblzma, so the expected output of every folder is known.  Since round 5 also
+archives by an independent writer: libarchive's 7zip writer, driven by `cmake -E tar` (bottom of the file).  CPU: the index.  GPU: whole archives as one batch, CRC verification,
 encoded headers, and the same folders through the reference's sevenzip constructors."""
 import struct
 import zlib
@@ -206,3 +206,109 @@ def test_container_fuzz_with_decode(ctx):
     spec.loader.exec_module(mod)
     n, n_ok, _ = mod.fuzz(ctx, 6.0, 20251006, verbose=False)
     assert n > 200 and n_ok > 10
+
+
+# ---- archives by an INDEPENDENT writer: libarchive's 7zip writer through `cmake -E tar` --------------------
+def _golden_libarchive():
+    import json
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return open(os.path.join(g, "libarchive_solid.7z"), "rb").read(), json.load(open(os.path.join(g, "libarchive_solid.json")))
+
+
+def _check_index(folders, subs, total, exp):
+    assert total == exp["folder"]["unpack_size"] and len(folders) == 1
+    f = folders[0]
+    props = bytes.fromhex(exp["folder"]["props"])
+    assert f["method"] == 1 and f["props"] == props[0] and f["dict_size"] == struct.unpack("<I", props[1:5])[0]
+    assert (f["pack_off"], f["pack_len"], f["unpack_len"]) == (exp["folder"]["pack_off"], exp["folder"]["pack_len"], total)
+    assert f["n_substreams"] == len(exp["substreams"]) and subs == [tuple(x) for x in exp["substreams"]]
+
+
+def test_an_archive_written_by_libarchive_parses_like_its_own_index():
+    """tests/golden/libarchive_solid.7z was written by cmake's bundled libarchive (tests/golden/make_libarchive_7z.py): a
+    solid LZMA1 folder (coder 03 01 01, props 5d 00 00 80 00 = lc3 lp0 pb2, 8 MiB dictionary) of four files + an empty one,
+    an LZMA-ENCODED header, per-file CRCs.  CPU: the independent plain-Python reader (tests/sevenzip_read.py) and liblzma
+    reproduce the committed index and content; the PRODUCT's parser reads the same index from the archive with its header
+    stored plainly (an encoded header is a stream like any other: it needs the device -- the GPU test does that)."""
+    import hashlib
+    import sevenzip_read
+    a, exp = _golden_libarchive()
+    assert len(a) == exp["archive_bytes"]
+    r = sevenzip_read.read(a)
+    assert r["encoded"] == exp["encoded_header"]
+    m = r["main"]
+    f = m["folders"][0]
+    assert f["method"].hex() == exp["folder"]["method"] and f["props"].hex() == exp["folder"]["props"]
+    assert [list(x) for x in m["substreams"][0]] == exp["substreams"]
+    packed = a[32 + m["pack_pos"]: 32 + m["pack_pos"] + m["pack_sizes"][0]]
+    content = sevenzip_read.lzma1_decode(packed, f["props"], f["unpack_size"])
+    assert hashlib.sha256(content).hexdigest() == exp["sha256"]
+    at = 0
+    for size, crc in exp["substreams"]:
+        assert zlib.crc32(content[at:at + size]) == crc
+        at += size
+    _check_index(*lzma_amd.sevenzip_index(sevenzip_read.with_plain_header(a)), exp)
+    with pytest.raises(LzmaError):      # the encoded header itself: no device, no decode -- loudly
+        import torch
+        if torch.cuda.is_available():
+            raise LzmaError(lzma_amd.ERR_DEVICE, "(a GPU is present: the GPU test covers this)")
+        lzma_amd.sevenzip_index(a)
+
+
+def _cmake_7z(files, tmp_path, name):
+    """[(name, bytes)] -> the bytes of a .7z written by cmake / libarchive (entries in the order given)"""
+    import shutil
+    import subprocess
+    if not shutil.which("cmake"):
+        pytest.skip("no cmake on this box: nothing here writes a .7z archive")
+    d = tmp_path / name
+    d.mkdir()
+    for n, b in files:
+        (d / n).write_bytes(b)
+    out = tmp_path / (name + ".7z")
+    subprocess.check_call(["cmake", "-E", "tar", "cf", str(out), "--format=7zip"] + [n for n, _ in files], cwd=str(d))
+    return out.read_bytes()
+
+
+@pytest.mark.gpu
+def test_archives_written_by_libarchive_decode(ctx, tmp_path):
+    """the .7z front-end on archives the test suite did NOT write itself.  The committed fixture and three
+    archives written here by cmake's libarchive from seeded files -- one file; 300 small files in one solid folder; 20 MiB
+    of far-reaching matches so that the folder's 8 MiB dictionary wraps -- through xlz_7z_decode (CRCs verified, the encoded
+    header decoded on the device) and through the reference's plugin entry, NewLZMADecompressorForSevenZip(props,
+    unpackSize, readers) (reader1.go:28-61), folder by folder as bodgit/sevenzip calls it."""
+    import hashlib
+    a, exp = _golden_libarchive()
+    _check_index(*lzma_amd.sevenzip_index(a, ctx), exp)
+    assert hashlib.sha256(lzma_amd.sevenzip_decode(ctx, a, verify=True)).hexdigest() == exp["sha256"]
+    cases = {
+        "one": [("only.txt", corpus.plain("T", 8101, 400_000))],
+        "many": [("f%03d.%s" % (i, "txt" if i % 3 else "bin"), corpus.plain("TRMZ"[i % 4], 8200 + i, 50 + 97 * i)) for i in range(300)],
+        "wrap": [("far.bin", corpus.plain_far(8301, 12 << 20)), ("text.txt", corpus.plain("T", 8302, 8 << 20))],
+    }
+    for name, files in cases.items():
+        arch = _cmake_7z(files, tmp_path, name)
+        want = b"".join(b for _, b in files)
+        folders, subs, total = lzma_amd.sevenzip_index(arch, ctx)
+        assert total == len(want), name
+        assert subs == [(len(b), zlib.crc32(b)) for _, b in files if b], name
+        assert lzma_amd.sevenzip_decode(ctx, arch, verify=True) == want, name
+        out = b""
+        for f in folders:   # the reference's own plugin surface
+            assert f["method"] == 1, (name, f)
+            packed = arch[f["pack_off"]: f["pack_off"] + f["pack_len"]]
+            r, err = lzma_amd.NewLZMADecompressorForSevenZip(ctx, bytes([f["props"]]) + struct.pack("<I", f["dict_size"]),
+                                                             f["unpack_len"], [packed])
+            assert err is None
+            b, e = r.read_all()
+            assert e is None and r.Close() is None
+            out += b
+        assert out == want, name
+        if name == "wrap":
+            assert folders[0]["dict_size"] == 8 << 20 and folders[0]["unpack_len"] > 2 * folders[0]["dict_size"]
+    # a damaged folder is caught by the CRCs libarchive wrote
+    bad = bytearray(a)
+    bad[exp["folder"]["pack_off"] + exp["folder"]["pack_len"] // 2] ^= 0x20
+    with pytest.raises(LzmaError):
+        lzma_amd.sevenzip_decode(ctx, bytes(bad), verify=True)

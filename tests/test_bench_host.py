@@ -133,7 +133,7 @@ def test_the_bench_line_is_compact_and_round_trips():
                                    "break_even_streams": 256, "note": "n" * 200},
             "containers": [{"name": "xz-blocks", "value": 4.31, "workload": "w" * 300}],
             "configs": [{"name": n, "workload": bench.workload_text(n, bench.CONFIGS[n]), "baseline_config": bench.CONFIGS[n]["baseline"],
-                         "value": 17.2412, "kernel_ms": 232.123, "roofline": _stub_roofline(n), "cpu_baseline": dict(cpu)}
+                         "value": 17.2412, "value_wall": 17.1234, "kernel_ms": 232.123, "roofline": _stub_roofline(n), "cpu_baseline": dict(cpu)}
                         for n in bench.SIDE_ALL]}
     assert len(json.dumps(full)) > 20000          # the detail record is the big one ...
     line = bench.compact_line(full, "bench_detail.json")
@@ -154,7 +154,9 @@ def test_the_bench_line_is_compact_and_round_trips():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in back["cpu_baseline"], k
     assert [c["name"] for c in back["configs"]] == bench.SIDE_ALL
-    assert all(set(c) == {"name", "value", "kernel_ms", "frac", "frac_of_bound", "binding", "cpu", "cpu_cores"} for c in back["configs"])
+    # (value = bytes / HIP-event time, value_wall = bytes / host wall time: ADVICE r4 -- two definitions, two keys)
+    assert all(set(c) == {"name", "value", "value_wall", "kernel_ms", "frac", "frac_of_bound", "binding", "cpu", "cpu_cores"} for c in back["configs"])
+    assert "value_wall" in back["configs_unit"]
     # an N > 1 line (no side configs, no cpu baseline) is a valid line too
     multi = dict(full, n_gpus=8, cpu_baseline=None, configs=None, host_to_host=None, stream_count_sweep=None, containers=None)
     small = bench.compact_line(multi)

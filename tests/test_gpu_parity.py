@@ -758,3 +758,31 @@ def test_large_mixed_call_of_decode_batch(ctx):
         for i, (g, w) in enumerate(zip(got, want)):
             assert g[1] == w[1], (i, g[1], w[1])
             assert g[0] == w[0], i
+
+
+def test_descriptor_flags_and_reserved_bytes_are_checked(ctx):
+    """`flags` was a reserved byte before round 4.  Unknown flag bits, the LZMA2 slice flag on a format that has
+    no slices and non-zero reserved bytes fail the CALL with XLZ_ERR_BAD_ARG instead of silently changing what a stream
+    means; a zeroed descriptor decodes."""
+    import ctypes
+    from lzma_amd import _native as N
+    from lzma_amd import ERR_BAD_ARG
+    p = corpus.plain("T", 77, 3000)
+    c = corpus.compress_alone(p)
+    buf = ctypes.create_string_buffer(c, len(c))
+    out = ctypes.create_string_buffer(len(p))
+
+    def call(flags=0, reserved=0, fmt=FMT_LZMA_ALONE):
+        d = (N.StreamDesc * 1)()
+        d[0].inp, d[0].in_len = ctypes.cast(buf, ctypes.c_void_p), len(c)
+        d[0].out, d[0].out_cap = ctypes.cast(out, ctypes.c_void_p), len(p)
+        d[0].format, d[0].flags = fmt, flags
+        d[0].reserved[5] = reserved
+        r = (N.Result * 1)()
+        return N.lib().xlz_decode_batch(ctx._h, d, 1, r), r[0].status
+
+    assert call() == (0, 0) and out.raw == p
+    assert call(flags=1)[0] == ERR_BAD_ARG          # a slice of an LZMA1 stream does not exist
+    assert call(flags=2)[0] == ERR_BAD_ARG          # no such flag
+    assert call(reserved=7)[0] == ERR_BAD_ARG
+    assert call(flags=1, fmt=lzma_amd.FMT_LZMA2_RAW)[0] == 0   # (the call runs; what the bytes decode to is another matter)

@@ -1,6 +1,6 @@
 """Dev tool (GPU box): host-buffers-in, host-buffers-out rate of xlz_decode_batch (the PCIe-inclusive path that a
 drop-in caller sees) for several settings of the sliced form (xlz_ctx_set_slicing), with the call's phase times.
-usage: python tools/host_path.py [family] [streams] [size] [distinct] [--slices 1,4,8] [--reps 4] [--preset6]
+usage: python tools/host_path.py [family] [streams] [size] [distinct] [--slices 0,1,4,8] [--reps 4] [--preset6]   (0: the library's default rule)
 The corpus is bench.py's (liblzma MODE_FAST / HC3) unless --preset6."""
 import hashlib, os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,7 +33,10 @@ for i in range(n):
     descs[i].format = lzma_amd.FMT_LZMA_ALONE
 res = (N.Result * n)()
 for k in slices:
-    ctx.set_slicing(1 if k > 1 else 0, max(1, n * size // max(k, 1)), k)
+    if k == 0:
+        ctx.set_slicing(0, 0, 0)   # the library's defaults
+    else:
+        ctx.set_slicing(1 if k > 1 else 0, max(1, n * size // max(k, 1)), k)
     times = []
     for rep in range(reps + 1):
         out[:] = 0
