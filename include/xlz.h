@@ -190,7 +190,7 @@ typedef struct xlz_call_stats {
     double decode_ms;      /* decode launch(es) until the per-stream results are on the host        */
     double download_ms;    /* device -> host and scatter into the callers' buffers                  */
     double total_ms;
-    double kernel_span_ms; /* first wave's start to last wave's end of the main launch (device clock) */
+    double kernel_span_ms; /* first wave's start to last wave's end over all launches of the call (device clock) */
     double slot_occupancy; /* busy wave time / (wave_slots x kernel span): 1.0 = every slot busy throughout */
     uint64_t streams;      /* n of the call                                                          */
     uint64_t units;        /* work units of the main launch (streams; LZMA2: dictionary-reset units and
@@ -207,6 +207,10 @@ typedef struct xlz_call_stats {
     uint32_t reserved;
 } xlz_call_stats;
 int xlz_ctx_last_call_stats(xlz_ctx *ctx, xlz_call_stats *out);
+/* xlz_decode_batch keeps the device and pinned memory of its (sub-)batches in the context between calls (a
+ * call of the same shape finds its blocks again; what two calls in a row did not use is released by
+ * itself).  xlz_ctx_trim releases all of it now; *released (may be NULL) = the bytes given back.      */
+int xlz_ctx_trim(xlz_ctx *ctx, uint64_t *released);
 /* Tuning of xlz_decode_batch's sliced form (xlz_call_stats.slices): a call of one wave round with at least
  * min_call_bytes of output room runs as one launch for every slice_bytes of it, at most max_slices (<= 64).
  * 0 = the default of that argument (256 MiB, 128 MiB, 8); max_slices = 1 turns slicing off.  The decoded

@@ -91,6 +91,14 @@ class Context:
         if st != OK:
             raise LzmaError(st, "xlz_ctx_set_slicing")
 
+    def trim(self):
+        """release the device / pinned memory decode_batch keeps between calls (xlz_ctx_trim) -> bytes released"""
+        n = ctypes.c_uint64()
+        st = N.lib().xlz_ctx_trim(self._h, ctypes.byref(n))
+        if st != OK:
+            raise LzmaError(st, "xlz_ctx_trim")
+        return n.value
+
     def event_record(self, slot):
         st = N.lib().xlz_ctx_event_record(self._h, slot)
         if st != OK:

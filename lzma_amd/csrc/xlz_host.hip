@@ -74,6 +74,96 @@ struct xlz_reader;
 struct Batcher;
 static void batcher_shutdown(Batcher *bt); // defined next to the readers
 
+// Device (and pinned) memory of the (sub-)batches xlz_decode_batch makes is kept by the context between calls: a call of
+// nine sub-batches makes and drops some sixty allocations, hipFree waits for the device every time, and the next call of
+// the same shape wants the same sizes again.  A block is reused for a request of at least two thirds of its size; what
+// two calls in a row did not touch is released (trim), xlz_ctx_trim releases everything.  Batches made through the
+// public xlz_batch_create are not pooled (they live as long as their owner wants).
+struct MemPool {
+    struct Blk {
+        void *p;
+        size_t cap;
+        uint64_t gen;
+        bool pinned;
+    };
+    std::mutex mu;
+    std::vector<Blk> idle;
+    std::vector<Blk> live;
+    uint64_t gen = 1;
+    void *take(size_t n, bool pinned)
+    {
+        if (n == 0) n = 1;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].pinned == pinned && idle[i].cap >= n && idle[i].cap <= n + n / 2 + (1u << 16) &&
+                    (best == idle.size() || idle[i].cap < idle[best].cap))
+                    best = i;
+            if (best != idle.size()) {
+                Blk b = idle[best];
+                idle.erase(idle.begin() + (long)best);
+                b.gen = gen;
+                live.push_back(b);
+                return b.p;
+            }
+        }
+        void *p = nullptr;
+        const hipError_t e = pinned ? hipHostMalloc(&p, n, hipHostMallocDefault) : hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            drop_idle(); // the cache may be what is in the way: release it and try once more
+            if ((pinned ? hipHostMalloc(&p, n, hipHostMallocDefault) : hipMalloc(&p, n)) != hipSuccess) return nullptr;
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        live.push_back(Blk{p, n, gen, pinned});
+        return p;
+    }
+    void give(void *p) // (the caller knows that no work on the device still uses the block)
+    {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < live.size(); i++)
+            if (live[i].p == p) {
+                idle.push_back(live[i]);
+                live.erase(live.begin() + (long)i);
+                return;
+            }
+    }
+    void end_of_call() // a call is over: blocks that this call and the one before did not use go back to the system
+    {
+        std::vector<Blk> out;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < idle.size();)
+                if (idle[i].gen + 1 < gen) {
+                    out.push_back(idle[i]);
+                    idle.erase(idle.begin() + (long)i);
+                } else {
+                    i++;
+                }
+            gen++;
+        }
+        for (const Blk &b : out) (void)(b.pinned ? hipHostFree(b.p) : hipFree(b.p));
+    }
+    void drop_idle()
+    {
+        std::vector<Blk> out;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            out.swap(idle);
+        }
+        for (const Blk &b : out) (void)(b.pinned ? hipHostFree(b.p) : hipFree(b.p));
+    }
+    uint64_t idle_bytes()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        uint64_t t = 0;
+        for (const Blk &b : idle) t += b.cap;
+        return t;
+    }
+};
+
 // Host side of the boundary (host buffers in, host buffers out): pinned staging that lives as
 // long as the context, so that neither page pinning nor pageable copies sit on the path.
 //  * input: one grow-only pinned image, packed by several host threads, one async H2D copy;
@@ -138,6 +228,7 @@ struct xlz_ctx {
     hipEvent_t ev[kEventSlots] = {};
     std::mutex mu;
     HostPipe pipe;
+    MemPool pool; // device / pinned blocks of xlz_decode_batch's (sub-)batches, kept between calls
     xlz_call_stats last_call = {}; // of the most recent xlz_decode_batch on this context (xlz_ctx_last_call_stats)
     bool have_last_call = false;
     // xlz_ctx_set_slicing: when a call of one wave round runs as a sequence of launches, and as how many
@@ -183,6 +274,8 @@ struct xlz_batch {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t run_stream = nullptr; // where the batch's launches go (the context's stream, or its second one)
     uint32_t *queue = nullptr;        // ... and their work-queue head
+    bool pooled = false;      // made by xlz_decode_batch: its memory comes from and returns to the context's pool
+    bool quiet = false;       // ... and nothing on the device uses it any more (else batch_free waits for the device first)
     bool many_rounds = false; // a sub-batch of a pipelined call: the launch takes as many wave slots as a call of many rounds
     bool ran = false;
     uint64_t algo_in = 0; // compressed payload bytes handed to the device
@@ -354,6 +447,7 @@ extern "C" void xlz_ctx_destroy(xlz_ctx *c)
     if (!c) return;
     if (c->batcher) batcher_shutdown(c->batcher);
     (void)hipSetDevice(c->device);
+    c->pool.drop_idle();
     if (c->queue) (void)hipFree(c->queue);
     if (c->queue2) (void)hipFree(c->queue2);
     if (c->prio_tab) (void)hipFree(c->prio_tab);
@@ -640,30 +734,50 @@ extern "C" int xlz_batch_advice(const xlz_ctx *ctx, const xlz_stream_desc *strea
 
 namespace {
 
+// memory of a batch: the context's pool for the batches xlz_decode_batch makes, the runtime otherwise
+template <class T> bool batch_alloc(xlz_batch *b, T **p, size_t bytes, bool pinned = false)
+{
+    if (b->pooled) {
+        *p = static_cast<T *>(b->ctx->pool.take(bytes, pinned));
+        return *p != nullptr;
+    }
+    return (pinned ? hipHostMalloc(reinterpret_cast<void **>(p), bytes, hipHostMallocDefault) : hipMalloc(reinterpret_cast<void **>(p), bytes)) ==
+           hipSuccess;
+}
+void batch_release(xlz_batch *b, void *p, bool pinned = false)
+{
+    if (!p) return;
+    if (b->pooled)
+        b->ctx->pool.give(p);
+    else
+        (void)(pinned ? hipHostFree(p) : hipFree(p));
+}
+
 int batch_free(xlz_batch *b)
 {
     if (!b) return XLZ_OK;
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
-    if (b->d_in) (void)hipFree(b->d_in);
-    if (b->d_out) (void)hipFree(b->d_out);
-    if (b->d_units) (void)hipFree(b->d_units);
-    if (b->d_order) (void)hipFree(b->d_order);
-    if (b->d_results) (void)hipFree(b->d_results);
-    if (b->d_scratch) (void)hipFree(b->d_scratch);
-    if (b->d_mlit) (void)hipFree(b->d_mlit);
+    if (b->pooled && !b->quiet) (void)hipDeviceSynchronize(); // (a block must not return to the pool while work still uses it)
+    batch_release(b, b->d_in);
+    batch_release(b, b->d_out);
+    batch_release(b, b->d_units);
+    batch_release(b, b->d_order);
+    batch_release(b, b->d_results);
+    batch_release(b, b->d_scratch);
+    batch_release(b, b->d_mlit);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     for (hipEvent_t e : b->slice_ev)
         if (e) (void)hipEventDestroy(e);
-    if (b->d_stage) (void)hipFree(b->d_stage); // (hipFree waits for the device: a pending upload has left the pinned image)
-    if (b->d_up_pieces) (void)hipFree(b->d_up_pieces);
+    batch_release(b, b->d_stage); // (hipFree waits for the device: a pending upload has left the pinned image)
+    batch_release(b, b->d_up_pieces);
     if (b->ev_heads) (void)hipEventDestroy(b->ev_heads);
     if (b->ev_tails) (void)hipEventDestroy(b->ev_tails);
     b->in_lease.release();
-    if (b->d_states) (void)hipFree(b->d_states);
-    if (b->d_pieces) (void)hipFree(b->d_pieces);
-    if (b->d_pack) (void)hipFree(b->d_pack);
-    if (b->pin_res) (void)hipHostFree(b->pin_res);
+    batch_release(b, b->d_states);
+    batch_release(b, b->d_pieces);
+    batch_release(b, b->d_pack);
+    batch_release(b, b->pin_res, true);
     delete b;
     return XLZ_OK;
 }
@@ -678,6 +792,7 @@ struct BatchOpts {
     uint32_t want_slices = 1;
     uint32_t head_frac = 0;
     bool many_rounds = false;        // xlz_batch::many_rounds
+    bool pooled = false;             // xlz_batch::pooled
     hipStream_t run_stream = nullptr; // xlz_batch::run_stream / queue (nullptr: the context's)
     uint32_t *queue = nullptr;
 };
@@ -713,6 +828,7 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
     b->n = n;
     b->plans.resize(n);
     b->many_rounds = opts.many_rounds;
+    b->pooled = opts.pooled;
     b->run_stream = opts.run_stream;
     b->queue = opts.queue;
 
@@ -838,25 +954,24 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
         batch_free(b);
         return st;
     };
-    if (hipMalloc(&b->d_in, b->in_bytes) != hipSuccess) return fail(XLZ_ERR_DEVICE);
-    if (hipMalloc(&b->d_out, b->out_bytes) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+    if (!batch_alloc(b, &b->d_in, b->in_bytes)) return fail(XLZ_ERR_DEVICE);
+    if (!batch_alloc(b, &b->d_out, b->out_bytes)) return fail(XLZ_ERR_DEVICE);
     if (nu) {
-        if (hipMalloc(&b->d_units, nu * sizeof(Unit)) != hipSuccess) return fail(XLZ_ERR_DEVICE);
-        if (hipMalloc(&b->d_order, nu * sizeof(uint32_t)) != hipSuccess) return fail(XLZ_ERR_DEVICE);
-        if (hipMalloc(&b->d_results, nu * sizeof(UnitResult)) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+        if (!batch_alloc(b, &b->d_units, nu * sizeof(Unit))) return fail(XLZ_ERR_DEVICE);
+        if (!batch_alloc(b, &b->d_order, nu * sizeof(uint32_t))) return fail(XLZ_ERR_DEVICE);
+        if (!batch_alloc(b, &b->d_results, nu * sizeof(UnitResult))) return fail(XLZ_ERR_DEVICE);
     }
     if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess)
         return fail(XLZ_ERR_DEVICE);
     if (b->n_normal < nu) { // some models live in HBM: one scratch slot per workgroup of that launch
         b->scratch_stride = num_probs(b->max_lc_lp_big) + num_matched_probs(b->max_lc_lp_big);
-        if (hipMalloc(&b->d_scratch, (size_t)big_model_grid(ctx->num_cus) * b->scratch_stride * sizeof(uint16_t)) !=
-            hipSuccess)
+        if (!batch_alloc(b, &b->d_scratch, (size_t)big_model_grid(ctx->num_cus) * b->scratch_stride * sizeof(uint16_t)))
             return fail(XLZ_ERR_DEVICE);
     }
     if (b->n_normal) { // the matched-literal half of every resident model (xlz_format.h)
         b->mlit_stride = num_matched_probs(b->max_lc_lp);
         const size_t slots = (size_t)decode_grid(b->max_lc_lp, ctx->num_cus, ~0u);
-        if (hipMalloc(&b->d_mlit, slots * b->mlit_stride * sizeof(uint16_t)) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+        if (!batch_alloc(b, &b->d_mlit, slots * b->mlit_stride * sizeof(uint16_t))) return fail(XLZ_ERR_DEVICE);
     }
     if (want_slices > 1 && nu && b->n_normal == nu && nu <= decode_grid(b->max_lc_lp, ctx->num_cus, b->many_rounds ? ~0u : (uint32_t)nu)) {
         // sliced batch: equal shares of every unit's output per launch; a state block per unit; per launch the table of
@@ -864,7 +979,7 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
         const uint32_t K = std::min<uint32_t>(want_slices, 64);
         for (uint32_t k = 1; k <= K; k++) b->slice_fracs.push_back(k == K ? kSliceOne : (uint32_t)((uint64_t)kSliceOne * k / K));
         b->state_stride = align_up(state_bytes(b->max_lc_lp), kArenaAlign);
-        if (hipMalloc(&b->d_states, nu * b->state_stride) != hipSuccess) return fail(XLZ_ERR_DEVICE);
+        if (!batch_alloc(b, &b->d_states, nu * b->state_stride)) return fail(XLZ_ERR_DEVICE);
         for (size_t k = 0; k < nu; k++) b->units[k].state = (uint64_t)(uintptr_t)(b->d_states + k * b->state_stride);
         b->slice_pieces.resize(K);
         b->slice_pack_bytes.assign(K, 0);
@@ -890,9 +1005,9 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
         b->slice_ev.assign(K, nullptr);
         for (uint32_t k = 0; k < K; k++)
             if (hipEventCreateWithFlags(&b->slice_ev[k], hipEventDisableTiming) != hipSuccess) return fail(XLZ_ERR_DEVICE);
-        if (hipMalloc(&b->d_pieces, std::max<size_t>(total_pieces, 1) * sizeof(SlicePiece)) != hipSuccess ||
-            hipMalloc(&b->d_pack, (size_t)max_pack + kArenaAlign) != hipSuccess ||
-            hipHostMalloc(&b->pin_res, (size_t)K * nu * sizeof(UnitResult), hipHostMallocDefault) != hipSuccess)
+        if (!batch_alloc(b, &b->d_pieces, std::max<size_t>(total_pieces, 1) * sizeof(SlicePiece)) ||
+            !batch_alloc(b, &b->d_pack, (size_t)max_pack + kArenaAlign) ||
+            !batch_alloc(b, &b->pin_res, (size_t)K * nu * sizeof(UnitResult), true))
             return fail(XLZ_ERR_DEVICE);
         size_t at = 0;
         for (uint32_t k = 0; k < K; k++) {
@@ -924,8 +1039,8 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
         }
         A = align_up(A, kArenaAlign);
         B = align_up(B, kArenaAlign);
-        if (hipMalloc(&b->d_stage, A + B + kArenaAlign) != hipSuccess ||
-            hipMalloc(&b->d_up_pieces, std::max<size_t>(heads->size() + tails->size(), 1) * sizeof(SlicePiece)) != hipSuccess ||
+        if (!batch_alloc(b, &b->d_stage, A + B + kArenaAlign) ||
+            !batch_alloc(b, &b->d_up_pieces, std::max<size_t>(heads->size() + tails->size(), 1) * sizeof(SlicePiece)) ||
             hipEventCreateWithFlags(&b->ev_heads, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&b->ev_tails, hipEventDisableTiming) != hipSuccess)
             return fail(XLZ_ERR_DEVICE);
@@ -1765,29 +1880,27 @@ int download_sliced(xlz_batch *b, const xlz_stream_desc *streams, std::vector<do
 
 static int decode_oversize(xlz_ctx *ctx, const xlz_stream_desc *streams, xlz_result *results, const std::vector<size_t> &idx);
 
-// busy wave time / (wave slots x launch span) of a batch's last main launch, from the units' s_memrealtime stamps
-static void launch_occupancy(xlz_batch *b, xlz_call_stats &cs)
-{
-    uint32_t slots = 0;
-    (void)xlz_batch_launch_info(b, &slots, nullptr);
-    cs.wave_slots = slots;
-    cs.units = b->unit_results.size();
-    cs.slot_occupancy = 0;
-    cs.kernel_span_ms = 0;
-    if (b->unit_results.empty() || slots == 0) return;
-    uint32_t t0 = b->unit_results[0].t_start;
-    for (const UnitResult &u : b->unit_results)
-        if ((int32_t)(u.t_start - t0) < 0) t0 = u.t_start;
+// Wave-slot bookkeeping of a call from the units' s_memrealtime stamps (100 MHz, the same clock for every launch of the
+// device): busy wave time, first start and last end over ALL sub-batches of the call -- their launches overlap on two
+// streams, so a sub-batch's own span says little; the call's occupancy = busy / (wave slots x (last end - first start)).
+struct SlotClock {
+    bool any = false;
+    uint32_t ref = 0;        // the first stamp seen: everything else relative to it (the 32-bit clock wraps every 43 s)
+    int64_t first = 0, last = 0;
     uint64_t busy = 0;
-    uint32_t span = 0;
-    for (const UnitResult &u : b->unit_results) {
-        busy += (uint32_t)(u.t_end - u.t_start);
-        span = std::max(span, (uint32_t)(u.t_end - t0));
+    void add(const std::vector<UnitResult> &ur)
+    {
+        for (const UnitResult &u : ur) {
+            if (!any) ref = u.t_start, first = 0, last = 0, any = true;
+            const int64_t a = (int32_t)(u.t_start - ref), e = (int32_t)(u.t_end - ref);
+            first = std::min(first, a);
+            last = std::max(last, e);
+            busy += (uint32_t)(u.t_end - u.t_start);
+        }
     }
-    if (span == 0) return;
-    cs.kernel_span_ms = span / 1e5; // 100 MHz ticks
-    cs.slot_occupancy = (double)busy / ((double)slots * span);
-}
+    double span_ms() const { return any ? (double)(last - first) / 1e5 : 0.0; }
+    double occupancy(uint32_t slots) const { return any && slots && last > first ? (double)busy / ((double)slots * (double)(last - first)) : 0.0; }
+};
 
 extern "C" int xlz_ctx_set_slicing(xlz_ctx *ctx, uint64_t min_call_bytes, uint64_t slice_bytes, uint32_t max_slices)
 {
@@ -1796,6 +1909,15 @@ extern "C" int xlz_ctx_set_slicing(xlz_ctx *ctx, uint64_t min_call_bytes, uint64
     ctx->sliced_call_bytes = min_call_bytes ? min_call_bytes : kSlicedCallBytes;
     ctx->slice_bytes = slice_bytes ? slice_bytes : kSliceBytes;
     ctx->max_slices = max_slices ? std::min<uint32_t>(max_slices, 64) : (uint32_t)kMaxSlices;
+    return XLZ_OK;
+}
+
+extern "C" int xlz_ctx_trim(xlz_ctx *ctx, uint64_t *released)
+{
+    if (!ctx) return XLZ_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (released) *released = ctx->pool.idle_bytes();
+    ctx->pool.drop_idle();
     return XLZ_OK;
 }
 
@@ -1808,10 +1930,12 @@ extern "C" int xlz_ctx_last_call_stats(xlz_ctx *ctx, xlz_call_stats *out)
     return XLZ_OK;
 }
 
-// Where a call of several wave rounds is cut into sub-batches whose upload, decode and download overlap: equal
-// shares of the output, each at least one wave round of streams and a quarter of a GiB, at most sixteen (what stays
-// exposed is the first sub-batch's upload and the last one's download: the smaller they are, the less; the launches of
-// consecutive sub-batches overlap on two streams, so a sub-batch need not be a whole number of rounds).  One sub-batch =
+// Where a call of several wave rounds is cut into sub-batches whose upload, decode and download overlap: up to eight
+// equal shares of the output, each at least one wave round of streams and half a GiB -- and in front of and behind them a
+// piece a quarter that size: what stays exposed is the first piece's upload and the last one's download, and the launches
+// of consecutive pieces overlap on two streams (xlz_ctx: stream2), so a small piece costs no idle wave slots.  (Sixteen
+// equal pieces of 4096 streams were measured on the 65 536 x 64 KiB batch: 6 % slower than eight -- while piece k drains
+// only piece k + 1 can fill its slots, and 4096 units do not fill 5120; profiles/r05/pipeline_pieces.txt.)  One sub-batch =
 // the call is one wave round (or too small to bother): it overlaps its copies with its own decode (slices).
 static void plan_sub_batches(const xlz_stream_desc *streams, size_t n, std::vector<size_t> &cuts)
 {
@@ -1819,14 +1943,21 @@ static void plan_sub_batches(const xlz_stream_desc *streams, size_t n, std::vect
     uint64_t total = 0;
     for (size_t i = 0; i < n; i++) total += streams[i].out_cap;
     const size_t k_round = 4096; // streams of one wave round (16 waves on each of 256 CUs)
-    size_t n_sub = std::min<size_t>(std::min<size_t>(16, n / k_round), (size_t)(total >> 28));
-    if (total < (1ull << 30)) n_sub = 1; // (below a GiB a call is one sub-batch, as before)
+    const size_t n_sub = std::min<size_t>(std::min<size_t>(8, n / k_round), (size_t)(total >> 29));
     if (n_sub >= 2) {
+        // shares: 1/4, 1, ..., 1, 1/4 (n_sub - 1 whole ones)
+        const double whole = (double)total / ((double)(n_sub - 1) + 0.5);
+        std::vector<double> bounds; // cumulative output at which a piece ends
+        double acc_b = whole / 4;
+        bounds.push_back(acc_b);
+        for (size_t k = 0; k + 1 < n_sub; k++) bounds.push_back(acc_b += whole);
         uint64_t acc = 0;
-        size_t next = 1;
-        for (size_t i = 0; i < n && next < n_sub; i++) {
+        size_t next = 0;
+        for (size_t i = 0; i < n && next < bounds.size(); i++) {
             acc += streams[i].out_cap;
-            if (acc >= total / n_sub * next && i + 1 - cuts.back() >= k_round / 2 && n - (i + 1) >= k_round / 2) {
+            const bool small = next == 0; // (the last piece is what is left)
+            const size_t least = small ? k_round / 8 : k_round / 2;
+            if ((double)acc >= bounds[next] && i + 1 - cuts.back() >= least && n - (i + 1) >= k_round / 8) {
                 cuts.push_back(i + 1);
                 next++;
             }
@@ -1857,17 +1988,18 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     cs.streams = n;
     cs.sub_batches = (uint32_t)S;
 
-    // A sub-batch of ONE wave round can also overlap its OWN copies with its decode: it runs as a sequence of launches
-    // (slices) that each advance every unit by a share of its output; share k - 1 is downloaded while share k decodes, and
-    // the first launch starts on the heads of the inputs.  A call of one sub-batch is that sub-batch; in a pipeline the
-    // first sub-batch (its upload is the exposed one) and the last (its download is).
+    // A call of ONE sub-batch overlaps its OWN copies with its decode: it runs as a sequence of launches (slices) that each
+    // advance every unit by a share of its output; share k - 1 is downloaded while share k decodes, and the first launch
+    // starts on the heads of the inputs.
     uint64_t sliced_call_bytes, slice_bytes, max_slices;
     {
         std::lock_guard<std::mutex> lock(ctx->mu); // (once: the launching thread holds this lock most of the call)
         sliced_call_bytes = ctx->sliced_call_bytes, slice_bytes = ctx->slice_bytes, max_slices = ctx->max_slices;
     }
     auto slices_for = [&](size_t k) -> uint32_t {
-        if (S > 1 && k != 0 && k + 1 != S) return 1;
+        // (in a pipeline the pieces overlap each other; slices of the first or last piece were measured there: the next
+        //  piece's workgroups take the slots every slice boundary frees and the two pieces finish together)
+        if (S > 1) return 1;
         uint64_t total = 0;
         for (size_t i = cuts[k]; i < cuts[k + 1]; i++) total += streams[i].out_cap;
         return total >= sliced_call_bytes ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(max_slices, total / slice_bytes)) : 1u;
@@ -1881,6 +2013,7 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     bool abort_all = false;
     const bool threaded = S > 1;
     double t_first_up = 0, t_decoded = 0, occ_busy = 0, occ_span = 0;
+    SlotClock clock;
 
     auto uploader = [&] {
         for (size_t k = 0; k < S; k++) {
@@ -1893,6 +2026,7 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
             o.want_slices = slices_for(k);
             o.head_frac = k == 0 ? head_frac_for(o.want_slices) : 0; // (only the first sub-batch's upload is exposed)
             o.many_rounds = S > 1;
+            o.pooled = true;
             if (S > 1 && k % 2) o.run_stream = ctx->stream2, o.queue = ctx->queue2; // (xlz_ctx: stream2)
             const int st = batch_create_ex(ctx, streams + cuts[k], cuts[k + 1] - cuts[k], &b, o);
             if (dbg) fprintf(stderr, "xlz_decode_batch: sub-batch %zu uploaded at %.1f ms\n", k, now_ms());
@@ -1912,16 +2046,11 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     auto collect_one = [&](size_t k) {
         int e = xlz_batch_results(sub[k], results + cuts[k]);
         if (e == XLZ_OK) {
-            xlz_call_stats one;
-            memset(&one, 0, sizeof one);
-            launch_occupancy(sub[k], one);
-            cs.units += one.units;
-            cs.wave_slots = std::max(cs.wave_slots, one.wave_slots);
-            cs.kernel_span_ms += one.kernel_span_ms;
-            if (sub[k]->slice_fracs.empty()) { // (a sliced sub-batch: the mean over its launches, from download_sliced)
-                occ_busy += one.slot_occupancy * one.kernel_span_ms;
-                occ_span += one.kernel_span_ms;
-            }
+            uint32_t slots = 0;
+            (void)xlz_batch_launch_info(sub[k], &slots, nullptr);
+            cs.units += sub[k]->unit_results.size();
+            cs.wave_slots = std::max(cs.wave_slots, slots);
+            if (sub[k]->slice_fracs.empty()) clock.add(sub[k]->unit_results); // (a sliced call: the mean over its launches, from download_sliced)
         }
         if (dbg) fprintf(stderr, "xlz_decode_batch: sub-batch %zu decoded at %.1f ms\n", k, now_ms());
         {
@@ -2055,7 +2184,8 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
         cs.download_ms = std::max(0.0, t_end - t_first_up - sliced_kernel_ms);
     }
     cs.total_ms = t_end;
-    cs.slot_occupancy = occ_span > 0 ? occ_busy / occ_span : 0;
+    cs.kernel_span_ms = sliced_kernel_ms >= 0 ? sliced_kernel_ms : clock.span_ms();
+    cs.slot_occupancy = occ_span > 0 ? occ_busy / occ_span : clock.occupancy(cs.wave_slots);
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
         ctx->last_call = cs;
@@ -2065,7 +2195,11 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     for (size_t k = 0; k < S && st == XLZ_OK; k++)
         for (size_t i = 0; i < sub[k]->n; i++)
             if (sub[k]->plans[i].oversize) big.push_back(cuts[k] + i);
-    for (xlz_batch *b : sub) xlz_batch_destroy(b); // (hipFree waits for the device: all of them at the end)
+    for (xlz_batch *b : sub) {
+        if (b && st == XLZ_OK) b->quiet = true; // every launch has been collected, every byte fetched
+        xlz_batch_destroy(b);                   // (the blocks return to the context's pool)
+    }
+    ctx->pool.end_of_call();
     if (st == XLZ_OK && !big.empty()) st = decode_oversize(ctx, streams, results, big);
     return st;
 }

@@ -77,10 +77,11 @@ def test_one_stream_wraps_an_8_mib_window(ctx):
 
 
 def test_a_call_of_several_wave_rounds_runs_as_a_pipeline(ctx):
-    """xlz_decode_batch with 12 288 streams / 3 GiB of output: three sub-batches whose upload, decode and download
-    overlap (xlz_call_stats.sub_batches).  Host buffers in and out; every stream's bytes, status and consumed input
-    as for the same streams decoded alone -- including damaged streams in every sub-batch (one bad stream never
-    fails the call) and an empty one."""
+    """xlz_decode_batch with 12 288 streams / 3 GiB of output: four sub-batches (a quarter-size one in front and behind,
+    two whole ones) whose upload, decode and download overlap (xlz_call_stats.sub_batches) and whose launches follow each
+    other on two streams.  Host buffers in and out; every stream's bytes, status and consumed input as for the same
+    streams decoded alone -- including damaged streams in every sub-batch (one bad stream never fails the call) and an
+    empty one."""
     import ctypes
     import numpy as np
     from lzma_amd import _native as N
@@ -107,7 +108,7 @@ def test_a_call_of_several_wave_rounds_runs_as_a_pipeline(ctx):
     res = (N.Result * n)()
     assert N.lib().xlz_decode_batch(ctx._h, descs, n, res) == 0
     st = ctx.last_call_stats()
-    assert st["sub_batches"] == 3 and st["streams"] == n and st["units"] == n - 1   # (the empty stream has no unit)
+    assert st["sub_batches"] == 4 and st["streams"] == n and st["units"] == n - 1   # (the empty stream has no unit)
     assert 0.5 < st["slot_occupancy"] <= 1.0 and st["total_ms"] > 0
     hs = [hashlib.sha256(p).digest() for p in ps]
     for i in range(n):
@@ -203,5 +204,8 @@ def test_a_call_of_one_wave_round_runs_in_slices(ctx):
         assert lzma_amd.decode_batch(ctx, [j[0] for j in jobs]) == got and ctx.last_call_stats()["slices"] == 2
         ctx.set_slicing(0, 0, 1)
         assert lzma_amd.decode_batch(ctx, [j[0] for j in jobs]) == got and ctx.last_call_stats()["slices"] <= 1
+        # the context keeps the calls' device memory for the next call of the same shape (xlz_ctx_trim gives it back)
+        assert ctx.trim() > 0 and ctx.trim() == 0
+        assert lzma_amd.decode_batch(ctx, [j[0] for j in jobs]) == got
     finally:
         ctx.set_slicing(0, 0, 0)
