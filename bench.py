@@ -91,7 +91,9 @@ CONFIGS = {
 HEADLINES = ["cfg3", "cfg3-heavy"]
 SIDE = ["cfg2-T", "cfg2-R", "cfg4", "cfg4-R", "cfg5", "cfg5-wrap"]   # default side list (cfg2-T-p6: on request, its preset-6 corpus takes 40 s)
 SIDE_ALL = SIDE + ["cfg2-T-p6"]
-EXTRAS = ["h2h", "sweep", "xz", "lone"]   # lone: the 64-unit launches behind roofline.issue.latency_bound
+EXTRAS = ["h2h", "sweep", "xz", "lone", "shard"]   # lone: the 64-unit launches behind roofline.issue.latency_bound;
+# shard: rank 0's shard of the headline batch at N = 2, 4, 8 decoded on THIS GPU -- a projection of the strong-scaling curve
+SHARD_COUNTS = [2, 4, 8]
 SWEEP_COUNTS = [64, 256, 1024]  # (4096 is cfg2-T itself)
 
 
@@ -558,6 +560,10 @@ def compact_line(full, detail_path=None):
         line["break_even_streams"] = sw.get("break_even_streams")
     if full.get("containers"):
         line["xz_1024_blocks_host_to_host"] = full["containers"][0]["value"]
+    if full.get("scaling_projection"):
+        line["scaling_projection"] = {"label": "one GPU, 1/N shard of the same batch (no inter-GPU traffic in this path)",
+                                      "points": [[x["n_gpus"], x["value_projected"], x["efficiency_projected"]] for x in full["scaling_projection"]["points"]],
+                                      "columns": ["n_gpus", "GiB/s projected", "of linear"]}
     if full.get("timing"):
         line["bench_wall_s"] = full["timing"].get("total_s")
     if detail_path:
@@ -880,6 +886,29 @@ def main():
                                                   "share of the algorithmic bytes")
     head_leg_s = time.time() - t_head0
 
+    # ------------------------------------------------------------ N = 1: what the N-GPU points of this curve would be ----
+    # The path has no inter-GPU traffic (the batch is split by stream, every rank decodes its shard on its own), so the
+    # time of rank 0's shard on ONE GPU is the time of the N-GPU step -- as far as one GPU can tell: a projection, labelled so.
+    projection = None
+    if world == 1 and "shard" in extras:
+        comp, dig = corp[head]
+        weights = [out_size_of(spec)] * spec["streams"]
+        projection = []
+        for nv in SHARD_COUNTS:
+            idx = multigpu.partition_by_weight(weights, nv)[0]
+            b = make_batch(lzma_amd, ctx, spec, [comp[i] for i in idx])
+            tl, kms, ea = timed_steps(ctx, b, 5, 1, torch.cuda.synchronize)
+            verify_all(b, len(idx), out_size_of(spec), [dig[i] for i in idx], "shard 0 of %d" % nv)
+            wg, _ = b.launch_info()
+            b.close()
+            step_ms = tl / 5 * 1e3
+            v = spec["streams"] * out_size_of(spec) / GIB / (step_ms / 1e3)
+            projection.append({"n_gpus": nv, "streams_on_rank_0": len(idx), "wave_slots": wg, "rounds": round(len(idx) / max(1, wg), 2),
+                               "ms_per_step": round(step_ms, 3), "kernel_ms_median": round(median(ea), 3) if ea else None,
+                               "value_projected": round(v, 3), "efficiency_projected": round(v / (nv * head_res["value"]), 4)})
+        log("[projection] " + ", ".join("N=%d: %.1f GiB/s (%.2f of linear; %d streams = %.2f rounds on %d slots)" % (
+            x["n_gpus"], x["value_projected"], x["efficiency_projected"], x["streams_on_rank_0"], x["rounds"], x["wave_slots"]) for x in projection))
+
     # ------------------------------------------------------------ N = 1: the other configs and the extras ----
     results = {}
     t_side0 = time.time()
@@ -1031,6 +1060,12 @@ def main():
             full["stream_count_sweep"] = sweep
             full["containers"] = containers
             full["configs"] = [results[n] for n in side if n in results]
+            if projection:
+                full["scaling_projection"] = {
+                    "label": "projection: one GPU, rank 0's 1/N shard of the same batch, no inter-GPU traffic in this path",
+                    "n1_value": head_res["value"], "points": projection,
+                    "note": "value_projected = bytes of the WHOLE batch / the shard's step time on one GPU; efficiency_projected = that / "
+                            "(N x the N = 1 value).  What it cannot see: N processes sharing one host's PCIe root and cores"}
         written = write_detail(full, args.detail_out)
         line = compact_line(full, os.path.relpath(written[0], ROOT) if written else None)
         log("[bench] value %.4f %s  ms_per_step %.3f  n_gpus %d  roofline.frac %.6f  cpu_baseline %s  (%.0f s; detail: %s)"

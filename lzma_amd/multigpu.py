@@ -61,7 +61,7 @@ def max_over_ranks(value, dist=None, device=None):
 
 def decode_batch_multi(streams, devices, decode=None):
     """Decode `streams` on several GPUs from one process: one host thread and one context
-    per device, shards balanced by output capacity, results returned in input order.
+    per device, shards balanced by compressed bytes, results returned in input order.
 
     `decode(device, shard_streams) -> list of results` defaults to the HIP path; tests pass a
     stand-in to exercise the sharding on machines without GPUs.
@@ -76,7 +76,9 @@ def decode_batch_multi(streams, devices, decode=None):
                 return lzma_amd.decode_batch(ctx, shard)
             finally:
                 ctx.close()
-    shards = partition_by_weight([int(s.out_cap) for s in streams], len(devices))
+    # balanced by COMPRESSED bytes, like the C entry (xlz_decode_batch_multi) and the kernel's own work queue: decode time
+    # tracks the number of binary decisions, which tracks them
+    shards = partition_by_weight([len(s.data) for s in streams], len(devices))
     results = [None] * len(streams)
     errors = []
 

@@ -33,7 +33,7 @@ def fuzz(ctx, budget, seed, per_round=160, verbose=True):
   rng = np.random.default_rng(seed)
   t_end = time.time() + budget
   n_total = n_bad_status = 0
-  rounds = 0
+  rounds = n_sliced_rounds = 0
   while time.time() < t_end:
       rounds += 1
       streams, wants = [], []
@@ -83,7 +83,14 @@ def fuzz(ctx, budget, seed, per_round=160, verbose=True):
               c = bytes(c)
           streams.append(Stream(c, FMT_LZMA2_RAW, out_cap=max(cap, 0), dict_size=d2))
           wants.append(oracle.lzma2_raw(c, d2, max(cap, 0)))
+      # every other round through the SLICED form of the call (round 5: a sequence of launches, heads of the inputs first,
+      # slices downloaded under the decode) with a random number of slices; the results must not depend on it
+      k_slices = int(rng.choice([2, 3, 5, 8, 13])) if rounds % 2 else 1
+      ctx.set_slicing(1 if k_slices > 1 else 0, 1 << 16, k_slices)
       got = lzma_amd.decode_batch(ctx, streams)
+      if k_slices > 1:
+          st = ctx.last_call_stats()
+          n_sliced_rounds += 1 if st["slices"] > 1 else 0
       for i, (g, w) in enumerate(zip(got, wants)):
           n_total += 1
           if g[1] != 0:
@@ -98,7 +105,8 @@ def fuzz(ctx, budget, seed, per_round=160, verbose=True):
                     % (i, s.fmt, s.out_cap, s.dict_size, g[1], len(g[0]), g[2], w[1], len(w[0]), w[2], d, fn), flush=True)
               raise AssertionError("GPU and oracle differ, input saved as " + fn)
       if verbose:
-        print("round %d: %d streams ok so far (%d with a non-OK status)" % (rounds, n_total, n_bad_status), flush=True)
+        print("round %d: %d streams ok so far (%d with a non-OK status; %d rounds ran in slices)" % (rounds, n_total, n_bad_status, n_sliced_rounds), flush=True)
+  ctx.set_slicing(0, 0, 0)
   return n_total, n_bad_status
 
 
