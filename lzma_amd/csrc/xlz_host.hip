@@ -973,14 +973,17 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
         const size_t slots = (size_t)decode_grid(b->max_lc_lp, ctx->num_cus, ~0u);
         if (!batch_alloc(b, &b->d_mlit, slots * b->mlit_stride * sizeof(uint16_t))) return fail(XLZ_ERR_DEVICE);
     }
-    if (want_slices > 1 && nu && b->n_normal == nu && nu <= decode_grid(b->max_lc_lp, ctx->num_cus, b->many_rounds ? ~0u : (uint32_t)nu)) {
+    // (units whose model lives in HBM -- lc + lp > 8 -- run in their own launch behind the slices; their streams are fetched at
+    //  the end like the streams of a re-run)
+    if (want_slices > 1 && b->n_normal && b->n_normal <= decode_grid(b->max_lc_lp, ctx->num_cus, b->many_rounds ? ~0u : b->n_normal)) {
         // sliced batch: equal shares of every unit's output per launch; a state block per unit; per launch the table of
         // the pieces it finishes (unit order = arena order, packed back to back on 256-byte boundaries)
         const uint32_t K = std::min<uint32_t>(want_slices, 64);
         for (uint32_t k = 1; k <= K; k++) b->slice_fracs.push_back(k == K ? kSliceOne : (uint32_t)((uint64_t)kSliceOne * k / K));
         b->state_stride = align_up(state_bytes(b->max_lc_lp), kArenaAlign);
         if (!batch_alloc(b, &b->d_states, nu * b->state_stride)) return fail(XLZ_ERR_DEVICE);
-        for (size_t k = 0; k < nu; k++) b->units[k].state = (uint64_t)(uintptr_t)(b->d_states + k * b->state_stride);
+        for (size_t k = 0; k < nu; k++) // (a unit of the HBM-model launch keeps state == 0: it is an ordinary unit there)
+            if (!(b->units[k].flags & UNIT_F_BIG_MODEL)) b->units[k].state = (uint64_t)(uintptr_t)(b->d_states + k * b->state_stride);
         b->slice_pieces.resize(K);
         b->slice_pack_bytes.assign(K, 0);
         size_t total_pieces = 0;
@@ -989,6 +992,7 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
             uint64_t cursor = 0;
             for (size_t ui = 0; ui < nu; ui++) {
                 const Unit &u = b->units[ui];
+                if (u.flags & UNIT_F_BIG_MODEL) continue; // (not in the sliced launches)
                 const uint32_t lo = k == 0 ? 0u : std::min(slice_bound(u.out_cap, b->slice_fracs[k - 1]), u.out_cap);
                 const uint32_t hi = std::min(slice_bound(u.out_cap, b->slice_fracs[k]), u.out_cap);
                 if (hi <= lo) continue;
@@ -1033,7 +1037,8 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
         };
         for (size_t ui = 0; ui < nu; ui++) {
             const Unit &u = b->units[ui];
-            const uint32_t h = slice_head(u.in_len, head_frac, u.kind == UNIT_LZMA2);
+            // (a unit of the HBM-model launch, which runs behind all slices, has no head: all of its input is "tail")
+            const uint32_t h = (u.flags & UNIT_F_BIG_MODEL) ? 0u : slice_head(u.in_len, head_frac, u.kind == UNIT_LZMA2);
             place(*heads, A, u.in_off, h, (uint32_t)ui);
             place(*tails, B, u.in_off + h, u.in_len - h, (uint32_t)ui);
         }
@@ -1842,6 +1847,10 @@ int download_sliced(xlz_batch *b, const xlz_stream_desc *streams, std::vector<do
     gaps.clear();
     for (size_t ui = 0; ui < nu && st == XLZ_OK && K > 1; ui++) {
         const Unit &u = b->units[ui];
+        if (u.flags & UNIT_F_BIG_MODEL) { // decoded by the HBM-model launch behind the slices: nothing of it has gone out
+            if (gaps.empty() || gaps.back() != u.stream) gaps.push_back(u.stream);
+            continue;
+        }
         const uint64_t fin = b->pin_res[(K - 1) * nu + ui].out_len;
         for (size_t k = 0; k + 1 < K; k++) {
             const uint64_t hi = std::min(slice_bound(u.out_cap, b->slice_fracs[k]), u.out_cap);
@@ -1861,11 +1870,13 @@ int download_sliced(xlz_batch *b, const xlz_stream_desc *streams, std::vector<do
             uint64_t busy = 0;
             bool any = false;
             for (size_t ui = 0; ui < nu; ui++) {
+                if (b->units[ui].flags & UNIT_F_BIG_MODEL) continue; // (no result yet)
                 if (prev && prev[ui].t_end == res[ui].t_end && prev[ui].t_start == res[ui].t_start) continue; // did not run
                 if (!any || (int32_t)(res[ui].t_start - t0) < 0) t0 = res[ui].t_start;
                 any = true;
             }
             for (size_t ui = 0; ui < nu && any; ui++) {
+                if (b->units[ui].flags & UNIT_F_BIG_MODEL) continue;
                 if (prev && prev[ui].t_end == res[ui].t_end && prev[ui].t_start == res[ui].t_start) continue;
                 busy += (uint32_t)(res[ui].t_end - res[ui].t_start);
                 span = std::max(span, (uint32_t)(res[ui].t_end - t0));

@@ -192,6 +192,10 @@ def test_a_call_of_one_wave_round_runs_in_slices(ctx):
     for i in range(40):                                                         # copies behind dictionary resets
         c, want = lzma_craft.random_lzma2_stream(rnd, dict_size=4096)
         raw2(c, len(want) + 64, dict_size=4096)
+    beyond_lds = lzma_craft.SMALL_PROPS + [(8, 4, 2), (6, 4, 0), (8, 1, 0)]     # models beyond LDS (lc + lp = 9 .. 12): their own
+    for i in range(16):                                                         # launch behind the slices, fetched at the end
+        c, want = lzma_craft.random_lzma2_stream(rnd, dict_size=4096, props=beyond_lds)
+        raw2(c, len(want) + 64, dict_size=4096)
     ctx.set_slicing(1, 1 << 20, 5)
     try:
         got = lzma_amd.decode_batch(ctx, [j[0] for j in jobs])
