@@ -616,6 +616,36 @@ func DecodeBatch(streams [][]byte, outs [][]byte) ([]int, []error, error) {
 	return lens, errs, nil
 }
 
+// SetSlicing tunes how DecodeBatch overlaps its copies with its decode when a call is ONE wave round of streams
+// (xlz_ctx_set_slicing): such a call runs as up to maxSlices launches that each advance every stream by a share of its
+// output, and share k-1 goes to the callers' buffers while share k decodes -- the batch form of what Read does for one
+// reader (reader1.go:223-254: decompress(need) produces, window.ReadPending drains).  0 = the default of that argument;
+// maxSlices = 1 turns it off.  The decoded bytes and errors do not depend on it.
+func SetSlicing(minCallBytes, sliceBytes uint64, maxSlices uint32) error {
+	c, err := context()
+	if err != nil {
+		return err
+	}
+	if st := C.xlz_ctx_set_slicing(c, C.uint64_t(minCallBytes), C.uint64_t(sliceBytes), C.uint32_t(maxSlices)); st != C.XLZ_OK {
+		return ErrDevice
+	}
+	return nil
+}
+
+// Trim gives back the device and pinned memory the context keeps between DecodeBatch calls (xlz_ctx_trim): a call of the
+// same shape as the one before finds its blocks again; a process that is done with large batches need not hold them.
+func Trim() (released uint64, err error) {
+	c, err := context()
+	if err != nil {
+		return 0, err
+	}
+	var n C.uint64_t
+	if st := C.xlz_ctx_trim(c, &n); st != C.XLZ_OK {
+		return 0, ErrDevice
+	}
+	return uint64(n), nil
+}
+
 // DecodeXZ decodes a whole .xz file (all streams, all blocks) as ONE GPU batch: every block is a
 // raw LZMA2 stream of its own -- what NewReader2(in, dictSize) takes -- so the file's block index
 // is the batch (xlz_xz_index / xlz_xz_decode, include/xlz.h).  Not part of the reference, which has

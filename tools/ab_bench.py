@@ -11,7 +11,9 @@ import corpus
 from lzma_amd import _native as N
 
 WORK = {"T": ("T", 1024, 4, 1 << 20, 6), "R": ("R", 512, 8, 1 << 20, 0), "S": ("T", 8192, 8, 65536, 0),
-        "M": ("M", 1024, 4, 1 << 20, 0), "Z": ("Z", 256, 16, 1 << 20, 0)}
+        "M": ("M", 1024, 4, 1 << 20, 0), "Z": ("Z", 256, 16, 1 << 20, 0),
+        # the cfg3 shape at the sizes of an N-GPU shard (bench.py: scaling_projection): 32 768 / 16 384 / 8 192 streams
+        "S2": ("T", 8192, 4, 65536, 0), "S4": ("T", 8192, 2, 65536, 0), "S8": ("T", 8192, 1, 65536, 0)}
 
 
 def load(path):
