@@ -1343,10 +1343,12 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
 
 // Resident waves per SIMD.  The compiler's default register allocation took 108 VGPRs -- FOUR waves per SIMD (512 / 112),
 // so a grid of 20 single-wave workgroups per CU was never resident (round 2's "20 waves per CU: +-0.5 %" measured nothing).
-// XLZ_WAVES_PER_EU = 5 caps the allocation at 96 VGPRs (the fast loop's fixed v13..v63 stay; the C++ around it spills 16
-// registers in cold code).
+// Round 3 capped the allocation at 96 VGPRs (five waves per SIMD).  Round 5: SIX -- 80 VGPRs (the fast loop's fixed v13..v63
+// stay; the C++ around it spills in cold code) cost nothing measurable (profiles/r05/ab_waves6.txt: the same 20 workgroups
+// per CU +0.1 % / 0.0 %), and every workgroup beyond 20 that LDS admits is worth about 1.7 %: 21 per CU (the 7416-byte model
+// of lc+lp = 3: 163840 / 7680) +3.1 % on the 65 536 x 64 KiB batch, 24 per CU (a 5240-byte model, lc+lp = 2) +7.0 %.
 #ifndef XLZ_WAVES_PER_EU
-#define XLZ_WAVES_PER_EU 5
+#define XLZ_WAVES_PER_EU 6
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XLZ_WAVES_PER_EU, XLZ_WAVES_PER_EU)))
 void xlz_decode_kernel(LaunchParams p)
@@ -1419,14 +1421,11 @@ int launch_gather(const SlicePiece *pieces, uint32_t n_pieces, uint8_t *arena, u
 uint32_t decode_lds_bytes(uint32_t max_lc_lp) { return num_probs(max_lc_lp) * 2u + 128u; }
 
 uint32_t big_model_grid(int num_cus) { return (uint32_t)num_cus; } // one workgroup per CU
-// resident single-wave workgroups per CU of the LDS-model launch
-// How many single-wave workgroups a CU really holds: gfx950 hands out LDS in granules of 1280 bytes (160 KiB / 128), so
-// the 7928-byte model of lc+lp = 3 takes 8960 bytes and EIGHTEEN fit, not the twenty that 163840 / 7928 promises
-// (measured: grids of 18, 19 and 20 per CU run alike, profiles/r03/ab_occupancy.txt), and the register allocation
-// (96 VGPRs) allows five waves per SIMD.  Per-wave speed at 16 waves per CU is already 78 % of a lone wave's
-// (bench.py roofline.issue.latency_bound), so the extra two buy 3.7 % on launches of many rounds and nothing on short
-// ones, where they only stretch every round (8192 units: 4096 + 4096 would become 4608 + 3584): 18 from four rounds
-// on, 16 (four per SIMD) below.
+// Resident single-wave workgroups per CU of the LDS-model launch.  gfx950 hands out LDS in granules of 1280 bytes (160 KiB /
+// 128): the 7416-byte model of lc+lp = 3 (+ 128 bytes of dump rows) takes six of them and TWENTY-ONE fit a CU (round 2's
+// 7928-byte model took seven: 18; profiles/r03/ab_occupancy.txt); the register allocation (80 VGPRs) allows six waves per
+// SIMD.  Per-wave speed at 16 waves per CU is already 78 % of a lone wave's (bench.py roofline.issue.latency_bound): every
+// further wave buys less than its share, and nothing at all on launches of few rounds, where it only stretches every round.
 constexpr uint32_t kLdsGranule = 1280;
 static uint32_t decode_per_cu(uint32_t max_lc_lp, uint32_t n_units, int num_cus)
 {
@@ -1436,7 +1435,16 @@ static uint32_t decode_per_cu(uint32_t max_lc_lp, uint32_t n_units, int num_cus)
     if (per_cu > XLZ_PER_CU_MAX) per_cu = XLZ_PER_CU_MAX;
 #else
     if (per_cu > 4 * XLZ_WAVES_PER_EU) per_cu = 4 * XLZ_WAVES_PER_EU; // what the register allocation lets be resident
-    if (per_cu > 16 && n_units < 4u * per_cu * (uint32_t)num_cus) per_cu = 16;
+    // More waves per CU raise the CU's rate but stretch every round, so they only pay when the launch has rounds to spare:
+    // the most a CU holds from 3.2 rounds of that many on, else 20, else 16 (four per SIMD).  Measured on the headline's
+    // data (profiles/r05/ab_shard_sizes.txt): 16 384 units -- 3.2 rounds of 5120 -- run 6.7 % faster with 20 per CU than as
+    // four rounds of 16 per CU (round 3's rule asked for four rounds of 5120 and chose 16); 8192 units 4.1 % slower.
+    const uint32_t steps[3] = {per_cu, 20u, 16u};
+    for (uint32_t c : steps)
+        if (c <= per_cu && (c <= 16 || (uint64_t)n_units * 5u >= 16ull * c * (uint32_t)num_cus)) { // (3.2 rounds: not "just over three")
+            per_cu = c;
+            break;
+        }
     if (per_cu > 4 && per_cu < 16) per_cu &= ~3u; // equal load on the four SIMDs
 #endif
     return per_cu;

@@ -13,7 +13,10 @@ from lzma_amd import _native as N
 WORK = {"T": ("T", 1024, 4, 1 << 20, 6), "R": ("R", 512, 8, 1 << 20, 0), "S": ("T", 8192, 8, 65536, 0),
         "M": ("M", 1024, 4, 1 << 20, 0), "Z": ("Z", 256, 16, 1 << 20, 0),
         # the cfg3 shape at the sizes of an N-GPU shard (bench.py: scaling_projection): 32 768 / 16 384 / 8 192 streams
-        "S2": ("T", 8192, 4, 65536, 0), "S4": ("T", 8192, 2, 65536, 0), "S8": ("T", 8192, 1, 65536, 0)}
+        "S2": ("T", 8192, 4, 65536, 0), "S4": ("T", 8192, 2, 65536, 0), "S8": ("T", 8192, 1, 65536, 0),
+        # the cfg3 shape behind lc = 2: the model is 5240 bytes = five LDS granules, 25 fit a CU -- what 24 waves per CU
+        # would buy, measured without touching the layout (round 5)
+        "L2": ("T", 8192, 8, 65536, 0, {"lc": 2})}
 
 
 def load(path):
@@ -56,9 +59,10 @@ def main():
         # kernel variant that never finishes costs two minutes, not the whole call
         corp = {}
         for f in fams:
-            fam, nd, rep, size, preset = WORK[f]
+            fam, nd, rep, size, preset = WORK[f][:5]
+            extra = WORK[f][5] if len(WORK[f]) > 5 else {}
             t0 = time.time()
-            cs, hs = corpus.make_alone_batch(fam, nd, size, base_seed=77, workers=min(os.cpu_count() or 1, 64), preset=preset)
+            cs, hs = corpus.make_alone_batch(fam, nd, size, base_seed=77, workers=min(os.cpu_count() or 1, 64), preset=preset, **extra)
             corp[f] = (cs, hs, rep, size)
             print("corpus %s: %d distinct x%d of %d B, ratio %.3f, %.1f s" % (f, nd, rep, size, sum(map(len, cs)) / (nd * size),
                                                                           time.time() - t0), flush=True)
