@@ -11,29 +11,50 @@ namespace xlz {
 // two children / four grandchildren sit in one aligned LDS word / double word.
 constexpr uint32_t kNumStates = 12;      // types.go:17
 constexpr uint32_t kPosBitsMax = 4;      // types.go:15
-constexpr uint32_t P_IS_MATCH = 0;       // [12 << 4]   index (state << 4) + posState
-constexpr uint32_t P_IS_REP = 192;       // [12]
-constexpr uint32_t P_IS_REP_G0 = 204;    // [12]
-constexpr uint32_t P_IS_REP_G1 = 216;    // [12]
-constexpr uint32_t P_IS_REP_G2 = 228;    // [12]
-constexpr uint32_t P_IS_REP0_LONG = 240; // [12 << 4]
-constexpr uint32_t P_POS_SLOT = 432;     // [4][64]
-constexpr uint32_t P_POS_DEC = 688;      // [115] (+1 pad) posDecoders, state.go:7
-constexpr uint32_t P_ALIGN = 804;        // [16]
-// length coder: choice, choice2, 2 pad, low[16][8], mid[16][8], high[256]
-constexpr uint32_t LEN_CHOICE = 0;
-constexpr uint32_t LEN_CHOICE2 = 1;
-constexpr uint32_t LEN_LOW = 4;
-constexpr uint32_t LEN_MID = 4 + 128;
-constexpr uint32_t LEN_HIGH = 4 + 256;
-constexpr uint32_t LEN_CODER_SIZE = 4 + 256 + 256; // 516
-constexpr uint32_t P_LEN = 820;
-constexpr uint32_t P_REP_LEN = P_LEN + LEN_CODER_SIZE; // 1336
-// The rep-length coder's HIGH tree (256 probs: rep matches of 18 bytes and more, rare) is not in LDS: it is the first
-// kRepHigh entries of the model's HBM part (in front of the matched-literal tables).  Without it the model of
-// lc+lp = 3 is 7416 bytes = SIX of gfx950's 1280-byte LDS granules instead of seven: 20 workgroups fit a CU, not 18.
-constexpr uint32_t REP_LEN_LDS_SIZE = 4 + 256;     // choice, choice2, 2 pad, low[16][8], mid[16][8]
-constexpr uint32_t P_LIT = P_REP_LEN + REP_LEN_LDS_SIZE; // 1596
+// Two layouts of the same inventory (round 5).  The FULL one has room for 2^4 posStates in every table that is indexed by one
+// (isMatch, isRep0Long: (state << 4) + posState; the length coders' low / mid trees: posState << 3) -- pb <= 4 is what the
+// reference accepts (reader1.go:210-221).  liblzma's and 7-Zip's default is pb = 2, which uses a quarter of those tables:
+// the COMPACT layout has room for 2^2 posStates, the model of lc+lp = 3 is 5944 bytes instead of 7416 -- FIVE of gfx950's
+// 1280-byte LDS granules instead of six -- and 24 workgroups fit a CU instead of 21 (+3.8 % on launches of many rounds,
+// profiles/r05/ab_waves6.txt).  A launch uses it when every unit's pb is <= 2 (LZMA2: every chunk the host's scan saw; a
+// chunk of a damaged stream that brings a larger pb stops its unit like one that brings a larger lc+lp does, and the
+// stream is decoded again by the widest launch, which uses the full layout).  Only the table BASES differ between the two.
+template <bool COMPACT> struct ModelLayout {
+    static constexpr uint32_t kPosBits = COMPACT ? 2u : kPosBitsMax; // posState bits the tables have room for
+    static constexpr uint32_t kPosStates = 1u << kPosBits;
+    static constexpr uint32_t P_IS_MATCH = 0;                               // [12 << kPosBits]  index (state << kPosBits) + posState
+    static constexpr uint32_t P_IS_REP = kNumStates << kPosBits;            // [12]
+    static constexpr uint32_t P_IS_REP_G0 = P_IS_REP + 12;                  // [12]
+    static constexpr uint32_t P_IS_REP_G1 = P_IS_REP + 24;                  // [12]
+    static constexpr uint32_t P_IS_REP_G2 = P_IS_REP + 36;                  // [12]
+    static constexpr uint32_t P_IS_REP0_LONG = P_IS_REP + 48;               // [12 << kPosBits]
+    static constexpr uint32_t P_POS_SLOT = P_IS_REP0_LONG + (kNumStates << kPosBits); // [4][64]
+    static constexpr uint32_t P_POS_DEC = P_POS_SLOT + 256;                 // [115] (+1 pad) posDecoders, state.go:7
+    static constexpr uint32_t P_ALIGN = P_POS_DEC + 116;                    // [16]
+    // length coder: choice, choice2, 2 pad, low[kPosStates][8], mid[kPosStates][8], high[256]
+    static constexpr uint32_t LEN_CHOICE = 0, LEN_CHOICE2 = 1, LEN_LOW = 4;
+    static constexpr uint32_t LEN_MID = LEN_LOW + (8u << kPosBits);
+    static constexpr uint32_t LEN_HIGH = LEN_LOW + (16u << kPosBits);
+    static constexpr uint32_t LEN_CODER_SIZE = LEN_HIGH + 256;
+    static constexpr uint32_t P_LEN = P_ALIGN + 16;
+    static constexpr uint32_t P_REP_LEN = P_LEN + LEN_CODER_SIZE;
+    // The rep-length coder's HIGH tree (256 probs: rep matches of 18 bytes and more, rare) is not in LDS: it is the first
+    // kRepHigh entries of the model's HBM part (in front of the matched-literal tables).
+    static constexpr uint32_t REP_LEN_LDS_SIZE = LEN_HIGH;                  // choice, choice2, 2 pad, low, mid
+    static constexpr uint32_t P_LIT = P_REP_LEN + REP_LEN_LDS_SIZE;
+};
+using FullLayout = ModelLayout<false>;
+constexpr uint32_t kCompactPosBits = ModelLayout<true>::kPosBits;
+// the full layout's constants by their old names (the host side and everything that is not a decode launch use them)
+constexpr uint32_t P_IS_MATCH = FullLayout::P_IS_MATCH, P_IS_REP = FullLayout::P_IS_REP, P_IS_REP_G0 = FullLayout::P_IS_REP_G0,
+                   P_IS_REP_G1 = FullLayout::P_IS_REP_G1, P_IS_REP_G2 = FullLayout::P_IS_REP_G2, P_IS_REP0_LONG = FullLayout::P_IS_REP0_LONG,
+                   P_POS_SLOT = FullLayout::P_POS_SLOT, P_POS_DEC = FullLayout::P_POS_DEC, P_ALIGN = FullLayout::P_ALIGN,
+                   P_LEN = FullLayout::P_LEN, P_REP_LEN = FullLayout::P_REP_LEN, P_LIT = FullLayout::P_LIT;
+constexpr uint32_t LEN_CHOICE = 0, LEN_CHOICE2 = 1, LEN_LOW = 4, LEN_MID = FullLayout::LEN_MID, LEN_HIGH = FullLayout::LEN_HIGH,
+                   LEN_CODER_SIZE = FullLayout::LEN_CODER_SIZE, REP_LEN_LDS_SIZE = FullLayout::REP_LEN_LDS_SIZE;
+static_assert(P_IS_REP == 192 && P_IS_REP0_LONG == 240 && P_POS_SLOT == 432 && P_POS_DEC == 688 && P_ALIGN == 804 && P_LEN == 820 &&
+                  P_REP_LEN == 1336 && P_LIT == 1596 && LEN_MID == 132 && LEN_HIGH == 260, "the full layout is round 3's");
+static_assert(ModelLayout<true>::P_LIT == 924 && ModelLayout<true>::P_LEN == 532 && ModelLayout<true>::P_REP_LEN == 856, "compact layout");
 constexpr uint32_t kRepHigh = 256;                 // HBM part: entries [0, 256) = rep-length high tree (index = tree slot)
 // The reference's literal coder has 0x300 probs per literal state (state.go:4,49): 0x100 for the
 // plain 8-bit tree and 0x200 used only by the FIRST literal after a match ("matched literal",
@@ -43,7 +64,10 @@ constexpr uint32_t kRepHigh = 256;                 // HBM part: entries [0, 256)
 constexpr uint32_t kLitPlain = 0x100;   // per literal state, in LDS at P_LIT
 constexpr uint32_t kLitMatched = 0x200; // per literal state, in HBM: index (matchBit << 8) + symbol
 
-static inline constexpr uint32_t num_probs(uint32_t lc_plus_lp) { return P_LIT + (kLitPlain << lc_plus_lp); }
+static inline constexpr uint32_t num_probs(uint32_t lc_plus_lp, bool compact = false)
+{
+    return (compact ? ModelLayout<true>::P_LIT : FullLayout::P_LIT) + (kLitPlain << lc_plus_lp);
+}
 // the model's HBM part: the rep-length high tree, then the matched-literal tables
 static inline constexpr uint32_t num_matched_probs(uint32_t lc_plus_lp) { return kRepHigh + (kLitMatched << lc_plus_lp); }
 
@@ -181,6 +205,9 @@ struct LaunchParams {
     uint32_t slice_k;      // index of the launch in its sequence (0: every unit starts, > 0: paused units resume)
     uint32_t head_frac;    // slice_k == 0 only: the launch sees the first slice_head(in_len, head_frac) bytes of every unit's
                            // input (the rest is still being uploaded) and pauses a unit that runs out of them; 0: all of it
+    uint32_t compact;      // != 0: the LDS model uses the COMPACT layout (ModelLayout<true>: every unit's pb <= 2); the host sets it
+                           // when every unit of the launch allows it, never for sessions or the HBM-model launch
+    uint32_t pad_;
     uint32_t many_rounds;  // != 0: one of a sequence of launches that follow each other without a gap (the sub-batches of a
                            // pipelined call): as many workgroups per CU as a launch of many rounds takes, whatever n_units
 };
@@ -217,8 +244,8 @@ static_assert(sizeof(SlicePiece) == 24, "SlicePiece layout is shared with the ho
 int launch_gather(const SlicePiece *pieces, uint32_t n_pieces, uint8_t *arena, uint8_t *pack, uint64_t pack_bytes, int num_cus,
                   void *stream /* hipStream_t */, bool scatter = false);
 int launch_decode(const LaunchParams &p, int num_cus, void *stream /* hipStream_t */, uint32_t max_grid = 0 /* HBM-model launch: at most that many workgroups */);
-uint32_t decode_lds_bytes(uint32_t max_lc_lp);
+uint32_t decode_lds_bytes(uint32_t max_lc_lp, bool compact = false);
 uint32_t big_model_grid(int num_cus);
-uint32_t decode_grid(uint32_t max_lc_lp, int num_cus, uint32_t n_units); // resident workgroups of the LDS-model launch over n_units units (~0u: the most)
+uint32_t decode_grid(uint32_t max_lc_lp, int num_cus, uint32_t n_units, bool compact = false); // resident workgroups of the LDS-model launch over n_units units (~0u: the most)
 
 } // namespace xlz

@@ -264,6 +264,8 @@ struct xlz_batch {
     uint32_t *d_order = nullptr;
     UnitResult *d_results = nullptr;
     size_t in_bytes = 0, out_bytes = 0;
+    uint32_t max_pb = 0;        // over the units whose model fits LDS
+    bool compact = false;       // ... and so their launch uses the compact model layout (xlz_format.h: ModelLayout<true>, pb <= 2)
     uint32_t max_lc_lp = 0;     // over the units whose model fits LDS
     uint32_t max_lc_lp_big = 0; // over the units decoded with an HBM-resident model
     uint32_t n_normal = 0;      // order[0, n_normal) = LDS units, the rest = big-model units
@@ -571,7 +573,8 @@ uint64_t stored_unit_bytes()
 #endif
 }
 
-void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint32_t &max_lc_lp)
+// max_pb (optional): the largest pb any properties byte of the stream announces (the model's layout depends on it)
+void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint32_t &max_lc_lp, uint32_t *max_pb = nullptr)
 {
     size_t pos = 0, unit_start = 0;
     uint64_t out = 0, unit_out = 0;
@@ -652,6 +655,7 @@ void scan_lzma2(const uint8_t *in, size_t len, std::vector<Lz2Unit> &units, uint
             const uint8_t props = in[pos + 5];
             if (props >= 225) break; // the walker reports ErrIncorrectProperties here
             max_lc_lp = std::max<uint32_t>(max_lc_lp, (props % 9) + (props / 9) % 5);
+            if (max_pb) *max_pb = std::max<uint32_t>(*max_pb, props / 45u);
             if (sub == 7 && pos != 0 && pos != unit_start) {
                 cut_at_candidates(true);
                 if (pos != unit_start) cut(pos, out, seen_lzma);
@@ -864,13 +868,13 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
                 continue;
             }
             std::vector<Lz2Unit> lu;
-            uint32_t mx = 0;
-            scan_lzma2(s.in, s.in_len, lu, mx);
+            uint32_t mx = 0, mpb = 0;
+            scan_lzma2(s.in, s.in_len, lu, mx, &mpb);
             const bool big = mx > kMaxLcLpLds; // model too large for LDS: HBM-model launch
             if (big)
                 b->max_lc_lp_big = std::max(b->max_lc_lp_big, mx);
             else
-                b->max_lc_lp = std::max(b->max_lc_lp, mx);
+                b->max_lc_lp = std::max(b->max_lc_lp, mx), b->max_pb = std::max(b->max_pb, mpb);
             pl.lzma2 = true;
             pl.in_off = in_cursor;
             pl.in_len = (uint32_t)s.in_len;
@@ -928,7 +932,7 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
         if (big)
             b->max_lc_lp_big = std::max(b->max_lc_lp_big, (uint32_t)u.lc + u.lp);
         else
-            b->max_lc_lp = std::max(b->max_lc_lp, (uint32_t)u.lc + u.lp);
+            b->max_lc_lp = std::max(b->max_lc_lp, (uint32_t)u.lc + u.lp), b->max_pb = std::max<uint32_t>(b->max_pb, u.pb);
         b->algo_in += payload;
         in_cursor += align_up(payload + 16, kArenaAlign);
         out_cursor += align_up((size_t)cap + kOutTailPad, kArenaAlign);
@@ -947,6 +951,10 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
     });
     for (uint32_t idx : b->order)
         if (!(b->units[idx].flags & UNIT_F_BIG_MODEL)) b->n_normal++;
+
+    // every LDS-model unit's pb <= 2 (liblzma's and 7-Zip's default): the launch uses the compact model layout -- five LDS
+    // granules instead of six for lc+lp = 3, 24 workgroups per CU instead of 21 (xlz_format.h: ModelLayout)
+    b->compact = b->max_pb <= kCompactPosBits && !getenv("XLZ_NO_COMPACT");
 
     // ---- device memory + upload ----------------------------------------
     const size_t nu = b->units.size();
@@ -970,12 +978,12 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
     }
     if (b->n_normal) { // the matched-literal half of every resident model (xlz_format.h)
         b->mlit_stride = num_matched_probs(b->max_lc_lp);
-        const size_t slots = (size_t)decode_grid(b->max_lc_lp, ctx->num_cus, ~0u);
+        const size_t slots = (size_t)decode_grid(b->max_lc_lp, ctx->num_cus, ~0u, b->compact);
         if (!batch_alloc(b, &b->d_mlit, slots * b->mlit_stride * sizeof(uint16_t))) return fail(XLZ_ERR_DEVICE);
     }
     // (units whose model lives in HBM -- lc + lp > 8 -- run in their own launch behind the slices; their streams are fetched at
     //  the end like the streams of a re-run)
-    if (want_slices > 1 && b->n_normal && b->n_normal <= decode_grid(b->max_lc_lp, ctx->num_cus, b->many_rounds ? ~0u : b->n_normal)) {
+    if (want_slices > 1 && b->n_normal && b->n_normal <= decode_grid(b->max_lc_lp, ctx->num_cus, b->many_rounds ? ~0u : b->n_normal, b->compact)) {
         // sliced batch: equal shares of every unit's output per launch; a state block per unit; per launch the table of
         // the pieces it finishes (unit order = arena order, packed back to back on 256-byte boundaries)
         const uint32_t K = std::min<uint32_t>(want_slices, 64);
@@ -1189,6 +1197,7 @@ extern "C" int xlz_batch_run(xlz_batch *b)
     if (b->n_normal) { // models in LDS
         p.n_units = b->n_normal;
         p.max_lc_lp = b->max_lc_lp;
+        p.compact = b->compact ? 1u : 0u;
         p.scratch = nullptr;
         p.scratch_stride = 0;
         p.mlit = b->d_mlit;
@@ -1222,7 +1231,8 @@ extern "C" int xlz_batch_run(xlz_batch *b)
             }
         }
     }
-    if (nu > b->n_normal) { // models in HBM (lc+lp > 6)
+    if (nu > b->n_normal) { // models in HBM (lc+lp > 8): the full layout
+        p.compact = 0;
         HIP_TRY(hipMemsetAsync(rq, 0, 256, rs));
         p.n_units = nu - b->n_normal;
         p.max_lc_lp = b->max_lc_lp_big;
@@ -1275,7 +1285,7 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
     uint32_t grid = std::min<uint32_t>((uint32_t)n, big ? big_model_grid(ctx->num_cus)
-                                                        : decode_grid(b->max_lc_lp, ctx->num_cus, (uint32_t)n));
+                                                        : decode_grid(b->max_lc_lp, ctx->num_cus, (uint32_t)n, b->compact));
     if (wide_lc_lp) grid = std::min(grid, kWideGrid); // (the launch's grid follows p.n_units: see below)
     int st = XLZ_ERR_DEVICE;
     uint16_t *d_wide = nullptr;
@@ -1304,6 +1314,7 @@ int run_units(xlz_batch *b, const std::vector<Unit> &units, std::vector<UnitResu
         p.scratch_stride = wide_lc_lp ? wide_stride : big ? b->scratch_stride : 0;
         p.mlit = big ? nullptr : b->d_mlit;
         p.mlit_stride = big ? 0 : b->mlit_stride;
+        p.compact = (!big && !wide_lc_lp && b->compact) ? 1u : 0u;
         p.order_base = 0;
         p.epochs = d_epochs;
         p.prio_tab = ctx->prio_tab;
@@ -1555,9 +1566,9 @@ extern "C" int xlz_batch_unit_trace(xlz_batch *b, uint32_t *t_start, uint32_t *t
 extern "C" int xlz_batch_launch_info(xlz_batch *b, uint32_t *workgroups, uint32_t *lds_bytes)
 {
     if (!b) return XLZ_ERR_BAD_ARG;
-    const uint32_t grid = std::min<uint32_t>(b->n_normal, decode_grid(b->max_lc_lp, b->ctx->num_cus, b->many_rounds ? ~0u : b->n_normal));
+    const uint32_t grid = std::min<uint32_t>(b->n_normal, decode_grid(b->max_lc_lp, b->ctx->num_cus, b->many_rounds ? ~0u : b->n_normal, b->compact));
     if (workgroups) *workgroups = grid;
-    if (lds_bytes) *lds_bytes = decode_lds_bytes(b->max_lc_lp);
+    if (lds_bytes) *lds_bytes = decode_lds_bytes(b->max_lc_lp, b->compact);
     return XLZ_OK;
 }
 

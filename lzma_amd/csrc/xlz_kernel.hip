@@ -411,14 +411,14 @@ __device__ __forceinline__ uint32_t tree_slot(uint32_t m, uint32_t level) { retu
 #define LEN_DECODE(LBASE, HIGH_ARR, HIGH_BASE, LEN)                                               \
     do {                                                                                          \
         uint32_t c_, m__;                                                                         \
-        BIT((LBASE) + LEN_CHOICE, c_);                                                            \
+        BIT((LBASE) + L::LEN_CHOICE, c_);                                                         \
         if (c_ == 0) {                                                                            \
-            TREE((LBASE) + LEN_LOW + (pos_state << 3), 3, m__);                                   \
+            TREE((LBASE) + L::LEN_LOW + (pos_state << 3), 3, m__);                                \
             (LEN) = m__ - 8;                                                                      \
         } else {                                                                                  \
-            BIT((LBASE) + LEN_CHOICE2, c_);                                                       \
+            BIT((LBASE) + L::LEN_CHOICE2, c_);                                                    \
             if (c_ == 0) {                                                                        \
-                TREE((LBASE) + LEN_MID + (pos_state << 3), 3, m__);                               \
+                TREE((LBASE) + L::LEN_MID + (pos_state << 3), 3, m__);                            \
                 (LEN) = m__;                                                                      \
             } else {                                                                              \
                 TREE_IN(HIGH_ARR, HIGH_BASE, 8, m__);                                             \
@@ -439,20 +439,22 @@ __device__ __forceinline__ bool bad_distance(const Dec &d)
 
 // ONE packet of (*Reader1).decompress (one iteration of the loop at decompress.go:13),
 // every mutation in the reference's order, every test of the reference present.
+// L = the model's layout (xlz_format.h: ModelLayout): the table bases and the room for posStates
+template <class L>
 __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint16_t *__restrict__ mprobs,
                                                    uint8_t *__restrict__ out, uint32_t lane)
 {
     uint32_t bit, length;
 
     const uint32_t pos_state = d.wpos & d.pos_mask;              // :22
-    const uint32_t state2 = (d.state << kPosBitsMax) + pos_state; // :23
+    const uint32_t state2 = (d.state << L::kPosBits) + pos_state; // :23 (the table has room for 2^kPosBits posStates)
 
-    BIT(P_IS_MATCH + state2, bit); // :25-43,176-190
+    BIT(L::P_IS_MATCH + state2, bit); // :25-43,176-190
     if (bit == 0) {
         // ---- literal, decompress.go:44-175 ----
         if (d.size_defined && d.bytes_left == 0) return RUN_ERR_RESULT; // :45-47
         const uint32_t lit_state = ((d.wpos & d.lp_mask) << d.lc) + (d.prev_byte >> (8 - d.lc)); // :56
-        const uint32_t lbase = P_LIT + kLitPlain * lit_state;                                  // :57
+        const uint32_t lbase = L::P_LIT + kLitPlain * lit_state;                                  // :57
         uint32_t symbol = 1;
         if (d.state >= 7) { // matched literal :59-114: probs[((1 + matchBit) << 8) + symbol] of the
                             // reference's table = mprobs[(matchBit << 8) + symbol] of this state
@@ -486,17 +488,17 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
         return RUN_CONTINUE;
     }
 
-    BIT(P_IS_REP + d.state, bit); // :195-213,669-683
+    BIT(L::P_IS_REP + d.state, bit); // :195-213,669-683
     if (bit == 0) {
         // ---- simple match, :215-668 ----
         d.rep3 = d.rep2;
         d.rep2 = d.rep1;
         d.rep1 = d.rep0; // :216
-        LEN_DECODE(P_LEN, probs, P_LEN + LEN_HIGH, length);
+        LEN_DECODE(L::P_LEN, probs, L::P_LEN + L::LEN_HIGH, length);
         d.state = d.state < 7 ? 7 : 10; // stateUpdateMatch :431
         const uint32_t len_state = length > 3 ? 3 : length;
         uint32_t pos_slot;
-        TREE(P_POS_SLOT + (len_state << 6), 6, pos_slot); // :441-486
+        TREE(L::P_POS_SLOT + (len_state << 6), 6, pos_slot); // :441-486
         pos_slot -= 64;
         if (pos_slot < 4) {
             d.rep0 = pos_slot; // :488-489
@@ -505,7 +507,7 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
             uint32_t dist = (2 | (pos_slot & 1)) << nbits; // :491-492
             uint32_t sym;
             if (pos_slot < kEndPosModelIndex) {
-                RTREE(P_POS_DEC + dist - pos_slot, nbits, sym); // :495-546
+                RTREE(L::P_POS_DEC + dist - pos_slot, nbits, sym); // :495-546
                 d.rep0 = dist + sym;
             } else {
                 uint32_t res = 0; // DecodeDirectBits :549-577
@@ -519,7 +521,7 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
                     NORMALIZE();
                 }
                 dist += res << kNumAlignBits;
-                RTREE(P_ALIGN, kNumAlignBits, sym); // :579-625
+                RTREE(L::P_ALIGN, kNumAlignBits, sym); // :579-625
                 d.rep0 = dist + sym;                // :627-628
             }
         }
@@ -537,9 +539,9 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
         // ---- rep match, :685-1123 ----
         if (d.size_defined && d.bytes_left == 0) return RUN_ERR_RESULT; // :686-688
         if (d.pos == d.wbase) return RUN_ERR_RESULT;                    // window.IsEmpty :690-692
-        BIT(P_IS_REP_G0 + d.state, bit);                                // :694-772
+        BIT(L::P_IS_REP_G0 + d.state, bit);                                // :694-772
         if (bit == 0) {
-            BIT(P_IS_REP0_LONG + state2, bit); // :715-756
+            BIT(L::P_IS_REP0_LONG + state2, bit); // :715-756
             if (bit == 0) {                    // short rep :735-739
                 d.state = d.state < 7 ? 9 : 11;
                 if (d.pos >= d.out_cap) return RUN_OUT_CAP;
@@ -553,7 +555,7 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
             }
         } else {
             uint32_t dist;
-            BIT_NN(P_IS_REP_G1 + d.state, bit); // :777-813
+            BIT_NN(L::P_IS_REP_G1 + d.state, bit); // :777-813
             if (bit == 0) {
                 dist = d.rep1;
                 d.rep1 = d.rep0;
@@ -561,7 +563,7 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
                 NORMALIZE();
             } else {
                 NORMALIZE();
-                BIT_NN(P_IS_REP_G2 + d.state, bit); // :816-861
+                BIT_NN(L::P_IS_REP_G2 + d.state, bit); // :816-861
                 if (bit == 0) {
                     dist = d.rep2;
                     d.rep2 = d.rep1;
@@ -575,7 +577,7 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
                 NORMALIZE();
             }
         }
-        LEN_DECODE(P_REP_LEN, mprobs, 0u, length);
+        LEN_DECODE(L::P_REP_LEN, mprobs, 0u, length);
         d.state = d.state < 7 ? 8 : 11; // stateUpdateRep :933,1027,1103
         length += kMatchMinLen;
     }
@@ -621,15 +623,15 @@ __device__ __forceinline__ int lzma_packet_checked(Dec &d, uint16_t *probs, uint
 //  path; the end-of-input / capacity / truncation tests are hoisted into lzma_run, which
 //  passes them in as two limits (arel_lim, pos_lim).
 // ================================================================================
-static_assert(P_IS_MATCH == 0 && P_IS_REP == 192 && P_IS_REP_G0 == 204 && P_IS_REP_G1 == 216 && P_IS_REP_G2 == 228 &&
-                  P_IS_REP0_LONG == 240 && P_POS_SLOT == 432 && P_POS_DEC == 688 && P_ALIGN == 804 && P_LEN == 820 &&
-                  P_REP_LEN == 1336 && P_LIT == 1596 && LEN_LOW == 4 && LEN_MID == 132 && LEN_HIGH == 260 && kRepHigh == 256,
-              "tools/gen_fastpath.py hard-codes the probability layout");
-
+// (tools/gen_fastpath.py computes the same table bases from the same rule: model_layout / xlz_format.h: ModelLayout;
+//  tests/test_fastpath_gen.py keeps both committed loops in sync with the generator)
 enum : uint32_t { FX_LIMIT = 0, FX_ERR = 1, FX_MARKER = 2, FX_COPY = 3 };
 
 #ifndef XLZ_FASTPATH_INC // A/B builds of generator variants (tools/gen_fastpath.py --variant ... --out ...)
 #define XLZ_FASTPATH_INC "xlz_fastpath.inc"
+#endif
+#ifndef XLZ_FASTPATH_PB2_INC // the same loop over the compact layout (gen_fastpath.py --variant compact)
+#define XLZ_FASTPATH_PB2_INC "xlz_fastpath_pb2.inc"
 #endif
 
 // Per-lane constants of the head gather: lane j fetches the j-th context-selected probability a
@@ -637,7 +639,7 @@ enum : uint32_t { FX_LIMIT = 0, FX_ERR = 1, FX_MARKER = 2, FX_COPY = 3 };
 struct HeadVec {
     uint32_t hc, hms, hm2, lit_next;
 };
-__device__ __forceinline__ HeadVec head_vectors(uint32_t lane)
+template <class L> __device__ __forceinline__ HeadVec head_vectors(uint32_t lane)
 {
     HeadVec h;
 #ifdef XLZ_HEAD_PLAIN // A/B build (tools/gen_fastpath.py --without hdpp): head probability j at lane j
@@ -646,27 +648,43 @@ __device__ __forceinline__ HeadVec head_vectors(uint32_t lane)
       // written with row_mask / bank_mask instead of a lane compare and a select
     const uint32_t hj = (lane % 4 == 0 && lane < 40) ? (lane / 16) * 4 + (lane % 16) / 4 : 10u;
 #endif
-    const uint32_t base = hj == 0 ? P_IS_MATCH
-                          : hj == 1 ? P_IS_REP
-                          : hj == 2 ? P_IS_REP_G0
-                          : hj == 3 ? P_IS_REP_G1
-                          : hj == 4 ? P_IS_REP_G2
-                          : hj == 5 ? P_IS_REP0_LONG
-                          : hj == 6 ? P_LEN + LEN_CHOICE
-                          : hj == 7 ? P_LEN + LEN_CHOICE2
-                          : hj == 8 ? P_REP_LEN + LEN_CHOICE
-                          : hj == 9 ? P_REP_LEN + LEN_CHOICE2
-                                    : P_LEN + 2; // the other lanes: an unused slot (their v40 is stored too)
+    const uint32_t base = hj == 0 ? L::P_IS_MATCH
+                          : hj == 1 ? L::P_IS_REP
+                          : hj == 2 ? L::P_IS_REP_G0
+                          : hj == 3 ? L::P_IS_REP_G1
+                          : hj == 4 ? L::P_IS_REP_G2
+                          : hj == 5 ? L::P_IS_REP0_LONG
+                          : hj == 6 ? L::P_LEN + L::LEN_CHOICE
+                          : hj == 7 ? L::P_LEN + L::LEN_CHOICE2
+                          : hj == 8 ? L::P_REP_LEN + L::LEN_CHOICE
+                          : hj == 9 ? L::P_REP_LEN + L::LEN_CHOICE2
+                                    : L::P_LEN + 2; // the other lanes: an unused slot (their v40 is stored too)
     h.hc = base * 2;
     h.lit_next = upd_literal(lane < 12 ? lane : 0); // stateUpdateLiteral as a table: lane = old state
     h.hms = (hj >= 1 && hj <= 4) ? 2u : 0u; // indexed by state
-    h.hm2 = (hj == 0 || hj == 5) ? 2u : 0u; // indexed by state2 = (state << 4) + posState
-#ifndef XLZ_NO_HISS // hiss: address = hc + state * (hms + 16 hm2) + posState * hm2 (three instructions); A/B builds --without hiss: -DXLZ_NO_HISS
-    h.hms += 16u * h.hm2;
+    h.hm2 = (hj == 0 || hj == 5) ? 2u : 0u; // indexed by state2 = (state << kPosBits) + posState
+#ifndef XLZ_NO_HISS // hiss: address = hc + state * (hms + 2^kPosBits hm2) + posState * hm2 (three instructions); A/B builds --without hiss: -DXLZ_NO_HISS (full layout only)
+    h.hms += L::kPosStates * h.hm2;
 #endif
     return h;
 }
 
+#define XLZ_FAST_OPERANDS                                                                                                          \
+        : [range] "+s"(d.range), [code] "+s"(d.code), [cur] "+s"(d.cur), [arel] "+s"(d.arel), [state] "+s"(d.state),                \
+          [rep0] "+s"(d.rep0), [rep1] "+s"(d.rep1), [rep2] "+s"(d.rep2), [rep3] "+s"(d.rep3), [pos] "+s"(d.pos),                    \
+          [wpos] "+s"(d.wpos), [prev] "+s"(d.prev_byte), [mb] "+s"(d.match_byte), [exitc] "=&s"(exitc),                             \
+          [lenout] "=&s"(lenout)                                                                                                    \
+        : [arel_lim] "s"(arel_lim), [pos_lim] "s"(pos_lim), [dict] "s"(d.dict_size), [dictm1] "s"(d.dict_size - 1), [pos_mask] "s"(d.pos_mask), \
+          [lc] "s"(d.lc), [lc8] "s"(8u - d.lc), [wbase] "s"(d.wbase), [outp] "s"(out), [mptr] "s"(mprobs),                          \
+          [vin] "v"(d.vin), [vlane] "v"(lane), [vhc] "v"(hv.hc), [vhms] "v"(hv.hms), [vhm2] "v"(hv.hm2),                            \
+          [vlitnext] "v"(hv.lit_next), [vlpm] "v"(vlpm), [vpm] "v"(vpm)                                                             \
+        : "scc", "vcc", "memory", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", \
+          "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", \
+          "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", \
+          "v63"
+
+// COMPACT: the loop rendered over the compact layout (only table bases differ; hv comes from head_vectors<ModelLayout<COMPACT>>)
+template <bool COMPACT>
 __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_t *mprobs, uint32_t lane,
                                                    const HeadVec &hv, uint32_t arel_lim, uint32_t pos_lim,
                                                    uint32_t &lenout)
@@ -680,22 +698,18 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_
     asm volatile("v_mov_b32 %0, %1" : "=v"(vlpm) : "s"(d.lp_mask));
 #endif
     asm volatile("v_mov_b32 %0, %1" : "=v"(vpm) : "s"(d.pos_mask));
-    asm volatile(
+    if constexpr (COMPACT) {
+        asm volatile(
+#include XLZ_FASTPATH_PB2_INC
+            XLZ_FAST_OPERANDS);
+    } else {
+        asm volatile(
 #include XLZ_FASTPATH_INC
-        : [range] "+s"(d.range), [code] "+s"(d.code), [cur] "+s"(d.cur), [arel] "+s"(d.arel), [state] "+s"(d.state),
-          [rep0] "+s"(d.rep0), [rep1] "+s"(d.rep1), [rep2] "+s"(d.rep2), [rep3] "+s"(d.rep3), [pos] "+s"(d.pos),
-          [wpos] "+s"(d.wpos), [prev] "+s"(d.prev_byte), [mb] "+s"(d.match_byte), [exitc] "=&s"(exitc),
-          [lenout] "=&s"(lenout)
-        : [arel_lim] "s"(arel_lim), [pos_lim] "s"(pos_lim), [dict] "s"(d.dict_size), [dictm1] "s"(d.dict_size - 1), [pos_mask] "s"(d.pos_mask),
-          [lc] "s"(d.lc), [lc8] "s"(8u - d.lc), [wbase] "s"(d.wbase), [outp] "s"(out), [mptr] "s"(mprobs),
-          [vin] "v"(d.vin), [vlane] "v"(lane), [vhc] "v"(hv.hc), [vhms] "v"(hv.hms), [vhm2] "v"(hv.hm2),
-          [vlitnext] "v"(hv.lit_next), [vlpm] "v"(vlpm), [vpm] "v"(vpm)
-        : "scc", "vcc", "memory", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
-          "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46",
-          "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62",
-          "v63");
+            XLZ_FAST_OPERANDS);
+    }
     return exitc;
 }
+#undef XLZ_FAST_OPERANDS
 
 // The SIMD's instruction arbiter serves its OLDEST wave first: of the four waves that share a
 // SIMD the first one dispatched runs ~1.45x faster than the last (measured: the unit durations of
@@ -736,6 +750,7 @@ __device__ __forceinline__ void rank_priority(Dec &d, uint32_t lane)
 }
 
 // (*Reader1).decompress run to the end of the current LZMA chunk (decompress.go:8-1136)
+template <bool COMPACT>
 __device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint16_t *__restrict__ mprobs,
                                         uint8_t *__restrict__ out, uint32_t lane, const HeadVec &hv, bool allow_fast)
 {
@@ -757,7 +772,7 @@ __device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint16_t *__res
         const bool fast = allow_fast && in_left >= kFastInput && (d.out_cap - d.pos) >= kFastOutput &&
                           (!d.size_defined || d.bytes_left >= kFastOutput);
         if (!fast) {
-            const int r = lzma_packet_checked(d, probs, mprobs, out, lane);
+            const int r = lzma_packet_checked<ModelLayout<COMPACT>>(d, probs, mprobs, out, lane);
             if (r != RUN_CONTINUE) return r;
             continue;
         }
@@ -767,7 +782,7 @@ __device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint16_t *__res
         if (d.size_defined) room = (uint32_t)min((uint64_t)room, d.bytes_left - kFastOutput);
         const uint32_t pos0 = d.pos;
         uint32_t len = 0;
-        const uint32_t ec = lzma_fast_loop(d, out, mprobs, lane, hv, arel_lim, min(pos0 + room + 1, d.pause_at), len);
+        const uint32_t ec = lzma_fast_loop<COMPACT>(d, out, mprobs, lane, hv, arel_lim, min(pos0 + room + 1, d.pause_at), len);
         d.bytes_left -= d.pos - pos0; // :172,660,665 ... (wraps harmlessly when the size is undefined)
         if (ec == FX_ERR) return RUN_ERR_RESULT; // :651-653, :690-692
         if (ec == FX_MARKER) {                    // end marker :633-645 (bytesLeft > 0 here if defined)
@@ -942,9 +957,9 @@ __device__ __forceinline__ void mprobs_reset(uint16_t *__restrict__ mprobs, uint
 }
 
 __device__ __forceinline__ void state_reset(Dec &d, uint16_t *probs, uint16_t *__restrict__ mprobs, uint32_t lc_lp,
-                                            uint32_t lane)
+                                            uint32_t lane, bool compact)
 {
-    probs_reset(probs, num_probs(lc_lp), lane); // state.Reset, state.go:79-121
+    probs_reset(probs, num_probs(lc_lp, compact), lane); // state.Reset, state.go:79-121
     mprobs_reset(mprobs, num_matched_probs(lc_lp), lane);
     d.state = 0;
     d.rep0 = d.rep1 = d.rep2 = d.rep3 = 0;
@@ -959,6 +974,7 @@ struct Walk {
     bool more_input;   // UNIT_F_MORE_INPUT: the unit's input is a window of a longer stream
     bool resumable;    // the unit has a state block (pull reader): it can pause for a larger model
     uint32_t model_lc_lp; // largest lc+lp this unit's model storage was sized for
+    bool compact;         // the launch's model layout has room for 2^kCompactPosBits posStates only (xlz_format.h: ModelLayout)
 };
 
 enum : int32_t { WALK_RUN_CHUNK = 1000 }; // lzma2_next: a compressed chunk is set up, run it
@@ -1057,19 +1073,19 @@ __device__ __forceinline__ int32_t lzma2_next(Dec &d, Walk &w, uint16_t *probs, 
             // NewReader1ForReader2 / Renew: props from header[5] (reader2.go:146-165)
             if (w.h5 >= 225) return ST_ERR_PROPS; // DecodeProp, reader1.go:211-213
             const uint32_t lc = w.h5 % 9, r = w.h5 / 9, lp = r % 5, pb = r / 5;
-            if (lc + lp > max_lc_lp || lc + lp > w.model_lc_lp) {
-                // LDS / the saved state are sized by the host's header scan; AUX_GROW tells the host that a launch with
-                // room for this model would go on (and not, say, a full epoch table: ADVICE r4)
-                aux = (aux & ~AUX_GROW_MASK) | AUX_GROW | ((lc + lp) << AUX_GROW_SHIFT);
+            if (lc + lp > max_lc_lp || lc + lp > w.model_lc_lp || (w.compact && pb > kCompactPosBits)) {
+                // LDS / the saved state are sized (and laid out: pb) by the host's header scan; AUX_GROW tells the host that
+                // a launch with room for this model would go on (and not, say, a full epoch table: ADVICE r4)
+                aux = (aux & ~AUX_GROW_MASK) | AUX_GROW | (min(lc + lp, 15u) << AUX_GROW_SHIFT);
                 return ST_ERR_UNSUPPORTED;
             }
             d.lc = lc;
             d.lp_mask = (1u << lp) - 1;
             d.pos_mask = (1u << pb) - 1;
             w.lc_lp = lc + lp;
-            state_reset(d, probs, mprobs, w.lc_lp, lane);
+            state_reset(d, probs, mprobs, w.lc_lp, lane, w.compact);
         } else if (sub == 5) {
-            state_reset(d, probs, mprobs, w.lc_lp, lane); // :156-157
+            state_reset(d, probs, mprobs, w.lc_lp, lane, w.compact); // :156-157
         }
         w.first_chunk = !w.have_reader;
         w.have_reader = true;
@@ -1121,11 +1137,12 @@ __device__ __forceinline__ void model_copy(uint32_t *__restrict__ dst, const uin
 // BIG = false: the model is this workgroup's LDS (the asm fast loop addresses it from LDS offset
 // 0).  BIG = true (lc+lp > 6): the model is a slot of HBM scratch and only the checked C++
 // packet decoder runs -- slow, but the reference's whole parameter range decodes.
-template <bool BIG>
+template <bool BIG, bool COMPACT>
 __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *probs, uint16_t *__restrict__ wg_mprobs)
 {
+    static_assert(!(BIG && COMPACT), "the HBM-model launch uses the full layout");
     const uint32_t lane = threadIdx.x;
-    const HeadVec hv = head_vectors(lane);
+    const HeadVec hv = head_vectors<ModelLayout<COMPACT>>(lane);
     constexpr bool big = BIG;
 
     for (;;) {
@@ -1184,6 +1201,7 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
         w.last_unit = (flags & UNIT_F_LAST) != 0;
         w.more_input = lzma2 && (flags & UNIT_F_MORE_INPUT);
         // only a pull reader's state block is sized per unit (LDS, and the blocks of a sliced launch: per launch)
+        w.compact = COMPACT;
         w.model_lc_lp = (st && !sliced) ? lc + lp : 0xFFu;
         w.resumable = st != nullptr && !sliced; // (a unit of a sliced launch asks the host for nothing)
         d.shadow = (st && lzma2 && !sliced)
@@ -1227,8 +1245,8 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
             in_window(d, d.abase + (consumed - d.in_base), lane);
             // inside an LZMA2 chunk the limitedByteReader's end stays where the chunk header put it
             d.aend = (lzma2 && phase == PH_CHUNK) ? min(d.abase + (RFL(st[SV_CHUNK_END]) - d.in_base), w.unit_end) : w.unit_end;
-            model_copy(reinterpret_cast<uint32_t *>(probs), st + kStateWords, num_probs(w.lc_lp), lane);
-            if (flags & UNIT_F_RESET_MODEL) state_reset(d, probs, mprobs, w.lc_lp, lane); // (*Reader1).Reset
+            model_copy(reinterpret_cast<uint32_t *>(probs), st + kStateWords, num_probs(w.lc_lp, COMPACT), lane);
+            if (flags & UNIT_F_RESET_MODEL) state_reset(d, probs, mprobs, w.lc_lp, lane, COMPACT); // (*Reader1).Reset
             if (flags & UNIT_F_REOPEN) { // (*Reader1).Reopen: SetUnpackSize, then rangeDec.Reopen on the new input
                 set_unpack_size(d, unpack);
                 d.aend = w.unit_end;
@@ -1254,7 +1272,7 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
             w.have_reader = (flags & UNIT_F_HAVE_READER) != 0;
             w.first_chunk = true;
             if (!lzma2) { // newState -> Reset (state.go:47-61)
-                probs_reset(probs, num_probs(lc + lp), lane);
+                probs_reset(probs, num_probs(lc + lp, COMPACT), lane);
                 mprobs_reset(mprobs, num_matched_probs(lc + lp), lane);
             }
         }
@@ -1283,7 +1301,7 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
                 // after the last copy.
                 if (d.state >= 7) reload_context(d, out, lane);
             }
-            const int r = lzma_run(d, probs, mprobs, out, lane, hv, !big);
+            const int r = lzma_run<COMPACT>(d, probs, mprobs, out, lane, hv, !big);
             if (r == RUN_PAUSE) {
                 status = ST_PAUSED;
                 break;
@@ -1325,7 +1343,7 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
             sv_store(st, SV_FIRST_CHUNK, w.first_chunk ? 1u : 0u);
             sv_store(st, SV_PHASE, phase);
             sv_store(st, SV_AUX, aux);
-            model_copy(st + kStateWords, reinterpret_cast<const uint32_t *>(probs), num_probs(w.lc_lp), lane);
+            model_copy(st + kStateWords, reinterpret_cast<const uint32_t *>(probs), num_probs(w.lc_lp, COMPACT), lane);
         }
         {
             UnitResult res; // every lane stores the same 32 bytes
@@ -1354,13 +1372,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XLZ_WAVES_PE
 void xlz_decode_kernel(LaunchParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds_probs[];
-    decode_units<false>(p, lds_probs, p.mlit + (size_t)blockIdx.x * p.mlit_stride);
+    decode_units<false, false>(p, lds_probs, p.mlit + (size_t)blockIdx.x * p.mlit_stride);
+}
+
+// the same over the COMPACT model layout (every unit's pb <= 2: xlz_format.h: ModelLayout): five LDS granules instead of six
+// for lc+lp = 3, 24 workgroups per CU
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XLZ_WAVES_PER_EU, XLZ_WAVES_PER_EU)))
+void xlz_decode_kernel_pb2(LaunchParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds_probs[];
+    decode_units<false, true>(p, lds_probs, p.mlit + (size_t)blockIdx.x * p.mlit_stride);
 }
 
 __global__ __launch_bounds__(64) void xlz_decode_kernel_hbm_model(LaunchParams p)
 {
     uint16_t *slot = p.scratch + (size_t)blockIdx.x * p.scratch_stride; // model, then its matched part
-    decode_units<true>(p, slot, slot + num_probs(p.max_lc_lp));
+    decode_units<true, false>(p, slot, slot + num_probs(p.max_lc_lp));
 }
 
 // Pieces of an arena <-> one packed image (xlz_format.h: SlicePiece; SCATTER = false: arena -> image, the download of a
@@ -1418,7 +1445,7 @@ int launch_gather(const SlicePiece *pieces, uint32_t n_pieces, uint8_t *arena, u
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-uint32_t decode_lds_bytes(uint32_t max_lc_lp) { return num_probs(max_lc_lp) * 2u + 128u; }
+uint32_t decode_lds_bytes(uint32_t max_lc_lp, bool compact) { return num_probs(max_lc_lp, compact) * 2u + 128u; }
 
 uint32_t big_model_grid(int num_cus) { return (uint32_t)num_cus; } // one workgroup per CU
 // Resident single-wave workgroups per CU of the LDS-model launch.  gfx950 hands out LDS in granules of 1280 bytes (160 KiB /
@@ -1427,9 +1454,9 @@ uint32_t big_model_grid(int num_cus) { return (uint32_t)num_cus; } // one workgr
 // SIMD.  Per-wave speed at 16 waves per CU is already 78 % of a lone wave's (bench.py roofline.issue.latency_bound): every
 // further wave buys less than its share, and nothing at all on launches of few rounds, where it only stretches every round.
 constexpr uint32_t kLdsGranule = 1280;
-static uint32_t decode_per_cu(uint32_t max_lc_lp, uint32_t n_units, int num_cus)
+static uint32_t decode_per_cu(uint32_t max_lc_lp, uint32_t n_units, int num_cus, bool compact)
 {
-    const uint32_t alloc = (decode_lds_bytes(max_lc_lp) + kLdsGranule - 1) / kLdsGranule * kLdsGranule;
+    const uint32_t alloc = (decode_lds_bytes(max_lc_lp, compact) + kLdsGranule - 1) / kLdsGranule * kLdsGranule;
     uint32_t per_cu = kMaxLdsBytes / alloc;
 #ifdef XLZ_PER_CU_MAX // A/B builds
     if (per_cu > XLZ_PER_CU_MAX) per_cu = XLZ_PER_CU_MAX;
@@ -1451,9 +1478,9 @@ static uint32_t decode_per_cu(uint32_t max_lc_lp, uint32_t n_units, int num_cus)
 }
 
 // resident workgroups of the LDS-model launch over n_units units (n_units = ~0u: the most any launch uses)
-uint32_t decode_grid(uint32_t max_lc_lp, int num_cus, uint32_t n_units)
+uint32_t decode_grid(uint32_t max_lc_lp, int num_cus, uint32_t n_units, bool compact)
 {
-    return decode_per_cu(max_lc_lp, n_units, num_cus) * (uint32_t)num_cus;
+    return decode_per_cu(max_lc_lp, n_units, num_cus, compact) * (uint32_t)num_cus;
 }
 
 int launch_decode(const LaunchParams &p, int num_cus, void *stream, uint32_t max_grid)
@@ -1466,16 +1493,18 @@ int launch_decode(const LaunchParams &p, int num_cus, void *stream, uint32_t max
         hipLaunchKernelGGL(xlz_decode_kernel_hbm_model, dim3(grid), dim3(kWave), 0, (hipStream_t)stream, p);
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
-    const uint32_t lds = decode_lds_bytes(p.max_lc_lp);
+    const bool compact = p.compact != 0;
+    const uint32_t lds = decode_lds_bytes(p.max_lc_lp, compact);
     if (lds > kMaxLdsBytes) return -1;
-    uint32_t grid = decode_grid(p.max_lc_lp, num_cus, p.many_rounds ? ~0u : p.n_units);
+    uint32_t grid = decode_grid(p.max_lc_lp, num_cus, p.many_rounds ? ~0u : p.n_units, compact);
     if (grid > p.n_units) grid = p.n_units;
     if (grid == 0) return 0;
-    if (lds > 64u * 1024u &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(xlz_decode_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes) != hipSuccess)
-        return -2;
-    hipLaunchKernelGGL(xlz_decode_kernel, dim3(grid), dim3(kWave), lds, (hipStream_t)stream, p);
+    const void *fn = compact ? reinterpret_cast<const void *>(xlz_decode_kernel_pb2) : reinterpret_cast<const void *>(xlz_decode_kernel);
+    if (lds > 64u * 1024u && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes) != hipSuccess) return -2;
+    if (compact)
+        hipLaunchKernelGGL(xlz_decode_kernel_pb2, dim3(grid), dim3(kWave), lds, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(xlz_decode_kernel, dim3(grid), dim3(kWave), lds, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

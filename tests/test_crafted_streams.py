@@ -227,6 +227,26 @@ def _fuzz_find_wide():
     return open(path, "rb").read(), 8192, 9481
 
 
+def walks_into_larger_pb():
+    """the same with properties that need no larger MODEL but a larger LAYOUT (round 5): the hidden chunk renews the model
+    with lc 0 / lp 0 / pb 4 -- sixteen posStates, where the launch, whose units' headers all said pb <= 2, laid its model
+    out with room for four (xlz_format.h: ModelLayout<true>).  The unit stops in front of that chunk (AUX_GROW) and the
+    stream is decoded again by the widest launch, which uses the full layout; the reference simply decodes on
+    (reader2.go:155-165).  Literals at posStates 4..15 would index beyond the compact tables."""
+    e = Encoder()
+    for b in b"abcabcabcabc":
+        e.literal(b)
+    p1 = e.payload()
+    e2 = Encoder(lc=0, lp=0, pb=4)
+    for b in b"the quick brown fox jumps over the lazy dog":
+        e2.literal(b)
+    e2.match(9, 20)
+    second = lzma2_lzma_chunk(0xE0, 43 + 20, e2.payload(), props_byte(0, 0, 4))
+    body = p1 + second
+    hdr = bytes([0xE0, 0, 11]) + (len(body) + 7 - 1).to_bytes(2, "big") + bytes([props_byte(3, 0, 2)])
+    return hdr + body + b"\x00" * 8, 1 << 16, 200
+
+
 def walks_into_larger_props():
     """the same on purpose.  A chunk ends when its announced output is there (decompress.go:14-20); what its header
     announced as compressed size beyond that stays in the source, and startChunk reads the next control byte from
@@ -279,6 +299,12 @@ def test_crafted_streams_cpu_expectations():
     # a real decode that walks into a chunk the header scan jumps over (larger properties: round 4's fuzzer find)
     blob, ds, cap = walks_into_larger_props()
     assert oracle.lzma2_raw(blob, ds, cap) == (b"abcabcabcabcxyzzy", 0, 39)
+    blob, ds, cap = walks_into_larger_pb()
+    fox = b"the quick brown fox jumps over the lazy dog"
+    got = oracle.lzma2_raw(blob, ds, cap)
+    assert got[:2] == (b"abcabcabcabc" + fox + (fox[-9:] * 3)[:20], 0)
+    import lzma_pydec
+    assert lzma_pydec.lzma2_raw(blob, ds)[:2] == got[:2]
     import lzma_amd
     assert [u["out_len"] for u in lzma_amd.lzma2_units(blob)] == [12]
     blob, ds, cap = _fuzz_find_wide()
@@ -361,6 +387,7 @@ def test_crafted_streams_on_gpu(ctx):
     c2.append(("fuzz find 424242/45182",) + _fuzz_find())
     c2.append(("fuzz find 5501/18774",) + _fuzz_find_wide())
     c2.append(("off the headers into lc 8 / lp 4",) + walks_into_larger_props())
+    c2.append(("off the headers into pb 4 (a compact-layout launch)",) + walks_into_larger_pb())
     streams = [Stream(b, FMT_LZMA2_RAW, out_cap=cap, dict_size=ds) for _, b, ds, cap in c2]
     got = lzma_amd.decode_batch(ctx, streams + [extra])
     for (name, b, ds, cap), g in zip(c2, got):

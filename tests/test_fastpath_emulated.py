@@ -21,7 +21,8 @@ import oracle
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-P_LEN, P_LIT = 820, 1596   # (xlz_format.h; the rep-length high tree is the first 256 entries of the model's HBM part)
+# (table bases: tools/gen_fastpath.py: model_layout = xlz_format.h: ModelLayout; the rep-length high tree is the first 256
+#  entries of the model's HBM part)
 K_IN_WINDOW, K_FAST_INPUT, K_FAST_OUTPUT = 256, 32, 128   # (xlz_kernel.hip: kInWindow, kFastInput, kFastOutput)
 
 
@@ -33,7 +34,9 @@ def _render(add=(), remove=()):
     g.VARIANT.difference_update(remove)
     _, final, _ = g.render()
     import layout
-    return Program((final, layout.sizes(final), layout), set(g.VARIANT))
+    prog = Program((final, layout.sizes(final), layout), set(g.VARIANT))
+    prog.lay = g.model_layout("compact" in g.VARIANT)
+    return prog
 
 
 class Program(tuple):
@@ -43,6 +46,7 @@ class Program(tuple):
     def __new__(cls, items, variant):
         self = super().__new__(cls, items)
         self.variant = variant
+        self.lay = None   # table bases of the layout the loop was rendered over (_render sets it)
         return self
 
 
@@ -51,9 +55,11 @@ def program():
     return _render()
 
 
-def _head_vectors(lane, dpp=True):
-    """xlz_kernel.hip: head_vectors (DPP cells; dpp=False: the XLZ_HEAD_PLAIN build, head probability j at lane j)"""
-    base_of = [0, 192, 204, 216, 228, 240, P_LEN + 0, P_LEN + 1, 1336 + 0, 1336 + 1]
+def _head_vectors(lane, dpp=True, lay=None):
+    """xlz_kernel.hip: head_vectors<L> (DPP cells; dpp=False: the XLZ_HEAD_PLAIN build, head probability j at lane j)"""
+    P_LEN = lay["P_LEN"]
+    base_of = [lay["P_IS_MATCH"], lay["P_IS_REP"], lay["P_IS_REP_G0"], lay["P_IS_REP_G1"], lay["P_IS_REP_G2"], lay["P_IS_REP0_LONG"],
+               P_LEN + 0, P_LEN + 1, lay["P_REP_LEN"] + 0, lay["P_REP_LEN"] + 1]
     hc, hms, hm2, litnext = [], [], [], []
     for l in range(64):
         if dpp:
@@ -75,7 +81,9 @@ def run_fast_loop(program, payload, lc, lp, pb, dict_size, size, expect, dpp=Tru
     final, sizes, layout = program
     m = Machine(final, sizes, layout.SGPR_OPS, layout.VGPR_OPS, layout.SGPR64_OPS)
     m.strict_waits = strict_waits
-    n_probs = P_LIT + (0x100 << (lc + lp))
+    lay = program.lay
+    assert pb <= (2 if lay["POS_STATES"] == 4 else 4), "the compact layout has room for four posStates"
+    n_probs = lay["P_LIT"] + (0x100 << (lc + lp))
     m.lds[0:2 * n_probs:2] = 0x00
     m.lds[1:2 * n_probs:2] = 0x04          # every probability 1024 (state.go:79-121)
     out = bytearray(size + 1024)
@@ -83,10 +91,10 @@ def run_fast_loop(program, payload, lc, lp, pb, dict_size, size, expect, dpp=Tru
     mp = bytearray(b"\x00\x04" * (256 + ((0x400 if "mlv" in getattr(program, "variant", ()) else 0x200) << (lc + lp))))
     m.mem["outp"], m.mem["mptr"] = out, mp
     lane = np.arange(64, dtype=np.uint32)
-    hc, hms, hm2, litnext = _head_vectors(lane, dpp)
+    hc, hms, hm2, litnext = _head_vectors(lane, dpp, lay)
     variant = getattr(program, "variant", ())
-    if "hiss" in variant:       # head address = hc + state * (hms + 16 hm2) + posState * hm2
-        hms = hms + 16 * hm2
+    if "hiss" in variant:       # head address = hc + state * (hms + posStates hm2) + posState * hm2
+        hms = hms + lay["POS_STATES"] * hm2
     m.v.update(vlane=lane, vhc=hc, vhms=hms, vhm2=hm2, vlitnext=litnext,
                vlpm=np.full(64, (lc + lp) if "lctx" in variant else (1 << lp) - 1, dtype=np.uint32),   # lctx: the bit field's width
                vpm=np.full(64, (1 << pb) - 1, dtype=np.uint32))
@@ -151,6 +159,29 @@ def test_committed_loop_decodes_real_streams_on_the_emulator(program, family, n,
     out, m, entries, exits, in_pos = run_fast_loop(program, payload, lc, lp, pb, ds, n, p)
     assert out == p[:len(out)]
     # the loop ran until the checked path's margins: nearly everything was decoded by it, over many entries
+    assert len(out) > n - 336 - 300 or len(payload) - in_pos < 64, (len(out), n, in_pos, len(payload))
+    assert exits[1] == 0 and exits[2] == 0 and entries >= 1
+    rc, st = _reference_state_at(payload, lc, lp, pb, ds, n, len(out))
+    s = m.s
+    assert (s["range"], s["code"], s["state"]) == (rc.range, rc.code, st.state)
+    assert [s["rep0"], s["rep1"], s["rep2"], s["rep3"]] == st.reps
+    assert in_pos == rc.p and s["prev"] == p[len(out) - 1]
+
+
+@pytest.mark.parametrize("family,n,lc,lp,pb,ds", [("T", 6000, 3, 0, 2, 1 << 16), ("R", 1500, 3, 0, 2, 1 << 16), ("M", 5000, 0, 2, 0, 4096),
+                                                  ("Z", 9000, 1, 1, 1, 4096), ("T", 5000, 4, 0, 2, 5000), ("M", 4000, 2, 2, 1, 1 << 16)])
+def test_compact_loop_decodes_real_streams_on_the_emulator(family, n, lc, lp, pb, ds):
+    """round 5: the COMMITTED loop over the compact model layout (xlz_fastpath_pb2.inc: room for 4 posStates in every
+    table a posState indexes; what launches use when every unit's pb is <= 2) on the same streams as the full loop --
+    every byte, and range / code / state / reps / input position where it hands back."""
+    program = _render(("compact",))
+    assert program.lay["P_LIT"] == 924
+    p = corpus.plain(family, 4242 + n, n)
+    blob = corpus.compress_alone(p, dict_size=ds, lc=lc, lp=lp, pb=pb, known_size=True, preset=6 if family == "T" else 0)
+    ds = max(4096, int.from_bytes(blob[1:5], "little"))
+    payload = blob[13:]
+    out, m, entries, exits, in_pos = run_fast_loop(program, payload, lc, lp, pb, ds, n, p, strict_waits=(family == "M"))
+    assert out == p[:len(out)]
     assert len(out) > n - 336 - 300 or len(payload) - in_pos < 64, (len(out), n, in_pos, len(payload))
     assert exits[1] == 0 and exits[2] == 0 and entries >= 1
     rc, st = _reference_state_at(payload, lc, lp, pb, ds, n, len(out))

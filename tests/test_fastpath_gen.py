@@ -26,6 +26,26 @@ def test_committed_inc_is_generated_and_hazard_free():
     assert n_nops < 20  # instruction order, not s_nop, is what satisfies the wait states
 
 
+def test_the_compact_loop_is_the_same_loop_over_other_table_bases():
+    """xlz_fastpath_pb2.inc (round 5: the model layout with room for 4 posStates instead of 16, xlz_format.h:
+    ModelLayout<true>) is `--variant compact` of the same generator: committed text in sync, hazard-free, and instruction
+    for instruction the full loop with other numbers -- nothing but table bases may differ."""
+    import re
+    g = _load()
+    g.VARIANT.add("compact")
+    text, final, n_nops = g.render()
+    with open(os.path.join(ROOT, "lzma_amd", "csrc", "xlz_fastpath_pb2.inc")) as f:
+        assert f.read() == text, "run python3 tools/gen_fastpath.py --variant compact --out lzma_amd/csrc/xlz_fastpath_pb2.inc"
+    import hazards
+    assert hazards.analyse(final) == {}
+    full = open(os.path.join(ROOT, "lzma_amd", "csrc", "xlz_fastpath.inc")).read()
+    strip = lambda t: re.sub(r"\b(0x[0-9a-f]+|\d+)\b", "N", t)
+    assert strip(full) == strip(text) and full != text
+    lay = g.model_layout(True)
+    assert (lay["P_IS_REP"], lay["P_IS_REP0_LONG"], lay["P_POS_SLOT"], lay["P_LEN"], lay["P_REP_LEN"], lay["P_LIT"]) == (48, 96, 144, 532, 856, 924)
+    assert 2 * (lay["P_LIT"] + (0x100 << 3)) + 128 <= 5 * 1280     # lc+lp = 3: five LDS granules
+
+
 def test_committed_layout_keeps_conditional_branches_in_lower_halves():
     """tools/layout.py: behind the alignment directive every conditional branch of the committed
     loop sits at address mod 16 = 0 or 4 -- checked with the assembler's own instruction sizes -- and the pass

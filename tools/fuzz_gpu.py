@@ -37,13 +37,16 @@ def fuzz(ctx, budget, seed, per_round=160, verbose=True):
   while time.time() < t_end:
       rounds += 1
       streams, wants = [], []
+      # half of the rounds keep every pb <= 2, so that the launch uses the COMPACT model layout (round 5: room for four
+      # posStates, 24 workgroups per CU); the other half mixes pb up to 4 in: the full layout
+      pb_max = 2 if rounds % 4 < 2 else 4
       for _ in range(per_round):
           fam = "TRMZ"[int(rng.integers(0, 4))]
           n = int(rng.choice([1, 2, 17, 300, 335, 336, 337, 1000, 5000, 40000, 70000, 131072, 200000, 300001]))
           if rng.random() < 0.02:
               n = int(rng.choice([1 << 20, 3 << 20]))  # rare: streams far longer than the small dictionaries
           n = max(1, n + int(rng.integers(-3, 4)))
-          lc = int(rng.integers(0, 5)); lp = int(rng.integers(0, 5 - lc)); pb = int(rng.integers(0, 5))
+          lc = int(rng.integers(0, 5)); lp = int(rng.integers(0, 5 - lc)); pb = int(rng.integers(0, pb_max + 1))
           dict_size = int(rng.choice([4096, 4097, 5000, 8192, 65536, 65537, 100003, 1 << 20, 8 << 20]))
           p = corpus.plain(fam, int(rng.integers(1, 1 << 30)), n)
           if rng.random() < 0.75:
@@ -75,7 +78,8 @@ def fuzz(ctx, budget, seed, per_round=160, verbose=True):
       for _ in range(per_round // 6):
           r2 = random.Random(int(rng.integers(1, 1 << 62)))
           d2 = r2.choice([4096, 4097, 8192, 65536])
-          c, expect = random_lzma2_stream(r2, d2, props=ANY_PROPS if r2.random() < 0.3 else SMALL_PROPS)
+          wide = ANY_PROPS if pb_max == 4 else [q for q in ANY_PROPS if q[2] <= 2 or q[0] + q[1] > 8]   # (lc+lp > 8: the HBM-model launch)
+          c, expect = random_lzma2_stream(r2, d2, props=wide if r2.random() < 0.3 else SMALL_PROPS)
           cap = len(expect) + int(rng.choice([0, 0, 7, -1])) if len(expect) > 1 else len(expect)
           if rng.random() < 0.2 and len(c) > 8:
               c = bytearray(c)

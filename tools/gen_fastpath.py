@@ -57,11 +57,42 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-# probability-table layout: must match xlz_format.h (checked by static_asserts in the .hip)
-P_IS_MATCH, P_IS_REP, P_IS_REP_G0, P_IS_REP_G1, P_IS_REP_G2, P_IS_REP0_LONG = 0, 192, 204, 216, 228, 240
-P_POS_SLOT, P_POS_DEC, P_ALIGN, P_LEN, P_REP_LEN, P_LIT = 432, 688, 804, 820, 1336, 1596
+# probability-table layout: must match xlz_format.h (ModelLayout<COMPACT>; checked by static_asserts in the .hip).
+# Two layouts (round 5): the FULL one has room for 16 posStates in every table that is indexed by one (pb <= 4,
+# types.go:15); the COMPACT one for 4 (pb <= 2 -- liblzma's and 7-Zip's default is pb = 2): the 7416-byte model of
+# lc+lp = 3 becomes 5944 bytes = five of gfx950's LDS granules instead of six, and 24 workgroups fit a CU instead of 21.
+# Only the table bases differ: a posState still selects eight consecutive probabilities of a length tree, and the
+# (state, posState) pairs of isMatch / isRep0Long are addressed through per-lane constants that xlz_kernel.hip builds
+# (head_vectors).  `--variant compact` renders the compact loop (xlz_fastpath_pb2.inc).
 REP_HIGH_BYTES = 512  # the rep-length coder's high tree: the first 256 entries of the model's HBM part (xlz_format.h: kRepHigh)
-LEN_CHOICE, LEN_CHOICE2, LEN_LOW, LEN_MID, LEN_HIGH = 0, 1, 4, 132, 260
+LEN_CHOICE, LEN_CHOICE2, LEN_LOW = 0, 1, 4
+
+
+def model_layout(compact):
+    """-> dict of the table bases (units: 16-bit probabilities), xlz_format.h: ModelLayout<compact>"""
+    ps = 4 if compact else 16                     # posStates a table has room for
+    d = {"P_IS_MATCH": 0, "P_IS_REP": 12 * ps}
+    d["P_IS_REP_G0"], d["P_IS_REP_G1"], d["P_IS_REP_G2"] = d["P_IS_REP"] + 12, d["P_IS_REP"] + 24, d["P_IS_REP"] + 36
+    d["P_IS_REP0_LONG"] = d["P_IS_REP"] + 48
+    d["P_POS_SLOT"] = d["P_IS_REP0_LONG"] + 12 * ps
+    d["P_POS_DEC"] = d["P_POS_SLOT"] + 256
+    d["P_ALIGN"] = d["P_POS_DEC"] + 116
+    d["P_LEN"] = d["P_ALIGN"] + 16
+    d["LEN_MID"] = LEN_LOW + 8 * ps
+    d["LEN_HIGH"] = LEN_LOW + 16 * ps
+    d["P_REP_LEN"] = d["P_LEN"] + d["LEN_HIGH"] + 256
+    d["P_LIT"] = d["P_REP_LEN"] + d["LEN_HIGH"]   # (the rep-length coder's high tree is not in LDS)
+    d["POS_STATES"] = ps
+    return d
+
+
+def set_layout(compact):
+    globals().update(model_layout(compact))
+
+
+set_layout(False)
+assert (P_IS_REP, P_IS_REP0_LONG, P_POS_SLOT, P_POS_DEC, P_ALIGN, P_LEN, LEN_MID, LEN_HIGH, P_REP_LEN, P_LIT) == \
+    (192, 240, 432, 688, 804, 820, 132, 260, 1336, 1596)
 
 # head gather lanes (the per-lane address constants are built in xlz_kernel.hip: head_vectors)
 H_IS_MATCH, H_IS_REP, H_G0, H_G1, H_G2, H_REP0_LONG, H_LEN_C, H_LEN_C2, H_REP_C, H_REP_C2 = range(10)
@@ -1908,6 +1939,7 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 def render():
     """-> (text of xlz_fastpath.inc, final instruction lines, number of s_nop the hazard pass added)"""
+    set_layout("compact" in VARIANT)
     gen()
     final, n_nops = hazards.fix(lines, verbose=bool(os.environ.get("XLZ_GEN_VERBOSE")))
     assert not hazards.analyse(final)
