@@ -283,6 +283,7 @@ def occupancy(batch, kernel_ms):
     corr = float(np.corrcoef(in_len.astype(np.float64), dur)[0, 1]) if len(dur) > 2 and dur.std() > 0 else None
     q = np.percentile(dur, [0, 50, 90, 99, 100]) / 1e3
     return {"slot_occupancy": round(float(dur.sum()) / (slots * span), 4), "slots": int(slots), "lds_bytes_per_slot": int(lds),
+            "kernel": batch.kernel_name(),
             "units": int(len(dur)), "rounds": round(len(dur) / slots, 2), "launch_span_ms": round(span / 1e3, 3),
             "unit_ms": {"min": round(q[0], 3), "p50": round(q[1], 3), "p90": round(q[2], 3), "p99": round(q[3], 3),
                         "max": round(q[4], 3)},
@@ -374,7 +375,7 @@ def roofline(name, cin, cout, units, kernel_ms, occ=None, lone=None):
     r = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 6),
          "traffic": prof["traffic_bytes_per_launch"] if prof else None,
-         "kernel": "xlz::xlz_decode_kernel", "kernel_ms": round(kernel_ms, 3),
+         "kernel": (occ or {}).get("kernel", "xlz::xlz_decode_kernel"), "kernel_ms": round(kernel_ms, 3),
          "algorithmic_bytes_per_launch": algo, "units_per_launch": units}
     issue = dict(occ) if occ else {}
     issue.update(issue_bounds(prof, cout, kernel_ms, lone, occ["slots"] if occ else None, algo))

@@ -240,6 +240,11 @@ int xlz_batch_unit_trace(xlz_batch *batch, uint32_t *t_start, uint32_t *t_end, u
                          size_t cap, size_t *n_units);
 /* shape of the decode launch: resident single-wave workgroups (= wave slots) and LDS bytes each */
 int xlz_batch_launch_info(xlz_batch *batch, uint32_t *workgroups, uint32_t *lds_bytes);
+/* which kernel the batch's main launch is (profiles are matched by it): "xlz::xlz_decode_kernel" -- the model laid out
+ * with room for 16 posStates (pb <= 4) --, "xlz::xlz_decode_kernel_pb2" -- room for 4: every unit's pb <= 2, the
+ * default of liblzma and 7-Zip; five LDS granules instead of six for lc+lp = 3, 24 workgroups per CU instead of 21 --
+ * or "xlz::xlz_decode_kernel_hbm_model" (only models beyond LDS, lc+lp > 8)                                          */
+const char *xlz_batch_kernel_name(xlz_batch *batch);
 void xlz_batch_destroy(xlz_batch *batch);
 
 /* ---- pull-style readers mirroring the reference's Go surface --------------- */

@@ -263,6 +263,10 @@ class Batch:
             raise LzmaError(st, "xlz_batch_launch_info")
         return a.value, b.value
 
+    def kernel_name(self):
+        """the kernel of the batch's main launch (xlz_batch_kernel_name): the full or the compact (pb <= 2) model layout"""
+        return N.lib().xlz_batch_kernel_name(self._h).decode()
+
     def unit_trace(self):
         """(t_start, t_end, in_len) numpy uint32 arrays, one entry per unit of the last run: ticks of
         the device's 100 MHz clock since the first unit started (xlz_batch_unit_trace)."""

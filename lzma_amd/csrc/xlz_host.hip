@@ -1572,6 +1572,13 @@ extern "C" int xlz_batch_launch_info(xlz_batch *b, uint32_t *workgroups, uint32_
     return XLZ_OK;
 }
 
+extern "C" const char *xlz_batch_kernel_name(xlz_batch *b)
+{
+    if (!b) return "";
+    if (!b->n_normal) return "xlz::xlz_decode_kernel_hbm_model";
+    return b->compact ? "xlz::xlz_decode_kernel_pb2" : "xlz::xlz_decode_kernel";
+}
+
 extern "C" int xlz_batch_device_output(xlz_batch *b, size_t i, void **dptr, size_t *cap)
 {
     if (!b || i >= b->n || !dptr) return XLZ_ERR_BAD_ARG;

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import save_profile as SP
 
-KERNEL = "xlz::xlz_decode_kernel("
+KERNELS = ("xlz::xlz_decode_kernel(", "xlz::xlz_decode_kernel_pb2(")   # the full and the compact (pb <= 2) model layout
 WIDE_READS = {"cfg4-R"}   # configs whose launch is the stored-chunk copy: 16-byte-per-lane streaming reads (FETCH_SIZE x 2)
 
 
@@ -60,7 +60,7 @@ def main():
         per_cfg_line[c["name"]] = c
 
     # ---- kernel trace: launches in time order
-    tr = [r for r in csv.DictReader(open(one(src + "/kt/*/*kernel_trace.csv"))) if r["Kernel_Name"].startswith(KERNEL)]
+    tr = [r for r in csv.DictReader(open(one(src + "/kt/*/*kernel_trace.csv"))) if r["Kernel_Name"].startswith(KERNELS)]
     tr.sort(key=lambda r: int(r["Start_Timestamp"]))
     header = list(tr[0].keys())
     tr_by = split(tr, legs, "kernel trace")
@@ -71,7 +71,7 @@ def main():
     vals_by = collections.defaultdict(lambda: collections.defaultdict(list))
     grid_by = {}
     for sub in ("fetch", "write", "sq", "sq2"):
-        rs = [r for r in csv.DictReader(open(one(src + "/%s/*/*counter_collection.csv" % sub))) if r["Kernel_Name"].startswith(KERNEL)]
+        rs = [r for r in csv.DictReader(open(one(src + "/%s/*/*counter_collection.csv" % sub))) if r["Kernel_Name"].startswith(KERNELS)]
         ids = sorted({int(r["Dispatch_Id"]) for r in rs})
         which = {}
         for name, chunk in split(ids, legs, sub + " pass").items():
@@ -109,7 +109,7 @@ def main():
             with open(pre + "_kernel_stats.csv", "w") as g:
                 w = csv.writer(g)
                 w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
-                w.writerow(["xlz::xlz_decode_kernel(xlz::LaunchParams)", len(dur), sum(dur), sum(dur) / len(dur), min(dur), max(dur)])
+                w.writerow([tr_by[name][0]["Kernel_Name"], len(dur), sum(dur), sum(dur) / len(dur), min(dur), max(dur)])
             stats_note = "computed from this config's launches in the kernel trace (the --stats table of the whole process: all_kernel_stats.csv)"
         with open(pre + "_pmc.csv", "w") as g:
             w = csv.writer(g)
@@ -131,10 +131,10 @@ def main():
                   % (pn, c["value"], c["roofline"]["kernel_ms"], c["roofline"]["achieved"]))
             p("\n## --kernel-trace (%s)\n" % stats_note)
             p("| kernel | calls | total ns | avg ns |\n|---|---|---|---|")
-            p("| xlz::xlz_decode_kernel(xlz::LaunchParams) | %d | %d | %.0f |" % (len(dur), sum(dur), sum(dur) / len(dur)))
+            p("| %s | %d | %d | %.0f |" % (tr_by[name][0]["Kernel_Name"], len(dur), sum(dur), sum(dur) / len(dur)))
             p("\nper launch of the decode kernel, in launch order (ms): %s -- the first is bench.py's untimed warm-up, the rest are "
               "the timed steps and agree with the HIP-event figure above." % ", ".join("%.3f" % (x / 1e6) for x in dur))
-            p("\n## PMC (per launch of xlz_decode_kernel, summed over the device)\n")
+            p("\n## PMC (per launch of the decode kernel, summed over the device)\n")
             p("| counter | per launch (mean) | launches |\n|---|---|---|")
             for k, v in sorted(vals.items()):
                 p("| %s | %.6g | %d |" % (k, sum(v) / len(v), len(v)))
