@@ -1466,6 +1466,12 @@ static uint32_t decode_per_cu(uint32_t max_lc_lp, uint32_t n_units, int num_cus,
     // the most a CU holds from 3.2 rounds of that many on, else 20, else 16 (four per SIMD).  Measured on the headline's
     // data (profiles/r05/ab_shard_sizes.txt): 16 384 units -- 3.2 rounds of 5120 -- run 6.7 % faster with 20 per CU than as
     // four rounds of 16 per CU (round 3's rule asked for four rounds of 5120 and chose 16); 8192 units 4.1 % slower.
+    // ... and a launch that fits ONE round at a higher occupancy takes it: 5000 units are one round of 20 per CU (every
+    // wave a little slower) instead of a full round of 16 per CU and a second one a fifth full -- and a call of one round
+    // can overlap its copies with its decode (xlz_host.hip: slices)
+    const uint32_t one_round[3] = {16u, 20u, per_cu};
+    for (uint32_t c : one_round)
+        if (c <= per_cu && n_units <= c * (uint32_t)num_cus) return c > 4 && c < 16 ? (c & ~3u) : c;
     const uint32_t steps[3] = {per_cu, 20u, 16u};
     for (uint32_t c : steps)
         if (c <= per_cu && (c <= 16 || (uint64_t)n_units * 5u >= 16ull * c * (uint32_t)num_cus)) { // (3.2 rounds: not "just over three")

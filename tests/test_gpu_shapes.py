@@ -213,3 +213,23 @@ def test_a_call_of_one_wave_round_runs_in_slices(ctx):
         assert lzma_amd.decode_batch(ctx, [j[0] for j in jobs]) == got
     finally:
         ctx.set_slicing(0, 0, 0)
+
+
+def test_a_call_of_5000_streams_is_one_round_of_20_per_cu(ctx):
+    """round 5: a launch that fits ONE round at a higher occupancy takes it -- 5000 units are one round of 20 workgroups
+    per CU, not a full round of 16 per CU and a second one a fifth full -- and a call of one round runs in slices
+    (xlz_call_stats: wave_slots, slices); every stream's bytes by SHA-256, a damaged one against the oracle."""
+    n, size = 5000, 8192
+    comp, digests = corpus.make_alone_batch("M", n, size, base_seed=97_000, preset={"mode": 1, "mf": 3, "nice_len": 32, "depth": 2})
+    comp = list(comp)
+    comp[1234] = comp[1234][: len(comp[1234]) // 2]
+    ctx.set_slicing(1, 8 << 20, 4)
+    try:
+        got = lzma_amd.decode_batch(ctx, [Stream(c, FMT_LZMA_ALONE, out_cap=size) for c in comp])
+        st = ctx.last_call_stats()
+    finally:
+        ctx.set_slicing(0, 0, 0)
+    assert st["slices"] == 4 and st["sub_batches"] == 1 and st["units"] == n
+    assert st["wave_slots"] == n and 4096 < n <= 20 * 256      # (the grid is the units: all of them resident at once)
+    assert got[1234] == oracle.lzma1_alone(comp[1234], size)
+    assert all(g[1] == 0 and hashlib.sha256(g[0]).digest() == d for i, (g, d) in enumerate(zip(got, digests)) if i != 1234)
