@@ -140,9 +140,11 @@ int xlz_ctx_batching_stats(xlz_ctx *ctx, uint64_t *batches, uint64_t *streams);
  * value is XLZ_OK unless the call itself could not run; per-stream outcomes are in
  * results[i].  Thread-safe across contexts; calls on one context are serialised.
  * A call of several wave rounds (>= 8192 streams and >= 1 GiB of output) is cut into up
- * to eight sub-batches whose upload, decode and download overlap.
+ * to ten sub-batches whose upload, decode and download overlap; a call of ONE wave round (and
+ * at least 256 MiB of output) runs as up to eight launches whose downloads overlap the decode
+ * (xlz_call_stats.slices, xlz_ctx_set_slicing).  Bytes of `out` beyond out_len are unspecified.
  * BREAK-EVEN: one wave decodes one unit (a stream; an LZMA2 dictionary-reset unit) at
- * 4-6 MB/s and the chip holds 4096 of them, so a call with few units is slower than the
+ * 4-6 MB/s and the chip holds 4096 of them (up to 6144 on calls of many rounds), so a call with few units is slower than the
  * host's own cores: measured on 1 MiB text streams, 64 units 0.34 GiB/s (16 host cores:
  * 1.27), 256 units 1.37 (1.28), 1024 units 5.2, 4096 units 17.2.  Below about 250 units
  * per 16 host cores decode on the CPU, or gather more streams first;
