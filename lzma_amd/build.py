@@ -11,11 +11,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libxlz.so")
 SOURCES = ["xlz_kernel.hip", "xlz_host.hip", "xlz_xz.hip", "xlz_7z.hip"]
-HEADERS = ["xlz_format.h", "xlz_check.h", "xlz_fastpath.inc", "xlz_fastpath_pb2.inc", os.path.join("..", "..", "include", "xlz.h")]
+HEADERS = ["xlz_format.h", "xlz_check.h", "xlz_fastpath.inc", "xlz_fastpath_pb2.inc", "xlz_fastpath_pb2_br.inc", os.path.join("..", "..", "include", "xlz.h")]
 ARCH = "gfx950"
 
 
-KERNEL_FILES = ["xlz_kernel.hip", "xlz_fastpath.inc", "xlz_fastpath_pb2.inc", "xlz_format.h"]  # what the device code is made of
+KERNEL_FILES = ["xlz_kernel.hip", "xlz_fastpath.inc", "xlz_fastpath_pb2.inc", "xlz_fastpath_pb2_br.inc", "xlz_format.h"]  # what the device code is made of
 
 
 def source_id(files=None):

@@ -246,6 +246,7 @@ int launch_gather(const SlicePiece *pieces, uint32_t n_pieces, uint8_t *arena, u
 int launch_decode(const LaunchParams &p, int num_cus, void *stream /* hipStream_t */, uint32_t max_grid = 0 /* HBM-model launch: at most that many workgroups */);
 uint32_t decode_lds_bytes(uint32_t max_lc_lp, bool compact = false);
 uint32_t big_model_grid(int num_cus);
+bool decode_branchy(uint32_t max_lc_lp, int num_cus, uint32_t n_units, bool compact); // the launch runs the branchy loop (xlz_kernel.hip)
 uint32_t decode_grid(uint32_t max_lc_lp, int num_cus, uint32_t n_units, bool compact = false); // resident workgroups of the LDS-model launch over n_units units (~0u: the most)
 
 } // namespace xlz

@@ -1576,6 +1576,7 @@ extern "C" const char *xlz_batch_kernel_name(xlz_batch *b)
 {
     if (!b) return "";
     if (!b->n_normal) return "xlz::xlz_decode_kernel_hbm_model";
+    if (decode_branchy(b->max_lc_lp, b->ctx->num_cus, b->many_rounds ? ~0u : b->n_normal, b->compact)) return "xlz::xlz_decode_kernel_pb2_br";
     return b->compact ? "xlz::xlz_decode_kernel_pb2" : "xlz::xlz_decode_kernel";
 }
 

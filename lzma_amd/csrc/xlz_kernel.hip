@@ -633,6 +633,17 @@ enum : uint32_t { FX_LIMIT = 0, FX_ERR = 1, FX_MARKER = 2, FX_COPY = 3 };
 #ifndef XLZ_FASTPATH_PB2_INC // the same loop over the compact layout (gen_fastpath.py --variant compact)
 #define XLZ_FASTPATH_PB2_INC "xlz_fastpath_pb2.inc"
 #endif
+// ... and with BRANCHY decisions (gen_fastpath.py --variant compact,dbr,dbrs): every decision branches on its outcome and
+// each outcome writes range and tree slot itself -- five scalar instructions per tree level instead of seven, one short
+// forward branch per outcome.  Which of the two is faster depends on how many waves share a CU (profiles/r05/
+// ab_dbr_at_24_per_cu.txt, ab_dbrs_combos.txt): with 16 per CU a wave mostly waits for its own previous instruction and
+// the branches' bubbles cost 3-5 % (rounds 3 and 4 measured exactly that and left the switch off); with 24 per CU the
+// CU's one scalar unit is what binds (0.86 scalar instructions per CU cycle of 0.97 possible) and the branchy loop is
+// 4.5-5 % FASTER; with 20 per CU it is still 5 % slower.  So launches that get 24 workgroups per CU run this loop.
+#ifndef XLZ_FASTPATH_PB2_BR_INC
+#define XLZ_FASTPATH_PB2_BR_INC "xlz_fastpath_pb2_br.inc"
+#endif
+constexpr uint32_t kBranchyPerCu = 24; // workgroups per CU from which on a launch runs the branchy loop (compact layout only)
 
 // Per-lane constants of the head gather: lane j fetches the j-th context-selected probability a
 // packet can start with; its LDS byte address is hc + state * hms + state2 * hm2.
@@ -683,8 +694,9 @@ template <class L> __device__ __forceinline__ HeadVec head_vectors(uint32_t lane
           "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", \
           "v63"
 
-// COMPACT: the loop rendered over the compact layout (only table bases differ; hv comes from head_vectors<ModelLayout<COMPACT>>)
-template <bool COMPACT>
+// COMPACT: the loop rendered over the compact layout (only table bases differ; hv comes from head_vectors<ModelLayout<COMPACT>>);
+// BRANCHY (compact only): the loop with branchy decisions, for launches of 24 workgroups per CU
+template <bool COMPACT, bool BRANCHY>
 __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_t *mprobs, uint32_t lane,
                                                    const HeadVec &hv, uint32_t arel_lim, uint32_t pos_lim,
                                                    uint32_t &lenout)
@@ -698,7 +710,12 @@ __device__ __forceinline__ uint32_t lzma_fast_loop(Dec &d, uint8_t *out, uint16_
     asm volatile("v_mov_b32 %0, %1" : "=v"(vlpm) : "s"(d.lp_mask));
 #endif
     asm volatile("v_mov_b32 %0, %1" : "=v"(vpm) : "s"(d.pos_mask));
-    if constexpr (COMPACT) {
+    static_assert(COMPACT || !BRANCHY, "the branchy loop exists over the compact layout only");
+    if constexpr (COMPACT && BRANCHY) {
+        asm volatile(
+#include XLZ_FASTPATH_PB2_BR_INC
+            XLZ_FAST_OPERANDS);
+    } else if constexpr (COMPACT) {
         asm volatile(
 #include XLZ_FASTPATH_PB2_INC
             XLZ_FAST_OPERANDS);
@@ -750,7 +767,7 @@ __device__ __forceinline__ void rank_priority(Dec &d, uint32_t lane)
 }
 
 // (*Reader1).decompress run to the end of the current LZMA chunk (decompress.go:8-1136)
-template <bool COMPACT>
+template <bool COMPACT, bool BRANCHY>
 __device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint16_t *__restrict__ mprobs,
                                         uint8_t *__restrict__ out, uint32_t lane, const HeadVec &hv, bool allow_fast)
 {
@@ -782,7 +799,7 @@ __device__ __forceinline__ int lzma_run(Dec &d, uint16_t *probs, uint16_t *__res
         if (d.size_defined) room = (uint32_t)min((uint64_t)room, d.bytes_left - kFastOutput);
         const uint32_t pos0 = d.pos;
         uint32_t len = 0;
-        const uint32_t ec = lzma_fast_loop<COMPACT>(d, out, mprobs, lane, hv, arel_lim, min(pos0 + room + 1, d.pause_at), len);
+        const uint32_t ec = lzma_fast_loop<COMPACT, BRANCHY>(d, out, mprobs, lane, hv, arel_lim, min(pos0 + room + 1, d.pause_at), len);
         d.bytes_left -= d.pos - pos0; // :172,660,665 ... (wraps harmlessly when the size is undefined)
         if (ec == FX_ERR) return RUN_ERR_RESULT; // :651-653, :690-692
         if (ec == FX_MARKER) {                    // end marker :633-645 (bytesLeft > 0 here if defined)
@@ -1137,7 +1154,7 @@ __device__ __forceinline__ void model_copy(uint32_t *__restrict__ dst, const uin
 // BIG = false: the model is this workgroup's LDS (the asm fast loop addresses it from LDS offset
 // 0).  BIG = true (lc+lp > 6): the model is a slot of HBM scratch and only the checked C++
 // packet decoder runs -- slow, but the reference's whole parameter range decodes.
-template <bool BIG, bool COMPACT>
+template <bool BIG, bool COMPACT, bool BRANCHY = false>
 __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *probs, uint16_t *__restrict__ wg_mprobs)
 {
     static_assert(!(BIG && COMPACT), "the HBM-model launch uses the full layout");
@@ -1301,7 +1318,7 @@ __device__ __forceinline__ void decode_units(const LaunchParams &p, uint16_t *pr
                 // after the last copy.
                 if (d.state >= 7) reload_context(d, out, lane);
             }
-            const int r = lzma_run<COMPACT>(d, probs, mprobs, out, lane, hv, !big);
+            const int r = lzma_run<COMPACT, BRANCHY>(d, probs, mprobs, out, lane, hv, !big);
             if (r == RUN_PAUSE) {
                 status = ST_PAUSED;
                 break;
@@ -1382,6 +1399,14 @@ void xlz_decode_kernel_pb2(LaunchParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds_probs[];
     decode_units<false, true>(p, lds_probs, p.mlit + (size_t)blockIdx.x * p.mlit_stride);
+}
+
+// ... with the branchy loop: launches of kBranchyPerCu workgroups per CU
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XLZ_WAVES_PER_EU, XLZ_WAVES_PER_EU)))
+void xlz_decode_kernel_pb2_br(LaunchParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds_probs[];
+    decode_units<false, true, true>(p, lds_probs, p.mlit + (size_t)blockIdx.x * p.mlit_stride);
 }
 
 __global__ __launch_bounds__(64) void xlz_decode_kernel_hbm_model(LaunchParams p)
@@ -1489,6 +1514,17 @@ uint32_t decode_grid(uint32_t max_lc_lp, int num_cus, uint32_t n_units, bool com
     return decode_per_cu(max_lc_lp, n_units, num_cus, compact) * (uint32_t)num_cus;
 }
 
+// does a launch over n_units units (~0u: of many rounds) run the branchy loop?  (compact layout at kBranchyPerCu per CU)
+bool decode_branchy(uint32_t max_lc_lp, int num_cus, uint32_t n_units, bool compact)
+{
+#ifdef XLZ_NO_BRANCHY // A/B builds
+    return false;
+#endif
+    if (const char *e = getenv("XLZ_BRANCHY")) // development aid (tools/fuzz_gpu.py): "1" runs every compact launch through the
+        return compact && e[0] == '1';         // branchy loop, "0" none -- the results must not depend on it
+    return compact && decode_per_cu(max_lc_lp, n_units, num_cus, compact) >= kBranchyPerCu;
+}
+
 int launch_decode(const LaunchParams &p, int num_cus, void *stream, uint32_t max_grid)
 {
     if (p.scratch) { // HBM-resident model
@@ -1505,9 +1541,13 @@ int launch_decode(const LaunchParams &p, int num_cus, void *stream, uint32_t max
     uint32_t grid = decode_grid(p.max_lc_lp, num_cus, p.many_rounds ? ~0u : p.n_units, compact);
     if (grid > p.n_units) grid = p.n_units;
     if (grid == 0) return 0;
-    const void *fn = compact ? reinterpret_cast<const void *>(xlz_decode_kernel_pb2) : reinterpret_cast<const void *>(xlz_decode_kernel);
+    const bool branchy = decode_branchy(p.max_lc_lp, num_cus, p.many_rounds ? ~0u : p.n_units, compact);
+    const void *fn = branchy ? reinterpret_cast<const void *>(xlz_decode_kernel_pb2_br)
+                     : compact ? reinterpret_cast<const void *>(xlz_decode_kernel_pb2) : reinterpret_cast<const void *>(xlz_decode_kernel);
     if (lds > 64u * 1024u && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes) != hipSuccess) return -2;
-    if (compact)
+    if (branchy)
+        hipLaunchKernelGGL(xlz_decode_kernel_pb2_br, dim3(grid), dim3(kWave), lds, (hipStream_t)stream, p);
+    else if (compact)
         hipLaunchKernelGGL(xlz_decode_kernel_pb2, dim3(grid), dim3(kWave), lds, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(xlz_decode_kernel, dim3(grid), dim3(kWave), lds, (hipStream_t)stream, p);

@@ -170,11 +170,13 @@ def test_committed_loop_decodes_real_streams_on_the_emulator(program, family, n,
 
 @pytest.mark.parametrize("family,n,lc,lp,pb,ds", [("T", 6000, 3, 0, 2, 1 << 16), ("R", 1500, 3, 0, 2, 1 << 16), ("M", 5000, 0, 2, 0, 4096),
                                                   ("Z", 9000, 1, 1, 1, 4096), ("T", 5000, 4, 0, 2, 5000), ("M", 4000, 2, 2, 1, 1 << 16)])
-def test_compact_loop_decodes_real_streams_on_the_emulator(family, n, lc, lp, pb, ds):
-    """round 5: the COMMITTED loop over the compact model layout (xlz_fastpath_pb2.inc: room for 4 posStates in every
-    table a posState indexes; what launches use when every unit's pb is <= 2) on the same streams as the full loop --
-    every byte, and range / code / state / reps / input position where it hands back."""
-    program = _render(("compact",))
+@pytest.mark.parametrize("branchy", [False, True])
+def test_compact_loop_decodes_real_streams_on_the_emulator(family, n, lc, lp, pb, ds, branchy):
+    """round 5: the COMMITTED loops over the compact model layout (xlz_fastpath_pb2.inc: room for 4 posStates in every
+    table a posState indexes; what launches use when every unit's pb is <= 2 -- and xlz_fastpath_pb2_br.inc, the same with
+    branchy decisions, what launches of 24 workgroups per CU run) on the same streams as the full loop -- every byte, and
+    range / code / state / reps / input position where it hands back."""
+    program = _render(("compact", "dbr", "dbrs") if branchy else ("compact",))
     assert program.lay["P_LIT"] == 924
     p = corpus.plain(family, 4242 + n, n)
     blob = corpus.compress_alone(p, dict_size=ds, lc=lc, lp=lp, pb=pb, known_size=True, preset=6 if family == "T" else 0)

@@ -41,6 +41,13 @@ def test_the_compact_loop_is_the_same_loop_over_other_table_bases():
     full = open(os.path.join(ROOT, "lzma_amd", "csrc", "xlz_fastpath.inc")).read()
     strip = lambda t: re.sub(r"\b(0x[0-9a-f]+|\d+)\b", "N", t)
     assert strip(full) == strip(text) and full != text
+    # the third committed loop: the compact layout with BRANCHY decisions (launches of 24 workgroups per CU)
+    g2 = _load()
+    g2.VARIANT.update(("compact", "dbr", "dbrs"))
+    text_br, final_br, _ = g2.render()
+    with open(os.path.join(ROOT, "lzma_amd", "csrc", "xlz_fastpath_pb2_br.inc")) as f:
+        assert f.read() == text_br, "run python3 tools/gen_fastpath.py --variant compact,dbr,dbrs --out lzma_amd/csrc/xlz_fastpath_pb2_br.inc"
+    assert hazards.analyse(final_br) == {}
     lay = g.model_layout(True)
     assert (lay["P_IS_REP"], lay["P_IS_REP0_LONG"], lay["P_POS_SLOT"], lay["P_LEN"], lay["P_REP_LEN"], lay["P_LIT"]) == (48, 96, 144, 532, 856, 924)
     assert 2 * (lay["P_LIT"] + (0x100 << 3)) + 128 <= 5 * 1280     # lc+lp = 3: five LDS granules

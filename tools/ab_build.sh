@@ -15,10 +15,18 @@ while [ $# -gt 0 ]; do
 done
 mkdir -p build_ab
 python3 tools/gen_fastpath.py "${GEN[@]}" --out lzma_amd/csrc/xlz_fastpath_$NAME.inc | tail -1
+# ... and the same variant over the compact model layout (launches whose units all have pb <= 2 run THAT loop)
+GENC=(); HAVE_VARIANT=0
+for ((i = 0; i < ${#GEN[@]}; i += 2)); do
+    if [ "${GEN[i]}" = "--variant" ]; then GENC+=(--variant "${GEN[i+1]},compact"); HAVE_VARIANT=1; else GENC+=("${GEN[i]}" "${GEN[i+1]}"); fi
+done
+[ $HAVE_VARIANT = 1 ] || GENC+=(--variant compact)
+python3 tools/gen_fastpath.py "${GENC[@]}" --out lzma_amd/csrc/xlz_fastpath_${NAME}_pb2.inc | tail -1
 python3 - "$NAME" "${FLAGS[@]}" <<'PY'
 import sys
 sys.path.insert(0, ".")
 from lzma_amd import build
 name, flags = sys.argv[1], sys.argv[2:]
-print(build.build(force=True, extra_flags=['-DXLZ_FASTPATH_INC="xlz_fastpath_%s.inc"' % name] + flags, out="build_ab/%s.so" % name))
+print(build.build(force=True, extra_flags=['-DXLZ_FASTPATH_INC="xlz_fastpath_%s.inc"' % name, '-DXLZ_FASTPATH_PB2_INC="xlz_fastpath_%s_pb2.inc"' % name] + flags,
+                  out="build_ab/%s.so" % name))
 PY

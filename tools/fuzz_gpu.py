@@ -40,6 +40,9 @@ def fuzz(ctx, budget, seed, per_round=160, verbose=True):
       # half of the rounds keep every pb <= 2, so that the launch uses the COMPACT model layout (round 5: room for four
       # posStates, 24 workgroups per CU); the other half mixes pb up to 4 in: the full layout
       pb_max = 2 if rounds % 4 < 2 else 4
+      # ... and every other compact round runs the loop with BRANCHY decisions (what launches of 24 workgroups per CU run;
+      # XLZ_BRANCHY is the library's development switch for it)
+      os.environ["XLZ_BRANCHY"] = "1" if rounds % 4 == 1 else "0"
       for _ in range(per_round):
           fam = "TRMZ"[int(rng.integers(0, 4))]
           n = int(rng.choice([1, 2, 17, 300, 335, 336, 337, 1000, 5000, 40000, 70000, 131072, 200000, 300001]))
@@ -111,6 +114,7 @@ def fuzz(ctx, budget, seed, per_round=160, verbose=True):
       if verbose:
         print("round %d: %d streams ok so far (%d with a non-OK status; %d rounds ran in slices)" % (rounds, n_total, n_bad_status, n_sliced_rounds), flush=True)
   ctx.set_slicing(0, 0, 0)
+  os.environ.pop("XLZ_BRANCHY", None)
   return n_total, n_bad_status
 
 

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import save_profile as SP
 
-KERNELS = ("xlz::xlz_decode_kernel(", "xlz::xlz_decode_kernel_pb2(")   # the full and the compact (pb <= 2) model layout
+KERNELS = ("xlz::xlz_decode_kernel(", "xlz::xlz_decode_kernel_pb2(", "xlz::xlz_decode_kernel_pb2_br(")   # full layout; compact (pb <= 2); compact with branchy decisions (24 per CU)
 WIDE_READS = {"cfg4-R"}   # configs whose launch is the stored-chunk copy: 16-byte-per-lane streaming reads (FETCH_SIZE x 2)
 
 
