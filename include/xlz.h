@@ -214,7 +214,8 @@ int xlz_ctx_last_call_stats(xlz_ctx *ctx, xlz_call_stats *out);
  * itself).  xlz_ctx_trim releases all of it now; *released (may be NULL) = the bytes given back.      */
 int xlz_ctx_trim(xlz_ctx *ctx, uint64_t *released);
 /* Tuning of xlz_decode_batch's sliced form (xlz_call_stats.slices): a call of one wave round with at least
- * min_call_bytes of output room runs as one launch for every slice_bytes of it, at most max_slices (<= 64).
+ * min_call_bytes of output room runs as one launch for every slice_bytes of it, at most max_slices (<= 63; from
+ * four on the last share is cut in two -- its download is the one nothing overlaps --: one launch more).
  * 0 = the default of that argument (256 MiB, 128 MiB, 8); max_slices = 1 turns slicing off.  The decoded
  * bytes, statuses and consumed input do not depend on it.  The reference's counterpart is the size of the
  * buffer its caller hands to Read (reader1.go:223-254: decompress(need) runs until `need` bytes are pending). */

@@ -986,8 +986,12 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
     if (want_slices > 1 && b->n_normal && b->n_normal <= decode_grid(b->max_lc_lp, ctx->num_cus, b->many_rounds ? ~0u : b->n_normal, b->compact)) {
         // sliced batch: equal shares of every unit's output per launch; a state block per unit; per launch the table of
         // the pieces it finishes (unit order = arena order, packed back to back on 256-byte boundaries)
-        const uint32_t K = std::min<uint32_t>(want_slices, 64);
-        for (uint32_t k = 1; k <= K; k++) b->slice_fracs.push_back(k == K ? kSliceOne : (uint32_t)((uint64_t)kSliceOne * k / K));
+        // equal shares -- but the LAST share is cut in two (from four slices on): its download is the one nothing overlaps
+        const uint32_t K0 = std::min<uint32_t>(want_slices, 63);
+        for (uint32_t k = 1; k < K0; k++) b->slice_fracs.push_back((uint32_t)((uint64_t)kSliceOne * k / K0));
+        if (K0 >= 4) b->slice_fracs.push_back((uint32_t)((uint64_t)kSliceOne * (2 * K0 - 1) / (2 * K0)));
+        b->slice_fracs.push_back(kSliceOne);
+        const uint32_t K = (uint32_t)b->slice_fracs.size();
         b->state_stride = align_up(state_bytes(b->max_lc_lp), kArenaAlign);
         if (!batch_alloc(b, &b->d_states, nu * b->state_stride)) return fail(XLZ_ERR_DEVICE);
         for (size_t k = 0; k < nu; k++) // (a unit of the HBM-model launch keeps state == 0: it is an ordinary unit there)
@@ -1938,7 +1942,7 @@ extern "C" int xlz_ctx_set_slicing(xlz_ctx *ctx, uint64_t min_call_bytes, uint64
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->sliced_call_bytes = min_call_bytes ? min_call_bytes : kSlicedCallBytes;
     ctx->slice_bytes = slice_bytes ? slice_bytes : kSliceBytes;
-    ctx->max_slices = max_slices ? std::min<uint32_t>(max_slices, 64) : (uint32_t)kMaxSlices;
+    ctx->max_slices = max_slices ? std::min<uint32_t>(max_slices, 63) : (uint32_t)kMaxSlices;
     return XLZ_OK;
 }
 
