@@ -208,8 +208,9 @@ struct LaunchParams {
     uint32_t compact;      // != 0: the LDS model uses the COMPACT layout (ModelLayout<true>: every unit's pb <= 2); the host sets it
                            // when every unit of the launch allows it, never for sessions or the HBM-model launch
     uint32_t pad_;
-    uint32_t many_rounds;  // != 0: one of a sequence of launches that follow each other without a gap (the sub-batches of a
-                           // pipelined call): as many workgroups per CU as a launch of many rounds takes, whatever n_units
+    uint32_t call_units;   // != 0: the launch is one piece of a pipelined call of that many units in all, whose pieces' launches
+                           // follow each other without a gap (two streams): workgroups per CU as ONE launch over call_units units
+                           // would take (decode_per_cu), whatever this piece's n_units
 };
 constexpr uint32_t kSliceOne = 65536;
 // output position (relative to the unit) at which a sliced launch with this slice_frac pauses a unit of out_cap bytes

@@ -278,7 +278,7 @@ struct xlz_batch {
     uint32_t *queue = nullptr;        // ... and their work-queue head
     bool pooled = false;      // made by xlz_decode_batch: its memory comes from and returns to the context's pool
     bool quiet = false;       // ... and nothing on the device uses it any more (else batch_free waits for the device first)
-    bool many_rounds = false; // a sub-batch of a pipelined call: the launch takes as many wave slots as a call of many rounds
+    uint32_t call_units = 0;  // a sub-batch of a pipelined call of that many streams: wave slots per CU as for ONE launch over all of them
     bool ran = false;
     uint64_t algo_in = 0; // compressed payload bytes handed to the device
     // per-stream results of the latest run (filled lazily by collect())
@@ -795,7 +795,7 @@ int batch_free(xlz_batch *b)
 struct BatchOpts {
     uint32_t want_slices = 1;
     uint32_t head_frac = 0;
-    bool many_rounds = false;        // xlz_batch::many_rounds
+    uint32_t call_units = 0;         // xlz_batch::call_units
     bool pooled = false;             // xlz_batch::pooled
     hipStream_t run_stream = nullptr; // xlz_batch::run_stream / queue (nullptr: the context's)
     uint32_t *queue = nullptr;
@@ -831,7 +831,7 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
     b->ctx = ctx;
     b->n = n;
     b->plans.resize(n);
-    b->many_rounds = opts.many_rounds;
+    b->call_units = opts.call_units;
     b->pooled = opts.pooled;
     b->run_stream = opts.run_stream;
     b->queue = opts.queue;
@@ -983,7 +983,7 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
     }
     // (units whose model lives in HBM -- lc + lp > 8 -- run in their own launch behind the slices; their streams are fetched at
     //  the end like the streams of a re-run)
-    if (want_slices > 1 && b->n_normal && b->n_normal <= decode_grid(b->max_lc_lp, ctx->num_cus, b->many_rounds ? ~0u : b->n_normal, b->compact)) {
+    if (want_slices > 1 && b->n_normal && b->n_normal <= decode_grid(b->max_lc_lp, ctx->num_cus, b->call_units ? b->call_units : b->n_normal, b->compact)) {
         // sliced batch: equal shares of every unit's output per launch; a state block per unit; per launch the table of
         // the pieces it finishes (unit order = arena order, packed back to back on 256-byte boundaries)
         // equal shares -- but the LAST share is cut in two (from four slices on): its download is the one nothing overlaps
@@ -1196,7 +1196,7 @@ extern "C" int xlz_batch_run(xlz_batch *b)
     p.results = b->d_results;
     p.queue = rq;
     p.prio_tab = ctx->prio_tab;
-    p.many_rounds = b->many_rounds ? 1u : 0u;
+    p.call_units = b->call_units;
     p.epochs = nullptr; // ordinary launch: copies that reach across a dictionary reset are only flagged
     if (b->n_normal) { // models in LDS
         p.n_units = b->n_normal;
@@ -1570,7 +1570,7 @@ extern "C" int xlz_batch_unit_trace(xlz_batch *b, uint32_t *t_start, uint32_t *t
 extern "C" int xlz_batch_launch_info(xlz_batch *b, uint32_t *workgroups, uint32_t *lds_bytes)
 {
     if (!b) return XLZ_ERR_BAD_ARG;
-    const uint32_t grid = std::min<uint32_t>(b->n_normal, decode_grid(b->max_lc_lp, b->ctx->num_cus, b->many_rounds ? ~0u : b->n_normal, b->compact));
+    const uint32_t grid = std::min<uint32_t>(b->n_normal, decode_grid(b->max_lc_lp, b->ctx->num_cus, b->call_units ? b->call_units : b->n_normal, b->compact));
     if (workgroups) *workgroups = grid;
     if (lds_bytes) *lds_bytes = decode_lds_bytes(b->max_lc_lp, b->compact);
     return XLZ_OK;
@@ -1580,7 +1580,7 @@ extern "C" const char *xlz_batch_kernel_name(xlz_batch *b)
 {
     if (!b) return "";
     if (!b->n_normal) return "xlz::xlz_decode_kernel_hbm_model";
-    if (decode_branchy(b->max_lc_lp, b->ctx->num_cus, b->many_rounds ? ~0u : b->n_normal, b->compact)) return "xlz::xlz_decode_kernel_pb2_br";
+    if (decode_branchy(b->max_lc_lp, b->ctx->num_cus, b->call_units ? b->call_units : b->n_normal, b->compact)) return "xlz::xlz_decode_kernel_pb2_br";
     return b->compact ? "xlz::xlz_decode_kernel_pb2" : "xlz::xlz_decode_kernel";
 }
 
@@ -1971,12 +1971,26 @@ extern "C" int xlz_ctx_last_call_stats(xlz_ctx *ctx, xlz_call_stats *out)
 // equal pieces of 4096 streams were measured on the 65 536 x 64 KiB batch: 6 % slower than eight -- while piece k drains
 // only piece k + 1 can fill its slots, and 4096 units do not fill 5120; profiles/r05/pipeline_pieces.txt.)  One sub-batch =
 // the call is one wave round (or too small to bother): it overlaps its copies with its own decode (slices).
-static void plan_sub_batches(const xlz_stream_desc *streams, size_t n, std::vector<size_t> &cuts)
+//
+// ROUNDS mode (*rounds = true): the streams are long -- a wave round of them (4096) is a GiB of output and more, i.e. hundreds
+// of milliseconds -- and the call has few rounds.  Overlapping pieces do nothing for such a call (8192 x 2 MiB are two rounds
+// whatever is done, and a quarter piece in front only misaligns them: measured 14.8 GiB/s host to host, then 12.0 with the
+// pieces at 16 per CU); instead every piece is exactly ONE round of 16 per CU, the pieces run one behind the other on ONE
+// stream, and each of them overlaps its copies with its own decode like a call of one round does (slices; piece k + 1's
+// upload runs under piece k's launches anyway).
+static void plan_sub_batches(const xlz_stream_desc *streams, size_t n, std::vector<size_t> &cuts, bool *rounds)
 {
     cuts.assign(1, 0);
+    *rounds = false;
     uint64_t total = 0;
     for (size_t i = 0; i < n; i++) total += streams[i].out_cap;
     const size_t k_round = 4096; // streams of one wave round (16 waves on each of 256 CUs)
+    if (n > 6144 && total / n >= (256u << 10)) { // (up to 6144 streams are ONE round of 20 / 24 per CU: one sliced piece)
+        *rounds = true;
+        for (size_t at = k_round; at < n; at += k_round) cuts.push_back(at);
+        cuts.push_back(n);
+        return;
+    }
     const size_t n_sub = std::min<size_t>(std::min<size_t>(8, n / k_round), (size_t)(total >> 29));
     if (n_sub >= 2) {
         // shares: 1/4, 1, ..., 1, 1/4 (n_sub - 1 whole ones)
@@ -2015,7 +2029,8 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     const auto t0 = std::chrono::steady_clock::now();
     auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     std::vector<size_t> cuts;
-    plan_sub_batches(streams, n, cuts);
+    bool rounds_mode = false;
+    plan_sub_batches(streams, n, cuts, &rounds_mode);
     const size_t S = cuts.size() - 1;
     xlz_call_stats cs;
     memset(&cs, 0, sizeof cs);
@@ -2033,7 +2048,7 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
     auto slices_for = [&](size_t k) -> uint32_t {
         // (in a pipeline the pieces overlap each other; slices of the first or last piece were measured there: the next
         //  piece's workgroups take the slots every slice boundary frees and the two pieces finish together)
-        if (S > 1) return 1;
+        if (S > 1 && !rounds_mode) return 1;
         uint64_t total = 0;
         for (size_t i = cuts[k]; i < cuts[k + 1]; i++) total += streams[i].out_cap;
         return total >= sliced_call_bytes ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(max_slices, total / slice_bytes)) : 1u;
@@ -2059,9 +2074,9 @@ extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, si
             BatchOpts o;
             o.want_slices = slices_for(k);
             o.head_frac = k == 0 ? head_frac_for(o.want_slices) : 0; // (only the first sub-batch's upload is exposed)
-            o.many_rounds = S > 1;
+            o.call_units = (S > 1 && !rounds_mode) ? (uint32_t)std::min<size_t>(n, 0xFFFFFFFFu) : 0u; // (streams: a lower bound of the call's units)
             o.pooled = true;
-            if (S > 1 && k % 2) o.run_stream = ctx->stream2, o.queue = ctx->queue2; // (xlz_ctx: stream2)
+            if (S > 1 && !rounds_mode && k % 2) o.run_stream = ctx->stream2, o.queue = ctx->queue2; // (xlz_ctx: stream2)
             const int st = batch_create_ex(ctx, streams + cuts[k], cuts[k + 1] - cuts[k], &b, o);
             if (dbg) fprintf(stderr, "xlz_decode_batch: sub-batch %zu uploaded at %.1f ms\n", k, now_ms());
             {

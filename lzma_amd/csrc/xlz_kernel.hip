@@ -1538,10 +1538,10 @@ int launch_decode(const LaunchParams &p, int num_cus, void *stream, uint32_t max
     const bool compact = p.compact != 0;
     const uint32_t lds = decode_lds_bytes(p.max_lc_lp, compact);
     if (lds > kMaxLdsBytes) return -1;
-    uint32_t grid = decode_grid(p.max_lc_lp, num_cus, p.many_rounds ? ~0u : p.n_units, compact);
+    uint32_t grid = decode_grid(p.max_lc_lp, num_cus, p.call_units ? p.call_units : p.n_units, compact);
     if (grid > p.n_units) grid = p.n_units;
     if (grid == 0) return 0;
-    const bool branchy = decode_branchy(p.max_lc_lp, num_cus, p.many_rounds ? ~0u : p.n_units, compact);
+    const bool branchy = decode_branchy(p.max_lc_lp, num_cus, p.call_units ? p.call_units : p.n_units, compact);
     const void *fn = branchy ? reinterpret_cast<const void *>(xlz_decode_kernel_pb2_br)
                      : compact ? reinterpret_cast<const void *>(xlz_decode_kernel_pb2) : reinterpret_cast<const void *>(xlz_decode_kernel);
     if (lds > 64u * 1024u && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes) != hipSuccess) return -2;

@@ -76,20 +76,23 @@ def test_one_stream_wraps_an_8_mib_window(ctx):
     assert got[1] == want[1]
 
 
-def test_a_call_of_several_wave_rounds_runs_as_a_pipeline(ctx):
-    """xlz_decode_batch with 12 288 streams / 3 GiB of output: four sub-batches (a quarter-size one in front and behind,
-    two whole ones) whose upload, decode and download overlap (xlz_call_stats.sub_batches) and whose launches follow each
-    other on two streams.  Host buffers in and out; every stream's bytes, status and consumed input as for the same
-    streams decoded alone -- including damaged streams in every sub-batch (one bad stream never fails the call) and an
-    empty one."""
+@pytest.mark.parametrize("n,size,pieces,sliced", [(12288, 256 << 10, 3, True), (16384, 128 << 10, 5, False)])
+def test_a_call_of_several_wave_rounds_runs_as_a_pipeline(ctx, n, size, pieces, sliced):
+    """xlz_decode_batch with more streams than the chip holds at once, host buffers in and out, in its two forms
+    (xlz_call_stats.sub_batches / slices).  12 288 streams of 256 KiB: LONG streams -- a wave round of them is a GiB -- run
+    as three pieces of exactly one round each, one behind the other, each overlapping its copies with its own decode
+    (slices).  16 384 streams of 128 KiB: five pieces (a quarter-size one in front and behind, three whole ones) whose
+    upload, decode and download overlap and whose launches follow each other on two streams.  Every stream's bytes, status
+    and consumed input as for the same streams decoded alone -- including damaged streams in every piece (one bad stream
+    never fails the call) and an empty one."""
     import ctypes
     import numpy as np
     from lzma_amd import _native as N
-    nd, n, size = 48, 12288, 256 << 10
+    nd = 48
     ps = [corpus.plain("TMZR"[i % 4], 93_000 + i, size) for i in range(nd)]
     cs = [corpus.compress_alone(p, preset=0) for p in ps]
     bad = {}
-    for j in (5, 4100, 4101, 9000, n - 1):      # damaged: a flipped byte deep inside, or cut short
+    for j in (5, 4100, 4101, 9000, 11000, n - 1):      # damaged: a flipped byte deep inside, or cut short
         c = bytearray(cs[j % nd])
         if j % 2:
             c[len(c) // 2] ^= 0x55
@@ -108,8 +111,8 @@ def test_a_call_of_several_wave_rounds_runs_as_a_pipeline(ctx):
     res = (N.Result * n)()
     assert N.lib().xlz_decode_batch(ctx._h, descs, n, res) == 0
     st = ctx.last_call_stats()
-    assert st["sub_batches"] == 4 and st["streams"] == n and st["units"] == n - 1   # (the empty stream has no unit)
-    assert 0.5 < st["slot_occupancy"] <= 1.0 and st["total_ms"] > 0
+    assert st["sub_batches"] == pieces and st["streams"] == n and st["units"] == n - 1   # (the empty stream has no unit)
+    assert (st["slices"] >= 4) == sliced and 0.3 < st["slot_occupancy"] <= 1.0 and st["total_ms"] > 0
     hs = [hashlib.sha256(p).digest() for p in ps]
     for i in range(n):
         if i in bad:

@@ -1,6 +1,6 @@
 """Dev tool (GPU box): host-buffers-in, host-buffers-out rate of xlz_decode_batch (the PCIe-inclusive path that a
 drop-in caller sees) for several settings of the sliced form (xlz_ctx_set_slicing), with the call's phase times.
-usage: python tools/host_path.py [family] [streams] [size] [distinct] [--slices 0,1,4,8] [--reps 4] [--preset6]   (0: the library's default rule)
+usage: python tools/host_path.py [family] [streams] [size] [distinct] [--slices 0,1,4,8] [--reps 4] [--preset6] [--lzma2 SEGMENTS] [--dict BYTES]   (--slices 0: the library's default rule)
 The corpus is bench.py's (liblzma MODE_FAST / HC3) unless --preset6."""
 import hashlib, os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,8 +17,14 @@ nd = int(args[3]) if len(args) > 3 else min(n, 512)
 slices = [int(x) for x in opts[opts.index("--slices") + 1].split(",")] if "--slices" in opts else [1, 2, 4, 8]
 reps = int(opts[opts.index("--reps") + 1]) if "--reps" in opts else 4
 preset = 6 if "--preset6" in opts else {"mode": 1, "mf": 3, "nice_len": 32, "depth": 2}
+segments = int(opts[opts.index("--lzma2") + 1]) if "--lzma2" in opts else 0   # every stream: one raw LZMA2 stream of that many segments of `size` bytes
+dict_size = int(opts[opts.index("--dict") + 1]) if "--dict" in opts else 65536
 t0 = time.time()
-cs, hs = corpus.make_alone_batch(fam, nd, size, workers=min(os.cpu_count() or 1, 64), preset=preset)
+if segments:
+    cs, hs = corpus.make_lzma2_batch(fam, nd, segments, size, workers=min(os.cpu_count() or 1, 64), preset=preset, dict_size=dict_size)
+    size *= segments
+else:
+    cs, hs = corpus.make_alone_batch(fam, nd, size, workers=min(os.cpu_count() or 1, 64), preset=preset, dict_size=dict_size)
 print("corpus %d distinct x %d B in %.1f s, ratio %.3f" % (nd, size, time.time() - t0, sum(map(len, cs)) / (nd * size)), flush=True)
 ctx = lzma_amd.Context(0)
 print("library:", N.library_info(), flush=True)
@@ -30,7 +36,8 @@ for i in range(n):
     descs[i].in_len = ins[i].size
     descs[i].out = out[i].ctypes.data
     descs[i].out_cap = size
-    descs[i].format = lzma_amd.FMT_LZMA_ALONE
+    descs[i].format = lzma_amd.FMT_LZMA2_RAW if segments else lzma_amd.FMT_LZMA_ALONE
+    descs[i].dict_size = dict_size if segments else 0
 res = (N.Result * n)()
 for k in slices:
     if k == 0:
