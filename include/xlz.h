@@ -201,11 +201,13 @@ typedef struct xlz_call_stats {
     uint32_t sub_batches;  /* > 1: the call ran as a pipeline (upload k+1 / decode k / download k-1); then
                               upload_ms = until the first sub-batch was on the device, decode_ms = first
                               launch to last results, download_ms = what was left after that            */
-    uint32_t slices;       /* > 1: a call of ONE wave round ran as a sequence of launches, each advancing every
-                              unit by a share of its output, the download of share k-1 under the decode of
-                              share k (the reference's Read pump in batch form, reader1.go:223-254); then
-                              decode_ms = the launches (HIP events), download_ms = what was left after them;
-                              slot_occupancy = the mean over the launches                                 */
+    uint32_t slices;       /* > 1: a call of ONE wave round -- or every one-round piece of a call of few rounds
+                              of long streams (sub_batches > 1) -- ran as a sequence of that many launches, each
+                              advancing every unit by a share of its output, the download of share k-1 under
+                              the decode of share k (the reference's Read pump in batch form,
+                              reader1.go:223-254); for a call of one piece decode_ms = the launches (HIP
+                              events), download_ms = what was left after them; slot_occupancy = the mean over
+                              the launches                                                                */
     uint32_t reserved;
 } xlz_call_stats;
 int xlz_ctx_last_call_stats(xlz_ctx *ctx, xlz_call_stats *out);

@@ -132,6 +132,10 @@ def test_the_bench_line_is_compact_and_round_trips():
             "stream_count_sweep": {"points": [{"streams": k, "cpu_baseline": dict(cpu)} for k in (64, 256, 1024, 4096)],
                                    "break_even_streams": 256, "note": "n" * 200},
             "containers": [{"name": "xz-blocks", "value": 4.31, "workload": "w" * 300}],
+            "scaling_projection": {"label": "l" * 100, "n1_value": 17.6, "note": "n" * 300,
+                                   "points": [{"n_gpus": k, "streams_on_rank_0": 65536 // k, "wave_slots": 6144, "rounds": 5.33, "ms_per_step": 110.9,
+                                               "ms_per_step_wall_mean": 111.2, "steps_ms": [110.9] * 5, "value_projected": 36.057,
+                                               "efficiency_projected": 1.0242} for k in (2, 4, 8)]},
             "configs": [{"name": n, "workload": bench.workload_text(n, bench.CONFIGS[n]), "baseline_config": bench.CONFIGS[n]["baseline"],
                          "value": 17.2412, "value_wall": 17.1234, "kernel_ms": 232.123, "roofline": _stub_roofline(n), "cpu_baseline": dict(cpu)}
                         for n in bench.SIDE_ALL]}
@@ -154,11 +158,13 @@ def test_the_bench_line_is_compact_and_round_trips():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in back["cpu_baseline"], k
     assert [c["name"] for c in back["configs"]] == bench.SIDE_ALL
+    assert [pt[0] for pt in back["scaling_projection"]["points"]] == [2, 4, 8] and "one GPU" in back["scaling_projection"]["label"]
     # (value = bytes / HIP-event time, value_wall = bytes / host wall time: ADVICE r4 -- two definitions, two keys)
     assert all(set(c) == {"name", "value", "value_wall", "kernel_ms", "frac", "frac_of_bound", "binding", "cpu", "cpu_cores"} for c in back["configs"])
     assert "value_wall" in back["configs_unit"]
     # an N > 1 line (no side configs, no cpu baseline) is a valid line too
-    multi = dict(full, n_gpus=8, cpu_baseline=None, configs=None, host_to_host=None, stream_count_sweep=None, containers=None)
+    multi = dict(full, n_gpus=8, cpu_baseline=None, configs=None, host_to_host=None, stream_count_sweep=None, containers=None,
+                 scaling_projection=None)
     small = bench.compact_line(multi)
     assert small["cpu_baseline"] is None and "configs" not in small and len(json.dumps(small)) < 2500
 
