@@ -150,6 +150,13 @@ int xlz_ctx_batching_stats(xlz_ctx *ctx, uint64_t *batches, uint64_t *streams);
  * per 16 host cores decode on the CPU, or gather more streams first;
  * xlz_batch_advice answers that question for a given call before anything is uploaded.  */
 int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_result *results);
+/* Host only (no device needed; only out_cap of every stream is looked at): how xlz_decode_batch would cut this call into
+ * pieces.  cuts[k] = index of the first stream of piece k, one entry more than there are pieces (the last is n); *n_cuts =
+ * entries (XLZ_ERR_OUT_CAP if max_cuts is smaller; cuts may be NULL with max_cuts = 0 to ask for the count); *mode (may be
+ * NULL): 0 one piece (a call of one wave round overlaps its copies with its own decode: slices), 1 a pipeline of pieces
+ * whose launches overlap on two streams (many short streams), 2 pieces of exactly one wave round of 4096 streams, one
+ * behind the other, each sliced (few rounds of long streams: 256 KiB and more on average).                          */
+int xlz_decode_batch_plan(const xlz_stream_desc *streams, size_t n, size_t *cuts, size_t max_cuts, size_t *n_cuts, int *mode);
 
 /* BEFORE uploading anything: how much of a GPU would this call fill, and is the host the faster
  * decoder for it?  Host only (reads stream and LZMA2 chunk headers; no device needed; `ctx` may be

@@ -163,6 +163,21 @@ def decode_batch(ctx, streams):
     return [(outs[i].raw[: res[i].out_len], res[i].status, res[i].in_consumed) for i in range(n)]
 
 
+def decode_batch_plan(out_caps):
+    """xlz_decode_batch_plan (host only): how decode_batch would cut a call of streams with these output capacities into
+    pieces -> (list of the pieces' first stream indices + [n], mode: 0 one piece, 1 overlapped pieces, 2 one-round pieces)"""
+    n = len(out_caps)
+    descs = (N.StreamDesc * max(n, 1))()
+    for i, c in enumerate(out_caps):
+        descs[i].out_cap = int(c)
+    cuts = (ctypes.c_size_t * (n + 2))()
+    k, mode = ctypes.c_size_t(), ctypes.c_int32()
+    st = N.lib().xlz_decode_batch_plan(descs, n, cuts, n + 2, ctypes.byref(k), ctypes.byref(mode))
+    if st != OK:
+        raise LzmaError(st, "xlz_decode_batch_plan")
+    return list(cuts[: k.value]), mode.value
+
+
 def batch_advice(streams, host_threads=0, ctx=None):
     """xlz_batch_advice: what a decode of `streams` would launch and whether the host's cores are the faster decoder
     for it -- host only, nothing is uploaded.  -> dict (units, in_bytes, wave_slots, break_even_units, fill, prefer_cpu)"""

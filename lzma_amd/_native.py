@@ -45,7 +45,7 @@ EXPORTS = [
     "xlz_new_lzma_decompressor_for_sevenzip", "xlz_new_lzma2_decompressor_for_sevenzip",
     "xlz_reader_read", "xlz_reader_close", "xlz_reader_free", "xlz_xz_index", "xlz_xz_decode",
     "xlz_decode_batch_multi", "xlz_decode_batch_multi_plan", "xlz_xz_decode_multi", "xlz_7z_decode_multi", "xlz_batch_unit_trace", "xlz_reader_stats", "xlz_reader_memory", "xlz_batch_advice", "xlz_batch_launch_info", "xlz_reader_reset", "xlz_reader_reopen", "xlz_reader_expect_more", "xlz_reader_feed", "xlz_reader_feed_eof", "xlz_7z_index", "xlz_7z_decode",
-    "xlz_lzma2_units", "xlz_ctx_set_slicing", "xlz_ctx_trim", "xlz_batch_kernel_name",
+    "xlz_lzma2_units", "xlz_ctx_set_slicing", "xlz_ctx_trim", "xlz_batch_kernel_name", "xlz_decode_batch_plan",
 ]
 
 
@@ -192,6 +192,7 @@ def lib():
     L.xlz_ctx_last_call_stats.argtypes = [vp, ctypes.POINTER(CallStats)]
     L.xlz_ctx_set_slicing.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
     L.xlz_ctx_trim.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.xlz_decode_batch_plan.argtypes = [ctypes.POINTER(StreamDesc), sz, ctypes.POINTER(sz), sz, ctypes.POINTER(sz), ctypes.POINTER(i32)]
     L.xlz_batch_kernel_name.argtypes = [vp]
     L.xlz_batch_kernel_name.restype = ctypes.c_char_p
     L.xlz_batch_create.argtypes = [vp, ctypes.POINTER(StreamDesc), sz, ctypes.POINTER(vp)]

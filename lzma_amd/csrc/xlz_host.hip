@@ -2014,6 +2014,18 @@ static void plan_sub_batches(const xlz_stream_desc *streams, size_t n, std::vect
     cuts.push_back(n);
 }
 
+extern "C" int xlz_decode_batch_plan(const xlz_stream_desc *streams, size_t n, size_t *cuts, size_t max_cuts, size_t *n_cuts, int *mode)
+{
+    if ((!streams && n) || !n_cuts || (!cuts && max_cuts)) return XLZ_ERR_BAD_ARG;
+    std::vector<size_t> c;
+    bool rounds = false;
+    plan_sub_batches(streams, n, c, &rounds);
+    *n_cuts = c.size();
+    for (size_t k = 0; k < c.size() && k < max_cuts; k++) cuts[k] = c[k];
+    if (mode) *mode = c.size() <= 2 ? 0 : rounds ? 2 : 1;
+    return max_cuts && c.size() > max_cuts ? XLZ_ERR_OUT_CAP : XLZ_OK;
+}
+
 extern "C" int xlz_decode_batch(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t n, xlz_result *results)
 {
     if (!ctx || (!streams && n) || (!results && n)) return XLZ_ERR_BAD_ARG;

@@ -262,3 +262,31 @@ def test_the_units_of_one_stream_are_dealt_to_several_contexts():
     small, _ = plan([stored(3000, True) for _ in range(10)])
     assert [it["whole"] for it in lzma_amd.multi_plan(3, [lzma_amd.Stream(small, lzma_amd.FMT_LZMA2_RAW, out_cap=30000)])] == [True]
     assert all(it["whole"] and it["context"] == 0 for it in lzma_amd.multi_plan(1, streams))
+
+
+def test_how_a_call_is_cut_into_pieces():
+    """xlz_decode_batch_plan (round 5, host only): the three forms of xlz_decode_batch.  Up to 6144 streams are ONE piece
+    (one wave round of 16 / 20 / 24 per CU: slices); many short streams are a pipeline of overlapping pieces -- a quarter
+    share, up to seven whole ones, a quarter share --; few rounds of LONG streams (256 KiB and more on average) are pieces of
+    exactly one round of 4096 streams, one behind the other."""
+    KiB, MiB = 1 << 10, 1 << 20
+    assert lzma_amd.decode_batch_plan([MiB] * 4096) == ([0, 4096], 0)                 # BASELINE configs[1]
+    assert lzma_amd.decode_batch_plan([MiB] * 6000) == ([0, 6000], 0)                 # one round of 24 per CU
+    assert lzma_amd.decode_batch_plan([64 * KiB] * 7000) == ([0, 7000], 0)            # too small to bother
+    assert lzma_amd.decode_batch_plan([]) == ([0, 0], 0)
+    cuts, mode = lzma_amd.decode_batch_plan([64 * KiB] * 65536)                       # BASELINE configs[2]: the headline
+    assert mode == 1 and len(cuts) == 10 and cuts[0] == 0 and cuts[-1] == 65536
+    sizes = [b - a for a, b in zip(cuts, cuts[1:])]
+    assert 2000 <= sizes[0] <= 2400 and 2000 <= sizes[-1] <= 2400 and all(8600 <= x <= 8900 for x in sizes[1:-1])
+    assert lzma_amd.decode_batch_plan([2 * MiB] * 8192) == ([0, 4096, 8192], 2)       # BASELINE configs[4]
+    assert lzma_amd.decode_batch_plan([MiB] * 16384) == ([0, 4096, 8192, 12288, 16384], 2)
+    assert lzma_amd.decode_batch_plan([256 * KiB] * 12288) == ([0, 4096, 8192, 12288], 2)
+    assert lzma_amd.decode_batch_plan([MiB] * 6200) == ([0, 4096, 6200], 2)
+    cuts, mode = lzma_amd.decode_batch_plan([128 * KiB] * 16384)
+    assert mode == 1 and len(cuts) == 6
+    # unequal streams: the pieces are equal shares of the OUTPUT
+    caps = [32 * KiB] * 30000 + [96 * KiB] * 30000
+    cuts, mode = lzma_amd.decode_batch_plan(caps)
+    assert mode == 1 and cuts[-1] == 60000
+    share = [sum(caps[a:b]) for a, b in zip(cuts, cuts[1:])]
+    assert max(share[1:-1]) < 1.1 * min(share[1:-1])
