@@ -168,9 +168,10 @@ def test_committed_loop_decodes_real_streams_on_the_emulator(program, family, n,
     assert in_pos == rc.p and s["prev"] == p[len(out) - 1]
 
 
-@pytest.mark.parametrize("family,n,lc,lp,pb,ds", [("T", 6000, 3, 0, 2, 1 << 16), ("R", 1500, 3, 0, 2, 1 << 16), ("M", 5000, 0, 2, 0, 4096),
-                                                  ("Z", 9000, 1, 1, 1, 4096), ("T", 5000, 4, 0, 2, 5000), ("M", 4000, 2, 2, 1, 1 << 16)])
-@pytest.mark.parametrize("branchy", [False, True])
+@pytest.mark.parametrize("family,n,lc,lp,pb,ds,branchy", [
+    ("T", 5000, 3, 0, 2, 1 << 16, False), ("R", 1500, 3, 0, 2, 1 << 16, False), ("M", 4000, 0, 2, 0, 4096, False),
+    ("Z", 9000, 1, 1, 1, 4096, False), ("M", 3000, 2, 2, 1, 1 << 16, False),
+    ("T", 5000, 3, 0, 2, 1 << 16, True), ("R", 1500, 3, 0, 2, 1 << 16, True), ("Z", 9000, 1, 1, 1, 4096, True), ("M", 3000, 2, 2, 1, 5000, True)])
 def test_compact_loop_decodes_real_streams_on_the_emulator(family, n, lc, lp, pb, ds, branchy):
     """round 5: the COMMITTED loops over the compact model layout (xlz_fastpath_pb2.inc: room for 4 posStates in every
     table a posState indexes; what launches use when every unit's pb is <= 2 -- and xlz_fastpath_pb2_br.inc, the same with
