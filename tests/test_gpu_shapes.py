@@ -236,3 +236,42 @@ def test_a_call_of_5000_streams_is_one_round_of_20_per_cu(ctx):
     assert st["wave_slots"] == n and 4096 < n <= 20 * 256      # (the grid is the units: all of them resident at once)
     assert got[1234] == oracle.lzma1_alone(comp[1234], size)
     assert all(g[1] == 0 and hashlib.sha256(g[0]).digest() == d for i, (g, d) in enumerate(zip(got, digests)) if i != 1234)
+
+
+def test_concurrent_calls_on_one_context(ctx):
+    """xlz_decode_batch is thread-safe across calls on ONE context (include/xlz.h): the pinned input image is leased to one
+    call at a time (a sliced call keeps it until the tails of its inputs have left it), the pinned output ring likewise,
+    the context's memory pool and its two launch streams are shared.  Four threads -- two sliced calls of one wave round,
+    two small plain calls, three times each -- and every result as for the same streams decoded alone."""
+    import threading
+    sets = []
+    for t in range(4):
+        n, size = (600, 64 << 10) if t < 2 else (40, 20_000)
+        ps = [corpus.plain("TMZR"[(i + t) % 4], 98_000 + 1000 * t + i, size) for i in range(24)]
+        cs = [corpus.compress_alone(p, preset=0) for p in ps]
+        streams = [Stream(cs[i % 24] if (i + t) % 17 else cs[i % 24][: len(cs[i % 24]) // 2], FMT_LZMA_ALONE, out_cap=size) for i in range(n)]
+        sets.append(streams)
+    want = []
+    ctx.set_slicing(0, 0, 1)
+    for s in sets:
+        want.append(lzma_amd.decode_batch(ctx, s))      # alone, unsliced
+    assert all(w[1] in (0, 1) and len(w[0]) > 0 for ws in want for w in ws)
+    ctx.set_slicing(1, 4 << 20, 6)                       # (calls of 4 MiB and more run in slices: the first two sets)
+    errors = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                got = lzma_amd.decode_batch(ctx, sets[k])
+                assert got == want[k], "thread %d" % k
+        except BaseException as e:   # noqa: BLE001 -- reported below
+            errors.append(e)
+    try:
+        th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+    finally:
+        ctx.set_slicing(0, 0, 0)
+    assert not errors, errors[0]
