@@ -172,8 +172,8 @@ struct MemPool {
 constexpr int kEventSlots = 64; // xlz_ctx_event_record: enough for one event per timed step of bench.py
 
 struct HostPipe {
-    static constexpr int kRing = 4;
-    static constexpr size_t kRingBytes = 64u << 20;
+    static constexpr int kRing = 8;                 // (round 5: eight slots of 32 MiB instead of four of 64: as many scatter threads
+    static constexpr size_t kRingBytes = 32u << 20; //  work on the LAST slice of a call, whose scatter nothing overlaps)
     std::mutex mu_in;  // the pinned input image: one pack + upload at a time per context (PinLease)
     std::condition_variable cv_in;
     bool in_busy = false;
