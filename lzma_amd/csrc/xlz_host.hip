@@ -978,7 +978,9 @@ static int batch_create_ex(xlz_ctx *ctx, const xlz_stream_desc *streams, size_t 
     }
     if (b->n_normal) { // the matched-literal half of every resident model (xlz_format.h)
         b->mlit_stride = num_matched_probs(b->max_lc_lp);
-        const size_t slots = (size_t)decode_grid(b->max_lc_lp, ctx->num_cus, ~0u, b->compact);
+        // one slot per workgroup of the largest grid any launch over these units can have -- the main launch, or a re-run of
+        // some of them (run_units): never more workgroups than units (a call of eight streams does not need 6144 slots: 53 MB)
+        const size_t slots = std::min<size_t>(b->n_normal, decode_grid(b->max_lc_lp, ctx->num_cus, ~0u, b->compact));
         if (!batch_alloc(b, &b->d_mlit, slots * b->mlit_stride * sizeof(uint16_t))) return fail(XLZ_ERR_DEVICE);
     }
     // (units whose model lives in HBM -- lc + lp > 8 -- run in their own launch behind the slices; their streams are fetched at

@@ -275,3 +275,21 @@ def test_concurrent_calls_on_one_context(ctx):
     finally:
         ctx.set_slicing(0, 0, 0)
     assert not errors, errors[0]
+
+
+def test_the_context_keeps_what_the_last_calls_used_and_no_more(ctx):
+    """xlz_decode_batch keeps its device and pinned memory in the context between calls (MemPool): a call of the same shape
+    finds its blocks again, and what two calls in a row did not touch goes back to the system -- a context does not grow with
+    every shape it has ever seen (xlz_ctx_trim says how much is kept and releases it)."""
+    big = [Stream(corpus.compress_alone(corpus.plain("T", 99_000 + i, 1 << 20), preset=0), FMT_LZMA_ALONE, out_cap=1 << 20) for i in range(96)]
+    small = [Stream(corpus.compress_alone(corpus.plain("T", 99_500 + i, 20_000), preset=0), FMT_LZMA_ALONE, out_cap=20_000) for i in range(8)]
+    ctx.trim()
+    want_big, want_small = lzma_amd.decode_batch(ctx, big), lzma_amd.decode_batch(ctx, small)
+    kept_both = ctx.trim()
+    assert kept_both >= 96 << 20                      # (at least the big call's output arena was being kept)
+    assert lzma_amd.decode_batch(ctx, big) == want_big
+    for _ in range(3):                                # three small calls in a row: the big call's blocks are let go
+        assert lzma_amd.decode_batch(ctx, small) == want_small
+    kept_small = ctx.trim()
+    assert kept_small < 8 << 20 and ctx.trim() == 0
+    assert lzma_amd.decode_batch(ctx, big) == want_big and all(g[1] == 0 for g in want_big)
