@@ -212,7 +212,7 @@ NEXT = ("slot0", "vprev", "rmov", "nopos", "l7blk", "warel", "vreps")   # round 
 def test_generator_switches_still_decode(add, remove):
     """the code paths kept in the generator as measured alternatives (profiles/r02/layout_scan.md)
     are not dead code: each of them decodes a stream correctly on the emulator"""
-    lc, lp, pb, ds, n = 3, 0, 2, 1 << 16, 2600
+    lc, lp, pb, ds, n = 3, 0, 2, 1 << 16, 1800
     p = corpus.plain("T", 99, n)
     blob = corpus.compress_alone(p, dict_size=ds, lc=lc, lp=lp, pb=pb, known_size=True, preset=6)
     out, m, entries, exits, in_pos = run_fast_loop(_render(add, remove), blob[13:], lc, lp, pb, ds, n, p, dpp="hdpp" not in remove)
