@@ -1,5 +1,6 @@
 """Mutation fuzz of the HOST-ONLY parsers (xlz_xz_index, xlz_7z_index without an encoded header, xlz_lzma2_units -- the
-chunk-header scan behind every raw LZMA2 decode): no GPU needed.  Valid .xz files (liblzma) and hand-built .7z archives (tests/sevenzip_craft.py) are truncated,
+chunk-header scan behind every raw LZMA2 decode) and planners (xlz_batch_advice, xlz_decode_batch_plan,
+xlz_decode_batch_multi_plan): no GPU needed.  Valid .xz files (liblzma) and hand-built .7z archives (tests/sevenzip_craft.py) are truncated,
 bit-flipped, overwritten near their ends / inside the 7z end header (its CRCs fixed up so that the parser
 gets that far).  A parse must either fail with a status or describe byte ranges inside the file.
 Under AddressSanitizer (CPU build only; the pool refuses GPU ASan):
@@ -165,9 +166,71 @@ def fuzz_lzma2_units(seconds, seed):
     return n, units
 
 
+def fuzz_plans(seconds, seed):
+    """-> (calls, items dealt).  The host-only planners behind a batch call: xlz_batch_advice (the break-even rule),
+    xlz_decode_batch_plan (how a call is cut into pieces) and xlz_decode_batch_multi_plan (what goes to which GPU) on
+    descriptors of every format with mutated inputs, odd capacities and odd properties.  No device, nothing is decoded: the
+    answers must be consistent with the descriptors whatever the bytes say."""
+    import corpus
+    rnd = random.Random(seed)
+    alone = [corpus.compress_alone(corpus.plain(f, seed + n, n), dict_size=1 << 16, known_size=k, preset=0)
+             for f, n, k in (("T", 20_000, True), ("R", 5_000, True), ("M", 60_000, False), ("Z", 100, True))]
+    raw2 = [corpus.compress_raw_lzma2(corpus.plain(f, seed + n, n), dict_size=1 << 16, preset=0) for f, n in (("T", 300_000), ("R", 150_000))]
+    raw2.append(corpus.lzma2_concat([corpus.plain("TR"[i % 2], seed + i, 70_000) for i in range(40)], dict_size=1 << 16, preset=0))
+    t_end = time.time() + seconds
+    calls = dealt = 0
+    while time.time() < t_end:
+        streams = []
+        for _ in range(rnd.choice([0, 1, 1, 2, 5, 40, 300])):
+            k = rnd.randrange(4)
+            cap = rnd.choice([0, 1, 4096, 70_000, 300_000, 1 << 22, (1 << 32) + 5, rnd.randrange(1 << 20)])
+            if k == 0:
+                b = rnd.choice(alone)
+                b = bytes(_mutate(rnd, b, tail_from=0)) if rnd.random() < 0.5 else b
+                streams.append(lzma_amd.Stream(b, lzma_amd.FMT_LZMA_ALONE, out_cap=cap))
+            elif k == 1:
+                b = rnd.choice(raw2)
+                b = bytes(_mutate(rnd, b, tail_from=0)) if rnd.random() < 0.5 else b
+                streams.append(lzma_amd.Stream(b, lzma_amd.FMT_LZMA2_RAW, out_cap=cap, dict_size=rnd.choice([0, 4096, 1 << 16, 1 << 26, 0xFFFFFFFF])))
+            elif k == 2:
+                b = rnd.choice(alone)[13:]
+                streams.append(lzma_amd.Stream(b, lzma_amd.FMT_LZMA_RAW, out_cap=cap, dict_size=rnd.choice([0, 1 << 16, 0xFFFFFFFF]),
+                                               unpack_size=rnd.choice([cap, lzma_amd.UNKNOWN_SIZE, 0]), props=rnd.randrange(256)))
+            else:
+                streams.append(lzma_amd.Stream(bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 40))),
+                                               rnd.choice([lzma_amd.FMT_LZMA_ALONE, lzma_amd.FMT_LZMA2_RAW, lzma_amd.FMT_LZMA_RAW, 7]), out_cap=cap,
+                                               props=rnd.randrange(256)))
+        calls += 1
+        threads = rnd.choice([0, 1, 16, 192, 1 << 20])
+        try:
+            adv = lzma_amd.batch_advice(streams, host_threads=threads)
+            assert adv["prefer_cpu"] in (0, 1) and adv["in_bytes"] == sum(len(s.data) for s in streams), adv
+            assert adv["cpu_cost"] >= 0 and adv["gpu_cost"] >= 0 and 0 <= adv["fill"], adv   # (a stream that does not plan launches no unit)
+        except lzma_amd.LzmaError:
+            pass
+        cuts, mode = lzma_amd.decode_batch_plan([s.out_cap for s in streams])
+        assert mode in (0, 1, 2) and cuts[0] == 0 and cuts[-1] == len(streams) and all(a < b for a, b in zip(cuts, cuts[1:])) or not streams, (cuts, mode)
+        n_ctx = rnd.choice([1, 2, 3, 8])
+        try:
+            items = lzma_amd.multi_plan(n_ctx, streams)
+        except lzma_amd.LzmaError:
+            continue
+        dealt += len(items)
+        seen = {}
+        for it in items:   # every stream's items: adjacent, in order, inside the descriptor, on a context that exists
+            s = streams[it["stream"]]
+            assert 0 <= it["context"] < n_ctx and it["in_off"] + it["in_len"] <= len(s.data) and it["out_off"] + it["out_len"] <= max(s.out_cap, it["out_off"] + it["out_len"] if it["whole"] else 0), (it, len(s.data), s.out_cap)
+            at = seen.get(it["stream"])
+            assert (at is None) == it["first"] and (at is None or at == (it["in_off"], it["out_off"])), (it, at)
+            seen[it["stream"]] = (it["in_off"] + it["in_len"], it["out_off"] + it["out_len"])
+        assert sorted(seen) == list(range(len(streams))), (sorted(seen)[:5], len(streams))
+    return calls, dealt
+
+
 if __name__ == "__main__":
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     print("xz_index: %d inputs, %d parsed" % fuzz_xz(secs, seed))
     print("7z_index: %d inputs, %d parsed" % fuzz_7z(secs, seed))
     print("lzma2_units: %d inputs, %d units planned" % fuzz_lzma2_units(secs, seed))
+    print("advice / piece plan / multi-GPU plan: %d calls, %d items dealt" % fuzz_plans(secs, seed))
