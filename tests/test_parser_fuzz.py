@@ -27,3 +27,10 @@ def test_mutated_7z_archives_parse_or_fail_cleanly(xlz_so):
 def test_lzma2_unit_plans_tile_whatever_the_headers_say():
     n, units = _tool().fuzz_lzma2_units(3.0, 2026)
     assert n > 200 and units >= n
+
+
+def test_batch_planners_answer_consistently_whatever_the_descriptors_say(xlz_so):
+    """xlz_batch_advice, xlz_decode_batch_plan and xlz_decode_batch_multi_plan on descriptors of every format with mutated
+    inputs and odd capacities: no device, nothing decoded; the assertions are the tool's own"""
+    calls, dealt = _tool().fuzz_plans(4.0, 2026)
+    assert calls > 50 and dealt > calls
